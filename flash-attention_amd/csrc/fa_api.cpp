@@ -1,0 +1,174 @@
+// C-ABI entry points of libfa_gfx950.so (declared in include/fa_gfx950.h).
+//
+// Host layer of the hot path: validates the contract, normalises (causal, window) exactly as the
+// reference host functions do, fills the device-side parameter block and enqueues the kernels.
+// Behavioural spec: reference csrc/flash_attn/flash_api.cpp -- mha_fwd :368-536,
+// mha_varlen_fwd :538-788, mha_bwd :800-1008, mha_varlen_bwd :1010-1241, set_params_fprop :44-177
+// (window/causal normalisation :155-162 and :422-427).  No ATen here: buffers are caller-owned.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/fa_gfx950.h"
+#include "fa_kernel_params.h"
+#include "fa_launch.h"
+
+namespace {
+
+thread_local char g_err[512] = {0};
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+bool head_dim_native(int d) { return d == 64 || d == 128; }
+
+// Reference flash_api.cpp:422-427 (+ :155-162): windows at least as wide as the key sequence are
+// unbounded, a single query row needs no causal mask, causal means window_right = 0.
+void normalize_window(int seqlen_q, int seqlen_k, bool has_alibi, int& is_causal, int& wl, int& wr) {
+  if (wl >= seqlen_k) wl = -1;
+  if (wr >= seqlen_k) wr = -1;
+  if (seqlen_q == 1 && !has_alibi) is_causal = 0;
+  if (is_causal) wr = 0;
+  if (wl < 0) wl = -1;
+  if (wr < 0) wr = -1;
+}
+
+int check_common(int b, int h, int h_k, int d, int dtype, float softcap) {
+  if (b <= 0) return fail(FA_ERR_INVALID_ARGUMENT, "batch size must be positive");
+  if (h <= 0 || h_k <= 0 || h % h_k != 0)
+    return fail(FA_ERR_INVALID_ARGUMENT, "Number of heads in key/value must divide number of heads in query");
+  if (d <= 0 || d > 256 || d % 8 != 0)
+    return fail(FA_ERR_INVALID_ARGUMENT, "head dimension must be a multiple of 8 and at most 256");
+  if (dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_BF16)
+    return fail(FA_ERR_INVALID_ARGUMENT, "FlashAttention only supports fp16 and bf16 data type");
+  if (!head_dim_native(d))
+    return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: head dimension %d is not built natively (64, 128); pad to the next one on the host", d);
+  if (softcap < 0.f) return fail(FA_ERR_INVALID_ARGUMENT, "softcap must be non-negative");
+  return FA_OK;
+}
+
+int do_fwd(const FaFwdParams* a, void* stream, bool varlen) {
+  if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+  g_err[0] = 0;
+  if (int rc = check_common(a->b, a->h, a->h_k, a->d, a->dtype, a->softcap)) return rc;
+  if (!a->q || !a->k || !a->v || !a->o || !a->softmax_lse)
+    return fail(FA_ERR_INVALID_ARGUMENT, "q, k, v, o and softmax_lse must be non-NULL");
+  if (varlen != (a->cu_seqlens_q != nullptr) || varlen != (a->cu_seqlens_k != nullptr))
+    return fail(FA_ERR_INVALID_ARGUMENT, varlen ? "fa_varlen_fwd needs cu_seqlens_q and cu_seqlens_k"
+                                                : "fa_fwd takes fixed-length batches (cu_seqlens must be NULL)");
+  if (a->seqlen_q < 0 || a->seqlen_k < 0) return fail(FA_ERR_INVALID_ARGUMENT, "negative sequence length");
+  if (a->seqlen_q == 0 || a->total_q == 0) return FA_OK;  // nothing to write
+
+  fa::FwdK k{};
+  k.q = a->q; k.k = a->k; k.v = a->v; k.o = a->o; k.lse = a->softmax_lse;
+  k.q_bs = a->q_batch_stride; k.q_rs = a->q_row_stride; k.q_hs = a->q_head_stride;
+  k.k_bs = a->k_batch_stride; k.k_rs = a->k_row_stride; k.k_hs = a->k_head_stride;
+  k.v_bs = a->v_batch_stride; k.v_rs = a->v_row_stride; k.v_hs = a->v_head_stride;
+  k.o_bs = a->o_batch_stride; k.o_rs = a->o_row_stride; k.o_hs = a->o_head_stride;
+  k.cu_q = a->cu_seqlens_q; k.cu_k = a->cu_seqlens_k; k.seqused_k = a->seqused_k;
+  k.alibi = a->alibi_slopes; k.alibi_bs = a->alibi_batch_stride;
+  k.b = a->b; k.h = a->h; k.h_k = a->h_k; k.hk_ratio = a->h / a->h_k;
+  k.sq = a->seqlen_q; k.sk = a->seqlen_k; k.total_q = a->total_q;
+  int causal = a->is_causal, wl = a->window_left, wr = a->window_right;
+  normalize_window(a->seqlen_q, a->seqlen_k, a->alibi_slopes != nullptr, causal, wl, wr);
+  k.wl = wl; k.wr = wr;
+  k.scale = a->softmax_scale;
+  k.scale_log2 = a->softmax_scale * 1.4426950408889634f;
+  k.softcap = a->softcap;
+
+  int nw = env_int("FA_FWD_NW", 0);
+  if (nw != 4 && nw != 8) nw = (a->seqlen_q <= 128) ? 4 : 8;
+  const int bm = fa::fwd_block_m(nw);
+  k.nmb = (a->seqlen_q + bm - 1) / bm;
+  const int rc = fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
+  if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
+  if (rc != 0) return fail(FA_ERR_LAUNCH, "forward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return FA_OK;
+}
+
+int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
+  if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+  g_err[0] = 0;
+  if (int rc = check_common(a->b, a->h, a->h_k, a->d, a->dtype, a->softcap)) return rc;
+  if (!a->dout || !a->q || !a->k || !a->v || !a->o || !a->softmax_lse || !a->dq || !a->dk || !a->dv || !a->softmax_d)
+    return fail(FA_ERR_INVALID_ARGUMENT, "dout, q, k, v, o, softmax_lse, dq, dk, dv and softmax_d must be non-NULL");
+  if (varlen != (a->cu_seqlens_q != nullptr) || varlen != (a->cu_seqlens_k != nullptr))
+    return fail(FA_ERR_INVALID_ARGUMENT, varlen ? "fa_varlen_bwd needs cu_seqlens_q and cu_seqlens_k"
+                                                : "fa_bwd takes fixed-length batches (cu_seqlens must be NULL)");
+  if (a->softcap > 0.f) return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: softcap backward is not built yet");
+  k = fa::BwdK{};
+  k.dout = a->dout; k.q = a->q; k.k = a->k; k.v = a->v; k.o = a->o; k.lse = a->softmax_lse;
+  k.dq = a->dq; k.dk = a->dk; k.dv = a->dv; k.delta = a->softmax_d;
+  k.do_bs = a->do_batch_stride; k.do_rs = a->do_row_stride; k.do_hs = a->do_head_stride;
+  k.q_bs = a->q_batch_stride; k.q_rs = a->q_row_stride; k.q_hs = a->q_head_stride;
+  k.k_bs = a->k_batch_stride; k.k_rs = a->k_row_stride; k.k_hs = a->k_head_stride;
+  k.v_bs = a->v_batch_stride; k.v_rs = a->v_row_stride; k.v_hs = a->v_head_stride;
+  k.o_bs = a->o_batch_stride; k.o_rs = a->o_row_stride; k.o_hs = a->o_head_stride;
+  k.dq_bs = a->dq_batch_stride; k.dq_rs = a->dq_row_stride; k.dq_hs = a->dq_head_stride;
+  k.dk_bs = a->dk_batch_stride; k.dk_rs = a->dk_row_stride; k.dk_hs = a->dk_head_stride;
+  k.dv_bs = a->dv_batch_stride; k.dv_rs = a->dv_row_stride; k.dv_hs = a->dv_head_stride;
+  k.cu_q = a->cu_seqlens_q; k.cu_k = a->cu_seqlens_k;
+  k.alibi = a->alibi_slopes; k.alibi_bs = a->alibi_batch_stride;
+  k.b = a->b; k.h = a->h; k.h_k = a->h_k; k.hk_ratio = a->h / a->h_k;
+  k.sq = a->seqlen_q; k.sk = a->seqlen_k; k.total_q = a->total_q; k.total_k = a->total_k;
+  int causal = a->is_causal, wl = a->window_left, wr = a->window_right;
+  normalize_window(a->seqlen_q, a->seqlen_k, a->alibi_slopes != nullptr, causal, wl, wr);
+  k.wl = wl; k.wr = wr;
+  k.scale = a->softmax_scale;
+  k.scale_log2 = a->softmax_scale * 1.4426950408889634f;
+  k.softcap = a->softcap;
+  k.nmb = (a->seqlen_q + fa::bwd_block_m() - 1) / fa::bwd_block_m();
+  k.nnb = (a->seqlen_k + fa::bwd_block_n() - 1) / fa::bwd_block_n();
+  return FA_OK;
+}
+
+int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
+  fa::BwdK k;
+  if (int rc = fill_bwd(a, varlen, k)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int bf = a->dtype == FA_DTYPE_BF16;
+  // Nothing to differentiate: the caller's dq/dk/dv hold no rows (Sq == 0 / Sk == 0 with fixed
+  // shapes are handled by the binder, which zero-fills as flash_api.cpp:992-999 does).
+  if (a->seqlen_q == 0 || a->seqlen_k == 0 || a->total_q == 0 || a->total_k == 0) return FA_OK;
+  int rc = fa::launch_bwd_delta(k, bf, a->d, s);
+  if (rc == 0) rc = fa::launch_bwd_dkdv(k, bf, a->d, s);
+  if (rc == 0) rc = fa::launch_bwd_dq(k, bf, a->d, s);
+  if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no backward kernel for head dim %d", a->d);
+  if (rc != 0) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return FA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fa_abi_version(void) { return FA_ABI_VERSION; }
+int fa_sizeof_fwd_params(void) { return (int)sizeof(FaFwdParams); }
+int fa_sizeof_bwd_params(void) { return (int)sizeof(FaBwdParams); }
+const char* fa_last_error(void) { return g_err; }
+
+int fa_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, false); }
+int fa_varlen_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, true); }
+
+int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {
+  (void)params;
+  return 0;  // the two-pass backward (dK/dV kernel + dQ kernel) needs no fp32 dq accumulator
+}
+int fa_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, false); }
+int fa_varlen_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, true); }
+
+}  // extern "C"

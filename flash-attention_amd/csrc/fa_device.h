@@ -1,0 +1,80 @@
+// Shared device-side helpers for the gfx950 attention kernels (wave64, MFMA 32x32x16, LDS tiles).
+//
+// Lane-layout facts used everywhere (verified on hardware by probe_gfx950.hip):
+//   v_mfma_f32_32x32x16_{bf16,f16}:  D[m][n] = sum_k A[m][k] * B[k][n]
+//     A operand : lane l holds A[l&31][8*(l>>5) + j],  j = 0..7   (8 x 16-bit = 4 VGPRs)
+//     B operand : lane l holds B[8*(l>>5) + j][l&31]
+//     C/D       : reg r of lane l = D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31],  r = 0..15
+//   ds_read_b64_tr_b16: inside each 16-lane group, lane i supplies the address of row (i>>2),
+//     columns 4*(i&3)..+3 of a 4x16 block of 16-bit elements; lane i receives column i
+//     (4 elements, rows 0..3) of that block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define FA_DEVINL __device__ __forceinline__
+#define FA_LDS __attribute__((address_space(3)))
+
+template <typename E> struct ElemTraits;
+template <> struct ElemTraits<__bf16> {
+  using v8 = bf16x8;
+  using v4 = bf16x4;
+  static FA_DEVINL f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct ElemTraits<_Float16> {
+  using v8 = f16x8;
+  using v4 = f16x4;
+  static FA_DEVINL f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+// Row index inside a 32x32 accumulator block held by register r of a lane in half hi (= lane>>5).
+FA_DEVINL constexpr int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+FA_DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// value held by lane (l ^ 32)
+FA_DEVINL float xchg_half(float x) { return __shfl_xor(x, 32); }
+
+// 16-byte global load of 8 consecutive 16-bit elements; zeros when !valid.
+FA_DEVINL u32x4 ld_global_16B(const void* p, bool valid) {
+  u32x4 z = {0u, 0u, 0u, 0u};
+  if (valid) z = *reinterpret_cast<const u32x4*>(p);
+  return z;
+}
+
+template <typename V> FA_DEVINL V bitcast_u32x4(u32x4 x) { return __builtin_bit_cast(V, x); }
+
+// LDS transpose read: returns the 4 x 16-bit column this lane owns (see header comment).
+FA_DEVINL s16x4 lds_read_tr16(const char FA_LDS* addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 FA_LDS*)addr);
+}
+
+template <typename V8> FA_DEVINL V8 combine_tr(s16x4 lo, s16x4 hi) {
+  s16x8 x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(V8, x);
+}
+
+// XCD-aware bijective remap of a 1-D grid: consecutive work items land on the same XCD
+// (block b is observed to run on XCD b % 8; performance only, never correctness).
+FA_DEVINL int xcd_remap(int bid, int total) {
+  constexpr int NX = 8;
+  if (total < NX * 2) return bid;
+  const int q = total / NX, r = total % NX;
+  const int xcd = bid % NX, slot = bid / NX;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+}  // namespace fa

@@ -1,0 +1,66 @@
+// Device-side parameter blocks (passed by value to the kernels).  Host code fills them from the
+// public C-ABI structs of include/fa_gfx950.h after validation/normalisation (fa_api.cpp).
+#pragma once
+#include <stdint.h>
+
+namespace fa {
+
+struct FwdK {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse;
+  int64_t q_bs, q_rs, q_hs;
+  int64_t k_bs, k_rs, k_hs;
+  int64_t v_bs, v_rs, v_hs;
+  int64_t o_bs, o_rs, o_hs;
+  const int32_t* cu_q;       // nullptr => fixed length
+  const int32_t* cu_k;
+  const int32_t* seqused_k;  // optional
+  const float* alibi;        // optional
+  int64_t alibi_bs;
+  int32_t b, h, h_k, hk_ratio;
+  int32_t sq, sk;            // fixed: exact; varlen: max
+  int32_t total_q;
+  int32_t nmb;               // query blocks per sequence (grid sizing)
+  int32_t wl, wr;            // normalised window, < 0 = unbounded
+  float scale;               // softmax_scale
+  float scale_log2;          // softmax_scale * log2(e)
+  float softcap;             // 0 = off
+};
+
+struct BwdK {
+  const void* dout;
+  const void* q;
+  const void* k;
+  const void* v;
+  const void* o;
+  const float* lse;
+  void* dq;
+  void* dk;
+  void* dv;
+  float* delta;              // softmax_d
+  int64_t do_bs, do_rs, do_hs;
+  int64_t q_bs, q_rs, q_hs;
+  int64_t k_bs, k_rs, k_hs;
+  int64_t v_bs, v_rs, v_hs;
+  int64_t o_bs, o_rs, o_hs;
+  int64_t dq_bs, dq_rs, dq_hs;
+  int64_t dk_bs, dk_rs, dk_hs;
+  int64_t dv_bs, dv_rs, dv_hs;
+  const int32_t* cu_q;
+  const int32_t* cu_k;
+  const float* alibi;
+  int64_t alibi_bs;
+  int32_t b, h, h_k, hk_ratio;
+  int32_t sq, sk;
+  int32_t total_q, total_k;
+  int32_t nmb, nnb;          // query / key blocks per sequence
+  int32_t wl, wr;
+  float scale;
+  float scale_log2;
+  float softcap;
+};
+
+}  // namespace fa

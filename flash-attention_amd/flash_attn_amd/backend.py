@@ -1,0 +1,330 @@
+"""Backend-module API of the reference (``flash_attn_2_cuda``) on top of the C ABI, via ctypes.
+
+Exports ``fwd``, ``varlen_fwd``, ``bwd``, ``varlen_bwd`` (and a raising ``fwd_kvcache``) with the
+exact positional signatures the reference custom ops use
+(flash_attn/flash_attn_interface.py:99,177,280,380; C++ originals csrc/flash_attn/flash_api.cpp
+:368-382, :538-561, :800-820, :1010-1035).  Validation messages follow the reference's
+``TORCH_CHECK`` texts where tests match on them.  torch is used for device memory and the
+current stream only; all arithmetic happens in libfa_gfx950.so.  No fallback path exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _cabi
+
+_NATIVE_HEAD_DIMS = (64, 128)
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _cabi.FA_DTYPE_BF16
+    if t.dtype == torch.float16:
+        return _cabi.FA_DTYPE_FP16
+    raise RuntimeError("FlashAttention only support fp16 and bf16 data type")
+
+
+def _check_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("Input tensor must be on CUDA device")
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _native_d(d: int) -> int:
+    for n in _NATIVE_HEAD_DIMS:
+        if d <= n:
+            return n
+    raise RuntimeError(f"libfa_gfx950: head dimension {d} > 128 is not built yet")
+
+
+def _pad_d(x: torch.Tensor, d_to: int) -> torch.Tensor:
+    d = x.shape[-1]
+    if d == d_to:
+        return x
+    return torch.nn.functional.pad(x, (0, d_to - d))
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _common_checks(q, k, v, p_dropout, alibi_slopes, gen_):
+    if gen_ is not None:
+        raise RuntimeError("Passing a `generator` argument is no longer supported; seed the default generator instead")
+    if p_dropout != 0.0:
+        raise RuntimeError("libfa_gfx950: dropout > 0 is not built (feature-gated like FLASHATTENTION_DISABLE_DROPOUT)")
+    _check_dev(q, k, v)
+    if not (q.dtype == k.dtype == v.dtype):
+        raise RuntimeError("query, key and value must have the same dtype")
+    for t in (q, k, v):
+        if t.stride(-1) != 1:
+            raise RuntimeError("Input tensor must have contiguous last dimension")
+    if alibi_slopes is not None:
+        if alibi_slopes.dtype != torch.float32:
+            raise RuntimeError("ALiBi slopes must have dtype fp32")
+        if alibi_slopes.stride(-1) != 1:
+            raise RuntimeError("ALiBi slopes tensor must have contiguous last dimension")
+
+
+def _alibi_args(alibi_slopes, batch, nheads):
+    if alibi_slopes is None:
+        return None, 0
+    if tuple(alibi_slopes.shape) not in ((nheads,), (batch, nheads)):
+        raise RuntimeError("ALiBi slopes must have shape (nheads,) or (batch_size, nheads)")
+    return alibi_slopes, (alibi_slopes.stride(0) if alibi_slopes.dim() == 2 else 0)
+
+
+def fwd(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, window_size_left,
+        window_size_right, softcap, return_softmax, gen_) -> List[torch.Tensor]:
+    """mha_fwd (flash_api.cpp:368-536): q (B,Sq,H,D), k/v (B,Sk,Hk,D) -> [out, softmax_lse, p, rng_state]."""
+    _common_checks(q, k, v, p_dropout, alibi_slopes_, gen_)
+    if return_softmax:
+        raise RuntimeError("return_softmax is only supported when p_dropout > 0.0")
+    B, Sq, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    if B <= 0:
+        raise RuntimeError("batch size must be positive")
+    if D > 256:
+        raise RuntimeError("FlashAttention forward only supports head dimension at most 256")
+    if D % 8 != 0:
+        raise RuntimeError("query, key, value, and out_ must have a head_size that is a multiple of 8")
+    if H % Hk != 0:
+        raise RuntimeError("Number of heads in key/value must divide number of heads in query")
+    if tuple(k.shape) != (B, Sk, Hk, D) or tuple(v.shape) != (B, Sk, Hk, D):
+        raise RuntimeError("key/value shape mismatch")
+    Dn = _native_d(D)
+    qp, kp, vp = _pad_d(q, Dn), _pad_d(k, Dn), _pad_d(v, Dn)
+    if out_ is not None:
+        if out_.dtype != q.dtype or tuple(out_.shape) != (B, Sq, H, D) or out_.stride(-1) != 1:
+            raise RuntimeError("out_ must have the same dtype/shape as q and a contiguous last dimension")
+    out = out_ if (out_ is not None and Dn == D) else torch.empty((B, Sq, H, Dn), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    rng_state = torch.empty((2,), dtype=torch.int64, device=q.device)
+    p_out = torch.empty((0,), dtype=q.dtype, device=q.device)
+    if Sk == 0:  # flash_api.cpp:524-528
+        out.zero_()
+        lse.fill_(float("inf"))
+    elif Sq > 0:
+        alibi, alibi_bs = _alibi_args(alibi_slopes_, B, H)
+        a = _cabi.FaFwdParams()
+        a.q, a.k, a.v, a.o, a.softmax_lse = _ptr(qp), _ptr(kp), _ptr(vp), _ptr(out), _ptr(lse)
+        a.q_batch_stride, a.q_row_stride, a.q_head_stride = qp.stride(0), qp.stride(1), qp.stride(2)
+        a.k_batch_stride, a.k_row_stride, a.k_head_stride = kp.stride(0), kp.stride(1), kp.stride(2)
+        a.v_batch_stride, a.v_row_stride, a.v_head_stride = vp.stride(0), vp.stride(1), vp.stride(2)
+        a.o_batch_stride, a.o_row_stride, a.o_head_stride = out.stride(0), out.stride(1), out.stride(2)
+        a.alibi_slopes, a.alibi_batch_stride = _ptr(alibi), alibi_bs
+        a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
+        a.seqlen_q, a.seqlen_k, a.total_q = Sq, Sk, B * Sq
+        a.dtype = _dtype_code(q)
+        a.is_causal, a.window_left, a.window_right = int(bool(is_causal)), int(window_size_left), int(window_size_right)
+        a.softmax_scale, a.softcap = float(softmax_scale), float(softcap)
+        with torch.cuda.device(q.device):
+            _cabi.check(_cabi.load().fa_fwd(C.byref(a), C.c_void_p(_stream_ptr(q.device))))
+    if Dn != D:
+        res = out[..., :D]
+        if out_ is not None:
+            out_.copy_(res)
+            res = out_
+        out = res
+    return [out, lse, p_out, rng_state]
+
+
+def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_, block_table_,
+               alibi_slopes_, max_seqlen_q, max_seqlen_k, p_dropout, softmax_scale, zero_tensors,
+               is_causal, window_size_left, window_size_right, softcap, return_softmax, gen_,
+               num_splits: int = 0) -> List[torch.Tensor]:
+    """mha_varlen_fwd (flash_api.cpp:538-788): packed q (total_q,H,D), k/v (total_k,Hk,D), int32 cu_seqlens (B+1)."""
+    _common_checks(q, k, v, p_dropout, alibi_slopes_, gen_)
+    if return_softmax:
+        raise RuntimeError("return_softmax is only supported when p_dropout > 0.0")
+    if block_table_ is not None:
+        raise RuntimeError("libfa_gfx950: paged KV (block_table) is not built")
+    if leftpad_k_ is not None:
+        raise RuntimeError("libfa_gfx950: leftpad_k is not built")
+    if num_splits > 1:
+        raise RuntimeError("num_splits > 1 is not supported")
+    for cu in (cu_seqlens_q, cu_seqlens_k):
+        if cu.dtype != torch.int32:
+            raise RuntimeError("cu_seqlens_q/k must have dtype int32")
+        if not cu.is_contiguous():
+            raise RuntimeError("cu_seqlens_q/k must be contiguous")
+    _check_dev(cu_seqlens_q, cu_seqlens_k, seqused_k)
+    total_q, H, D = q.shape
+    total_k, Hk = k.shape[0], k.shape[1]
+    B = cu_seqlens_q.numel() - 1
+    if B <= 0:
+        raise RuntimeError("batch size must be positive")
+    if cu_seqlens_k.numel() != B + 1:
+        raise RuntimeError("cu_seqlens_k must have shape (batch_size + 1)")
+    if D > 256 or D % 8 != 0:
+        raise RuntimeError("head_size must be a multiple of 8 and at most 256")
+    if H % Hk != 0:
+        raise RuntimeError("Number of heads in key/value must divide number of heads in query")
+    if seqused_k is not None and (seqused_k.dtype != torch.int32 or seqused_k.numel() != B or not seqused_k.is_contiguous()):
+        raise RuntimeError("seqused_k must be a contiguous int32 tensor of shape (batch_size)")
+    Dn = _native_d(D)
+    qp, kp, vp = _pad_d(q, Dn), _pad_d(k, Dn), _pad_d(v, Dn)
+    out = out_ if (out_ is not None and Dn == D) else torch.empty((total_q, H, Dn), dtype=q.dtype, device=q.device)
+    lse = torch.empty((H, total_q), dtype=torch.float32, device=q.device)
+    rng_state = torch.empty((2,), dtype=torch.int64, device=q.device)
+    p_out = torch.empty((0,), dtype=q.dtype, device=q.device)
+    if zero_tensors:  # flash_api.cpp:693-697
+        out.zero_()
+        lse.fill_(float("-inf"))
+    if max_seqlen_k == 0 or total_k == 0:
+        out.zero_()
+        lse.fill_(float("inf"))
+    elif total_q > 0 and max_seqlen_q > 0:
+        alibi, alibi_bs = _alibi_args(alibi_slopes_, B, H)
+        a = _cabi.FaFwdParams()
+        a.q, a.k, a.v, a.o, a.softmax_lse = _ptr(qp), _ptr(kp), _ptr(vp), _ptr(out), _ptr(lse)
+        a.q_row_stride, a.q_head_stride = qp.stride(0), qp.stride(1)
+        a.k_row_stride, a.k_head_stride = kp.stride(0), kp.stride(1)
+        a.v_row_stride, a.v_head_stride = vp.stride(0), vp.stride(1)
+        a.o_row_stride, a.o_head_stride = out.stride(0), out.stride(1)
+        a.cu_seqlens_q, a.cu_seqlens_k, a.seqused_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k), _ptr(seqused_k)
+        a.alibi_slopes, a.alibi_batch_stride = _ptr(alibi), alibi_bs
+        a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
+        a.seqlen_q, a.seqlen_k, a.total_q = int(max_seqlen_q), int(max_seqlen_k), total_q
+        a.dtype = _dtype_code(q)
+        a.is_causal, a.window_left, a.window_right = int(bool(is_causal)), int(window_size_left), int(window_size_right)
+        a.softmax_scale, a.softcap = float(softmax_scale), float(softcap)
+        with torch.cuda.device(q.device):
+            _cabi.check(_cabi.load().fa_varlen_fwd(C.byref(a), C.c_void_p(_stream_ptr(q.device))))
+    if Dn != D:
+        res = out[..., :D]
+        if out_ is not None:
+            out_.copy_(res)
+            res = out_
+        out = res
+    return [out, lse, p_out, rng_state]
+
+
+def _bwd_out(buf, like, name):
+    if buf is None:
+        return torch.empty_like(like)
+    if buf.dtype != like.dtype or tuple(buf.shape) != tuple(like.shape) or buf.stride(-1) != 1:
+        raise RuntimeError(f"{name} must have the same dtype/shape as its input and a contiguous last dimension")
+    return buf
+
+
+def _fill_bwd_common(a, dout, q, k, v, out, lse, dq, dk, dv, delta, alibi, alibi_bs, softmax_scale,
+                     is_causal, wl, wr, softcap, deterministic):
+    a.dout, a.q, a.k, a.v, a.o, a.softmax_lse = _ptr(dout), _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse)
+    a.dq, a.dk, a.dv, a.softmax_d = _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta)
+    a.alibi_slopes, a.alibi_batch_stride = _ptr(alibi), alibi_bs
+    a.dtype = _dtype_code(q)
+    a.is_causal, a.window_left, a.window_right = int(bool(is_causal)), int(wl), int(wr)
+    a.softmax_scale, a.softcap, a.deterministic = float(softmax_scale), float(softcap), int(bool(deterministic))
+
+
+def _run_bwd(a, device, varlen):
+    lib = _cabi.load()
+    ws_bytes = lib.fa_bwd_workspace_bytes(C.byref(a))
+    ws = None
+    if ws_bytes > 0:
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=device)
+        a.workspace, a.workspace_bytes = _ptr(ws), ws_bytes
+    with torch.cuda.device(device):
+        fn = lib.fa_varlen_bwd if varlen else lib.fa_bwd
+        _cabi.check(fn(C.byref(a), C.c_void_p(_stream_ptr(device))))
+    return ws
+
+
+def bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, alibi_slopes_, p_dropout, softmax_scale,
+        is_causal, window_size_left, window_size_right, softcap, deterministic, gen_, rng_state
+        ) -> List[torch.Tensor]:
+    """mha_bwd (flash_api.cpp:800-1008) -> [dq, dk, dv, softmax_d]."""
+    _common_checks(q, k, v, p_dropout, alibi_slopes_, gen_)
+    _check_dev(dout, out, softmax_lse)
+    if dout.dtype != q.dtype or out.dtype != q.dtype:
+        raise RuntimeError("query and dout/out must have the same dtype")
+    if dout.stride(-1) != 1 or out.stride(-1) != 1:
+        raise RuntimeError("out/dout tensor must have contiguous last dimension")
+    B, Sq, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    if D % 8 != 0 or D > 256:
+        raise RuntimeError("head_size should be a multiple of 8 and at most 256")
+    if H % Hk != 0:
+        raise RuntimeError("Number of heads in key/value must divide number of heads in query")
+    dq, dk, dv = _bwd_out(dq_, q, "dq"), _bwd_out(dk_, k, "dk"), _bwd_out(dv_, v, "dv")
+    delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    if Sq == 0 or Sk == 0:  # flash_api.cpp:992-999
+        dq.zero_(); dk.zero_(); dv.zero_(); delta.zero_()
+        return [dq, dk, dv, delta]
+    Dn = _native_d(D)
+    if Dn != D:
+        dop, qp, kp, vp, op = (_pad_d(t, Dn) for t in (dout, q, k, v, out))
+        dqp, dkp, dvp = (torch.empty(t.shape[:-1] + (Dn,), dtype=t.dtype, device=t.device) for t in (q, k, v))
+    else:
+        dop, qp, kp, vp, op, dqp, dkp, dvp = dout, q, k, v, out, dq, dk, dv
+    alibi, alibi_bs = _alibi_args(alibi_slopes_, B, H)
+    a = _cabi.FaBwdParams()
+    _fill_bwd_common(a, dop, qp, kp, vp, op, softmax_lse, dqp, dkp, dvp, delta, alibi, alibi_bs,
+                     softmax_scale, is_causal, window_size_left, window_size_right, softcap, deterministic)
+    for nm, t in (("do", dop), ("q", qp), ("k", kp), ("v", vp), ("o", op), ("dq", dqp), ("dk", dkp), ("dv", dvp)):
+        setattr(a, nm + "_batch_stride", t.stride(0))
+        setattr(a, nm + "_row_stride", t.stride(1))
+        setattr(a, nm + "_head_stride", t.stride(2))
+    a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
+    a.seqlen_q, a.seqlen_k, a.total_q, a.total_k = Sq, Sk, B * Sq, B * Sk
+    _run_bwd(a, q.device, False)
+    if Dn != D:
+        dq.copy_(dqp[..., :D]); dk.copy_(dkp[..., :D]); dv.copy_(dvp[..., :D])
+    return [dq, dk, dv, delta]
+
+
+def varlen_bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, cu_seqlens_q, cu_seqlens_k,
+               alibi_slopes_, max_seqlen_q, max_seqlen_k, p_dropout, softmax_scale, zero_tensors,
+               is_causal, window_size_left, window_size_right, softcap, deterministic, gen_, rng_state
+               ) -> List[torch.Tensor]:
+    """mha_varlen_bwd (flash_api.cpp:1010-1241) -> [dq, dk, dv, softmax_d]."""
+    _common_checks(q, k, v, p_dropout, alibi_slopes_, gen_)
+    _check_dev(dout, out, softmax_lse, cu_seqlens_q, cu_seqlens_k)
+    for cu in (cu_seqlens_q, cu_seqlens_k):
+        if cu.dtype != torch.int32 or not cu.is_contiguous():
+            raise RuntimeError("cu_seqlens_q/k must be contiguous int32")
+    total_q, H, D = q.shape
+    total_k, Hk = k.shape[0], k.shape[1]
+    B = cu_seqlens_q.numel() - 1
+    if D % 8 != 0 or D > 256:
+        raise RuntimeError("head_size should be a multiple of 8 and at most 256")
+    dq, dk, dv = _bwd_out(dq_, q, "dq"), _bwd_out(dk_, k, "dk"), _bwd_out(dv_, v, "dv")
+    delta = torch.empty((H, total_q), dtype=torch.float32, device=q.device)
+    if zero_tensors:  # flash_api.cpp:1171-1176
+        dq.zero_(); dk.zero_(); dv.zero_(); delta.zero_()
+    if max_seqlen_q == 0 or total_q == 0 or total_k == 0:
+        dk.zero_(); dv.zero_(); delta.zero_(); dq.zero_()
+        return [dq, dk, dv, delta]
+    Dn = _native_d(D)
+    if Dn != D:
+        dop, qp, kp, vp, op = (_pad_d(t, Dn) for t in (dout, q, k, v, out))
+        dqp, dkp, dvp = (torch.empty(t.shape[:-1] + (Dn,), dtype=t.dtype, device=t.device) for t in (q, k, v))
+    else:
+        dop, qp, kp, vp, op, dqp, dkp, dvp = dout, q, k, v, out, dq, dk, dv
+    alibi, alibi_bs = _alibi_args(alibi_slopes_, B, H)
+    a = _cabi.FaBwdParams()
+    _fill_bwd_common(a, dop, qp, kp, vp, op, softmax_lse, dqp, dkp, dvp, delta, alibi, alibi_bs,
+                     softmax_scale, is_causal, window_size_left, window_size_right, softcap, deterministic)
+    for nm, t in (("do", dop), ("q", qp), ("k", kp), ("v", vp), ("o", op), ("dq", dqp), ("dk", dkp), ("dv", dvp)):
+        setattr(a, nm + "_row_stride", t.stride(0))
+        setattr(a, nm + "_head_stride", t.stride(1))
+    a.cu_seqlens_q, a.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
+    a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
+    a.seqlen_q, a.seqlen_k, a.total_q, a.total_k = int(max_seqlen_q), int(max_seqlen_k), total_q, total_k
+    _run_bwd(a, q.device, True)
+    if Dn != D:
+        dq.copy_(dqp[..., :D]); dk.copy_(dkp[..., :D]); dv.copy_(dvp[..., :D])
+    return [dq, dk, dv, delta]
+
+
+def fwd_kvcache(*args, **kwargs):
+    """mha_fwd_kvcache (flash_api.cpp:1243-1532): decode path, next row of the scope table."""
+    raise RuntimeError("libfa_gfx950: fwd_kvcache (split-KV decode / paged KV) is not built yet")

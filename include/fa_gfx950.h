@@ -1,0 +1,138 @@
+/*
+ * fa_gfx950.h -- C ABI of the MI355X (gfx950 / CDNA4) fused-attention library `libfa_gfx950.so`.
+ *
+ * This is the drop-in boundary of the hot path: plain pointers, sizes and element strides, no
+ * torch / ATen types.  Each entry point replaces one host function of the reference's backend
+ * module `flash_attn_2_cuda` (the module `flash_attn/flash_attn_interface.py:13-23` imports):
+ *
+ *   fa_fwd         <->  mha_fwd         csrc/flash_attn/flash_api.cpp:368-536   (pybind "fwd",        :1537)
+ *   fa_varlen_fwd  <->  mha_varlen_fwd  csrc/flash_attn/flash_api.cpp:538-788   (pybind "varlen_fwd", :1538)
+ *   fa_bwd         <->  mha_bwd         csrc/flash_attn/flash_api.cpp:800-1008  (pybind "bwd",        :1539)
+ *   fa_varlen_bwd  <->  mha_varlen_bwd  csrc/flash_attn/flash_api.cpp:1010-1241 (pybind "varlen_bwd", :1540)
+ *
+ * The two parameter blocks below are this library's counterpart of the reference's kernel POD
+ * `Flash_fwd_params` / `Flash_bwd_params` (csrc/flash_attn/src/flash.h:47-189).  The caller owns
+ * every buffer (allocation stays with the framework's caching allocator); the library only
+ * enqueues kernels on `stream` and never synchronises.  The torch extension
+ * `flash_attn_2_cuda` (flash-attention_amd/csrc/torch_binding.cpp) and the ctypes loader
+ * (flash-attention_amd/flash_attn_amd/_cabi.py) are the two in-tree binders; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - all strides are in ELEMENTS (not bytes); the last (head-dim) stride is 1;
+ *   - q (B,Sq,H,D), k/v (B,Sk,Hk,D), o like q; varlen: q (total_q,H,D), k/v (total_k,Hk,D) and
+ *     batch strides are ignored; sequence b owns rows cu_seqlens[b] .. cu_seqlens[b+1]-1
+ *     (reference csrc/flash_attn/src/block_info.h:12-45);
+ *   - softmax_lse is fp32 (B,H,Sq) or, varlen, (H,total_q); natural log of sum_j exp(scale*s_ij);
+ *     rows without any visible key give out = 0, lse = +inf (reference softmax.h:179-180);
+ *   - window_left / window_right < 0 mean unbounded; is_causal forces window_right = 0; masks are
+ *     aligned to the bottom-right corner (reference flash_attn_interface.py:1175-1189);
+ *   - return value 0 = enqueued; negative = FA_ERR_* (message via fa_last_error()).
+ */
+#ifndef FA_GFX950_H_
+#define FA_GFX950_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_ABI_VERSION 1
+
+enum { FA_DTYPE_FP16 = 0, FA_DTYPE_BF16 = 1 };
+
+enum {
+  FA_OK = 0,
+  FA_ERR_INVALID_ARGUMENT = -1, /* shape/dtype/stride contract violated                     */
+  FA_ERR_UNSUPPORTED = -2,      /* valid in the reference but not built here (see message)   */
+  FA_ERR_LAUNCH = -3,           /* hipLaunchKernel failed                                     */
+  FA_ERR_WORKSPACE = -4         /* workspace missing or too small                             */
+};
+
+typedef struct FaFwdParams {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* softmax_lse;           /* (B,H,Sq) or varlen (H,total_q) */
+  int64_t q_batch_stride, q_row_stride, q_head_stride;
+  int64_t k_batch_stride, k_row_stride, k_head_stride;
+  int64_t v_batch_stride, v_row_stride, v_head_stride;
+  int64_t o_batch_stride, o_row_stride, o_head_stride;
+  const int32_t* cu_seqlens_q;  /* NULL => fixed-length batch          */
+  const int32_t* cu_seqlens_k;  /* NULL => fixed-length batch          */
+  const int32_t* seqused_k;     /* optional (B): keys actually used     */
+  const float* alibi_slopes;    /* optional (H) or (B,H) fp32           */
+  int64_t alibi_batch_stride;   /* 0 when slopes are (H)                */
+  int32_t b, h, h_k, d;
+  int32_t seqlen_q, seqlen_k;   /* fixed: exact; varlen: max_seqlen_*   */
+  int32_t total_q;              /* varlen: rows of q; fixed: b*seqlen_q */
+  int32_t dtype;                /* FA_DTYPE_*                           */
+  int32_t is_causal;
+  int32_t window_left, window_right;
+  float softmax_scale;
+  float softcap;                /* 0 = off                              */
+  int32_t reserved[4];
+} FaFwdParams;
+
+typedef struct FaBwdParams {
+  const void* dout;
+  const void* q;
+  const void* k;
+  const void* v;
+  const void* o;
+  const float* softmax_lse;     /* as written by fa_fwd                */
+  void* dq;
+  void* dk;
+  void* dv;
+  float* softmax_d;             /* out: rowsum(dO*O), fp32, same shape/indexing as softmax_lse */
+  void* workspace;              /* fa_bwd_workspace_bytes() bytes, 256-B aligned, may be NULL if that is 0 */
+  int64_t workspace_bytes;
+  int64_t do_batch_stride, do_row_stride, do_head_stride;
+  int64_t q_batch_stride, q_row_stride, q_head_stride;
+  int64_t k_batch_stride, k_row_stride, k_head_stride;
+  int64_t v_batch_stride, v_row_stride, v_head_stride;
+  int64_t o_batch_stride, o_row_stride, o_head_stride;
+  int64_t dq_batch_stride, dq_row_stride, dq_head_stride;
+  int64_t dk_batch_stride, dk_row_stride, dk_head_stride;
+  int64_t dv_batch_stride, dv_row_stride, dv_head_stride;
+  const int32_t* cu_seqlens_q;
+  const int32_t* cu_seqlens_k;
+  const float* alibi_slopes;
+  int64_t alibi_batch_stride;
+  int32_t b, h, h_k, d;
+  int32_t seqlen_q, seqlen_k;
+  int32_t total_q, total_k;
+  int32_t dtype;
+  int32_t is_causal;
+  int32_t window_left, window_right;
+  float softmax_scale;
+  float softcap;
+  int32_t deterministic;        /* accepted; this implementation is always deterministic */
+  int32_t reserved[4];
+} FaBwdParams;
+
+/* ABI version of the loaded library (== FA_ABI_VERSION of the header it was built from). */
+int fa_abi_version(void);
+/* sizeof() of the two parameter blocks as the library sees them (binder self-check). */
+int fa_sizeof_fwd_params(void);
+int fa_sizeof_bwd_params(void);
+/* Last error message of the calling thread ("" if none). */
+const char* fa_last_error(void);
+
+/* Forward, fixed-length batch.  cu_seqlens_* must be NULL.  `stream` is a hipStream_t. */
+int fa_fwd(const FaFwdParams* params, void* stream);
+/* Forward, packed variable-length batch.  cu_seqlens_q/k must be non-NULL device int32 (b+1). */
+int fa_varlen_fwd(const FaFwdParams* params, void* stream);
+/* Bytes of scratch the backward needs for this problem (0 is possible). */
+int64_t fa_bwd_workspace_bytes(const FaBwdParams* params);
+/* Backward, fixed-length batch: writes dq, dk, dv (caller-allocated) and softmax_d. */
+int fa_bwd(const FaBwdParams* params, void* stream);
+/* Backward, packed variable-length batch. */
+int fa_varlen_bwd(const FaBwdParams* params, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FA_GFX950_H_ */

@@ -1,0 +1,147 @@
+"""GPU parity tests of the forward path (through the C ABI): HIP kernels vs oracle / golden vectors.
+
+Tolerance rule is the reference's own (tests/test_flash_attn.py:1121,1556-1560): the fused kernel's
+max error against an fp32 reference must be at most twice the error of a same-dtype plain-PyTorch
+implementation (+1e-5 absolute floor); LSE (not pinned by the reference) is checked to 2e-3.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import attention_torch, case_meta, golden_inputs, max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from flash_attn_amd import backend
+    return backend
+
+
+def _fwd(be, q, k, v, causal=False, window=(-1, -1), softcap=0.0, alibi=None, scale=None):
+    scale = q.shape[-1] ** -0.5 if scale is None else scale
+    out, lse, _, _ = be.fwd(q, k, v, None, alibi, 0.0, scale, causal, window[0], window[1], softcap, False, None)
+    return out, lse
+
+
+GOLDEN_NATIVE = ["mha_full_d64", "mha_causal_d128", "gqa_causal_sq_gt_sk", "mqa_local_d128",
+                 "gqa_causal_window_d128", "local_left_only_d64", "local_right_only_d64", "tiny_sq1",
+                 "softcap_d64", "alibi_d64", "d32_full", "d96_causal"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_NATIVE)
+def test_forward_matches_reference_golden(be, golden_cases, name):
+    case = golden_cases[name]
+    m = case_meta(case)
+    q, k, v, _ = golden_inputs(case, "cuda")
+    alibi = None if m["alibi"] is None else torch.from_numpy(np.asarray(m["alibi"], dtype=np.float32)).cuda()
+    out, lse = _fwd(be, q, k, v, m["causal"], m["window"], m["softcap"], alibi)
+    ref = torch.from_numpy(case["out"]).cuda()
+    # bf16 output quantisation (2^-9 relative) + bf16 P rounding: absolute bound scaled by |out|max
+    tol = 1.2e-2 * max(1.0, float(ref.abs().max()))
+    assert max_abs(out.float(), ref) < tol, (name, max_abs(out.float(), ref))
+    from oracle import attention_oracle as orc
+    _, lse_ref = orc.attention_fwd(q.float().cpu(), k.float().cpu(), v.float().cpu(), None, m["causal"], m["window"],
+                                   m["softcap"], m["alibi"])
+    lse_ref = torch.from_numpy(lse_ref).cuda()
+    fin = torch.isfinite(lse_ref)
+    assert torch.equal(torch.isposinf(lse), ~fin)
+    assert max_abs(lse[fin], lse_ref[fin].float()) < 2e-3
+
+
+def test_unbuilt_head_dim_fails_loudly(be, golden_cases):
+    q, k, v, _ = golden_inputs(golden_cases["d256_causal"], "cuda")
+    with pytest.raises(RuntimeError):
+        _fwd(be, q, k, v, True)
+
+
+SEQ = [(113, 203), (128, 217), (113, 211), (108, 256), (256, 512), (512, 256), (1024, 1024), (1023, 1024), (1024, 1023), (2048, 2048)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mha_type", ["mha", "gqa", "mqa"])
+@pytest.mark.parametrize("mode", ["full", "causal", "local"])
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("sq,sk", SEQ)
+def test_forward_vs_fp32_reference(be, sq, sk, d, mode, mha_type, dtype):
+    torch.manual_seed(0)
+    B, H = 2, 6
+    Hk = {"mha": 6, "gqa": 2, "mqa": 1}[mha_type]
+    q = torch.randn(B, sq, H, d, device="cuda", dtype=dtype)
+    k = torch.randn(B, sk, Hk, d, device="cuda", dtype=dtype)
+    v = torch.randn(B, sk, Hk, d, device="cuda", dtype=dtype)
+    causal = mode == "causal"
+    window = (-1, -1)
+    if mode == "local":
+        g = torch.Generator().manual_seed(sq * 7 + sk)
+        window = tuple(int(x) for x in torch.randint(0, sk, (2,), generator=g))
+    out, lse = _fwd(be, q, k, v, causal, window)
+    ref, lse_ref = attention_torch(q, k, v, causal, window, upcast=True)
+    ref32 = attention_torch(q.float(), k.float(), v.float(), causal, window, upcast=True)[0]
+    pt, _ = attention_torch(q, k, v, causal, window, upcast=False, reorder=True)
+    err = max_abs(out.float(), ref32)
+    err_pt = max_abs(pt.float(), ref32)
+    assert err <= 2 * err_pt + 1e-5, (err, err_pt)
+    fin = torch.isfinite(lse_ref)
+    assert torch.equal(torch.isposinf(lse), ~fin)
+    assert max_abs(lse[fin], lse_ref[fin]) < 2e-3
+    assert not torch.isnan(out).any()
+
+
+def test_strided_qkv_packed_views(be):
+    """Packed-QKV callers pass views qkv[:, :, i] (flash_attn_interface.py:479,526-528)."""
+    torch.manual_seed(1)
+    qkv = torch.randn(2, 300, 3, 4, 128, device="cuda", dtype=torch.bfloat16)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    out, lse = _fwd(be, q, k, v, True)
+    out2, lse2 = _fwd(be, q.contiguous(), k.contiguous(), v.contiguous(), True)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
+
+
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_varlen_equals_per_sequence_bit_exact(be, d, causal):
+    torch.manual_seed(2)
+    lens_q = [0, 76, 34, 146, 1, 300, 257]
+    lens_k = [5, 76, 1, 300, 77, 300, 255]
+    H, Hk = 4, 2
+    cu_q = torch.tensor([0] + list(np.cumsum(lens_q)), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0] + list(np.cumsum(lens_k)), dtype=torch.int32, device="cuda")
+    q = torch.randn(int(cu_q[-1]), H, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(int(cu_k[-1]), Hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(int(cu_k[-1]), Hk, d, device="cuda", dtype=torch.bfloat16)
+    scale = d ** -0.5
+    out, lse, _, _ = be.varlen_fwd(q, k, v, None, cu_q, cu_k, None, None, None, None, max(lens_q), max(lens_k), 0.0, scale,
+                                   False, causal, -1, -1, 0.0, False, None)
+    for b in range(len(lens_q)):
+        a0, a1, b0, b1 = int(cu_q[b]), int(cu_q[b + 1]), int(cu_k[b]), int(cu_k[b + 1])
+        if a1 == a0:
+            continue
+        o1, l1 = _fwd(be, q[None, a0:a1], k[None, b0:b1], v[None, b0:b1], causal)
+        assert torch.equal(out[a0:a1], o1[0]), b
+        assert torch.equal(lse[:, a0:a1], l1[0]), b
+
+
+def test_empty_keys_and_validation(be):
+    q = torch.randn(1, 8, 2, 64, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(1, 0, 2, 64, device="cuda", dtype=torch.bfloat16)
+    out, lse = _fwd(be, q, k, k.clone())
+    assert torch.all(out == 0) and torch.all(torch.isposinf(lse))
+    with pytest.raises(RuntimeError):
+        be.fwd(q, q, q, None, None, 0.0, 0.125, False, -1, -1, 0.0, False, torch.Generator())
+    with pytest.raises(RuntimeError):
+        be.fwd(q.float(), q.float(), q.float(), None, None, 0.0, 0.125, False, -1, -1, 0.0, False, None)
+
+
+def test_run_to_run_bitwise_deterministic(be):
+    torch.manual_seed(3)
+    q = torch.randn(4, 777, 8, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(4, 901, 2, 128, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    o0, l0 = _fwd(be, q, k, v, True)
+    for _ in range(20):
+        o, l = _fwd(be, q, k, v, True)
+        assert torch.equal(o, o0) and torch.equal(l, l0)
