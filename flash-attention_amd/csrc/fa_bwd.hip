@@ -1,9 +1,595 @@
-// placeholder until the backward kernels land (next commit)
+// Fused attention backward for gfx950 (MI355X): delta pre-pass, dK/dV kernel, dQ kernel.
+//
+// Replaces the reference's three-launch backward (compute_dot_do_o, compute_dq_dk_dv_1colblock with
+// fp32 atomicAdd into dq_accum, convert_dQ: csrc/flash_attn/src/flash_bwd_preprocess_kernel.h:57-268,
+// flash_bwd_kernel.h:80-795) with a deterministic two-pass structure native to the MFMA layouts:
+//
+//   dK/dV kernel : one workgroup owns a block of keys (each wave 32 keys, K fragments in registers,
+//                  the V block resident in LDS) and streams query tiles (Q, dO, LSE, delta) through
+//                  LDS; S = Q.K^T and dP = dO.V^T land with column = key = lane, so P and dS are
+//                  directly the B operands of dV^T += dO^T.P and dK^T += Q^T.dS (dO^T / Q^T come from
+//                  LDS transpose reads).  The query heads of a GQA group are looped INSIDE the
+//                  workgroup, so dK/dV are written once -- no dk_expanded + sum_out
+//                  (reference flash_api.cpp:935-942,1002-1005) and no atomics.
+//   dQ kernel    : forward-shaped: one wave owns 32 query rows (Q, dO fragments in registers, LSE and
+//                  delta lane-local), streams K/V tiles; S^T = K.Q^T, dP^T = V.dO^T,
+//                  dQ^T += K^T.dS^T (K^T by transpose reads).  No fp32 dq_accum buffer, no convert pass.
+//
+// 7 MFMA contractions per tile instead of the reference's 5, traded for: zero atomics, bitwise
+// determinism for free, no 268 MB accumulator round trip, and every softmax quantity lane-local.
+// Arithmetic follows the reference: P = exp2(S*scale*log2e - LSE*log2e) (flash_bwd_kernel.h:536),
+// dS = P*(dP - delta) (:584-595), P and dS rounded to the input dtype before their contractions,
+// softmax_scale applied once at the end (:733, flash_bwd_preprocess_kernel.h:250).
+#include "fa_device.h"
+#include "fa_kernel_params.h"
 #include "fa_launch.h"
+
 namespace fa {
-int launch_bwd_delta(const BwdK&, int, int, hipStream_t) { return -2; }
-int launch_bwd_dkdv(const BwdK&, int, int, hipStream_t) { return -2; }
-int launch_bwd_dq(const BwdK&, int, int, hipStream_t) { return -2; }
-int bwd_block_m() { return 128; }
-int bwd_block_n() { return 128; }
+
+// Unified LDS tile layout (rows of D 16-bit elements, 16-B chunks XOR-swizzled) that is
+// conflict-free for both access patterns used on the same tile:
+//   - ds_read_b128 operand rows (16 distinct rows per lane group, same logical chunk),
+//   - ds_read_b64_tr_b16 (a half-wave reads 4 consecutive rows x 64 contiguous logical bytes).
+template <int D> FA_DEVINL int swz16(int row) {
+  return D == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+}
+template <int D> FA_DEVINL int tile_off(int row, int chunk) { return row * (D * 2) + ((chunk ^ swz16<D>(row)) << 4); }
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+// ------------------------------------------------------------------------------------------------
+// delta[b,h,i] = sum_d dO[i,d] * O[i,d]   (reference flash_bwd_preprocess_kernel.h:24-51, dropout off)
+// ------------------------------------------------------------------------------------------------
+template <typename E, int D>
+__global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
+  using V8 = typename ElemTraits<E>::v8;
+  constexpr int LPR = D / 8;        // lanes per row
+  constexpr int ROWS = 256 / LPR;   // rows per block
+  const int b = blockIdx.z, h = blockIdx.y;
+  int sq = p.sq;
+  int64_t row0 = 0, do_boff = (int64_t)b * p.do_bs, o_boff = (int64_t)b * p.o_bs;
+  if (p.cu_q) {
+    const int c0 = p.cu_q[b];
+    sq = p.cu_q[b + 1] - c0;
+    row0 = c0;
+    do_boff = 0;
+    o_boff = 0;
+  }
+  const int row = blockIdx.x * ROWS + threadIdx.x / LPR;
+  const int c = threadIdx.x % LPR;
+  float acc = 0.f;
+  if (row < sq) {
+    const E* dop = (const E*)p.dout + do_boff + (row0 + row) * p.do_rs + (int64_t)h * p.do_hs + c * 8;
+    const E* op = (const E*)p.o + o_boff + (row0 + row) * p.o_rs + (int64_t)h * p.o_hs + c * 8;
+    const V8 a = bitcast_u32x4<V8>(*reinterpret_cast<const u32x4*>(dop));
+    const V8 o = bitcast_u32x4<V8>(*reinterpret_cast<const u32x4*>(op));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)o[j];
+  }
+#pragma unroll
+  for (int off = LPR / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (row < sq && c == 0) {
+    float* dst = p.cu_q ? (p.delta + (int64_t)h * p.total_q + row0 + row) : (p.delta + ((int64_t)b * p.h + h) * p.sq + row);
+    *dst = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK / dV
+// ------------------------------------------------------------------------------------------------
+template <typename E, int D>
+__global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
+  using T = ElemTraits<E>;
+  using V8 = typename T::v8;
+  using V4 = typename T::v4;
+  constexpr int NW = 8, NT = NW * 64;
+  constexpr int BNK = NW * 32;   // keys per workgroup
+  constexpr int BMQ = 64;        // queries per streamed tile (two 32-row sub-blocks)
+  constexpr int CPR = D / 8, ROW_BYTES = D * 2;
+  constexpr int KS = D / 16, DB = D / 32;
+  constexpr int VBLK_BYTES = BNK * ROW_BYTES;
+  constexpr int QT_BYTES = BMQ * ROW_BYTES;
+  constexpr int LDQ = (BMQ * CPR) / NT;  // 16-B chunks per thread per streamed tile (Q and dO each)
+  static_assert(LDQ >= 1, "tile too small for the workgroup");
+  // LDS: V block | Q0 | Q1 | dO0 | dO1 | lse0 lse1 | delta0 delta1
+  constexpr int OFF_Q = VBLK_BYTES, OFF_DO = OFF_Q + 2 * QT_BYTES, OFF_LSE = OFF_DO + 2 * QT_BYTES, OFF_DEL = OFF_LSE + 2 * BMQ * 4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char FA_LDS* lds = (char FA_LDS*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, ki = lane & 31;
+
+  // grid: x = key block (low blocks first: they see the most queries under a causal mask), y = kv head, z = batch
+  const int n_block = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  int sq = p.sq, sk = p.sk;
+  int64_t q_row0 = 0, k_row0 = 0;
+  int64_t q_boff = (int64_t)b * p.q_bs, do_boff = (int64_t)b * p.do_bs;
+  int64_t k_boff = (int64_t)b * p.k_bs, v_boff = (int64_t)b * p.v_bs, dk_boff = (int64_t)b * p.dk_bs, dv_boff = (int64_t)b * p.dv_bs;
+  if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; }
+  if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; dk_boff = 0; dv_boff = 0; }
+  const int n0 = n_block * BNK;
+  if (n0 >= sk) return;
+  const int n1 = min(n0 + BNK, sk);
+  const int shift = sk - sq;
+
+  const E* __restrict__ kp = (const E*)p.k + k_boff + k_row0 * p.k_rs + (int64_t)hk * p.k_hs;
+  const E* __restrict__ vp = (const E*)p.v + v_boff + k_row0 * p.v_rs + (int64_t)hk * p.v_hs;
+
+  // ---- query range that can see this key block -------------------------------------------------
+  int q_lo = 0, q_hi = sq - 1;
+  if (p.wr >= 0) q_lo = max(0, n0 - shift - p.wr);
+  if (p.wl >= 0) q_hi = min(sq - 1, n1 - 1 - shift + p.wl);
+  const int m_lo = q_lo / BMQ;
+  const int nm = (q_hi >= q_lo) ? (q_hi / BMQ + 1 - m_lo) : 0;  // tiles per query head
+  const int n_items = nm * p.hk_ratio;
+
+  // ---- this wave's keys ----------------------------------------------------------------------------
+  const int wk0 = n0 + wave * 32;
+  const int wk1 = min(wk0 + 31, sk - 1);
+  const bool wave_valid = wk0 < sk;
+  const int my_key = wk0 + ki;
+  const bool key_valid = my_key < sk;
+
+  // K fragments (B operand of S = Q.K^T): lane = key, 8 consecutive d per k-step
+  V8 kf[KS];
+  {
+    const E* krow = kp + (int64_t)my_key * p.k_rs + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = bitcast_u32x4<V8>(ld_global_16B(krow + 16 * ks, key_valid));
+  }
+  // V block -> LDS (B operand of dP = dO.V^T is re-read per step to keep registers for the accumulators)
+  {
+    constexpr int LDV = (BNK * CPR) / NT;
+#pragma unroll
+    for (int i = 0; i < LDV; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / CPR, ch = idx % CPR;
+      const u32x4 x = ld_global_16B(vp + (int64_t)(n0 + row) * p.v_rs + ch * 8, n0 + row < sk);
+      *(u32x4 FA_LDS*)(lds + tile_off<D>(row, ch)) = x;
+    }
+  }
+
+  // ---- streamed tile staging --------------------------------------------------------------------
+  u32x4 qreg[LDQ], doreg[LDQ];
+  float lse_reg = 0.f, del_reg = 0.f;
+  auto item_head = [&](int it) { return hk * p.hk_ratio + it / nm; };
+  auto item_m0 = [&](int it) { return (m_lo + it % nm) * BMQ; };
+  auto load_item = [&](int it) {
+    const int h = item_head(it);
+    const int m0 = item_m0(it);
+    const E* qp = (const E*)p.q + q_boff + q_row0 * p.q_rs + (int64_t)h * p.q_hs;
+    const E* dop = (const E*)p.dout + do_boff + q_row0 * p.do_rs + (int64_t)h * p.do_hs;
+#pragma unroll
+    for (int i = 0; i < LDQ; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / CPR, ch = idx % CPR;
+      const bool ok = (m0 + row) < sq;
+      qreg[i] = ld_global_16B(qp + (int64_t)(m0 + row) * p.q_rs + ch * 8, ok);
+      doreg[i] = ld_global_16B(dop + (int64_t)(m0 + row) * p.do_rs + ch * 8, ok);
+    }
+    if (tid < 2 * BMQ) {
+      const int r = tid & (BMQ - 1);
+      const bool ok = (m0 + r) < sq;
+      const int64_t base = p.cu_q ? ((int64_t)h * p.total_q + q_row0) : (((int64_t)b * p.h + h) * p.sq);
+      if (tid < BMQ) lse_reg = ok ? p.lse[base + m0 + r] * kLog2e : INFINITY;  // rows past the end: P = 0
+      else del_reg = ok ? p.delta[base + m0 + r] : 0.f;
+    }
+  };
+  auto store_item = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LDQ; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / CPR, ch = idx % CPR;
+      *(u32x4 FA_LDS*)(lds + OFF_Q + buf * QT_BYTES + tile_off<D>(row, ch)) = qreg[i];
+      *(u32x4 FA_LDS*)(lds + OFF_DO + buf * QT_BYTES + tile_off<D>(row, ch)) = doreg[i];
+    }
+    if (tid < BMQ) *(float FA_LDS*)(lds + OFF_LSE + (buf * BMQ + tid) * 4) = lse_reg;
+    else if (tid < 2 * BMQ) *(float FA_LDS*)(lds + OFF_DEL + (buf * BMQ + tid - BMQ) * 4) = del_reg;
+  };
+
+  // per-lane LDS read offsets
+  const int row_off = tile_off<D>(ki, 0) - (swz16<D>(ki) << 4);  // = ki * ROW_BYTES
+  const int rswz = swz16<D>(ki);
+  const int tr_i = lane & 15, tr_half = (lane >> 4) & 1, tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
+  int tr_off[DB][2];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int row = 8 * s + 4 * hi + tr_rr;
+      tr_off[db][s] = tile_off<D>(row, 4 * db + 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
+    }
+
+  f32x16 dk_acc[DB], dv_acc[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk_acc[db][r] = 0.f; dv_acc[db][r] = 0.f; }
+
+  const float cs = p.alibi ? kLog2e : p.scale_log2;
+
+  if (n_items > 0) {
+    load_item(0);
+    store_item(0);
+  }
+  __syncthreads();
+
+  for (int it = 0; it < n_items; ++it) {
+    const int cur = it & 1;
+    const bool has_next = it + 1 < n_items;
+    if (has_next) load_item(it + 1);
+    const int m0 = item_m0(it);
+    const float slope = p.alibi ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
+    const char FA_LDS* qbuf = lds + OFF_Q + cur * QT_BYTES;
+    const char FA_LDS* dobuf = lds + OFF_DO + cur * QT_BYTES;
+
+#pragma unroll
+    for (int qb = 0; qb < BMQ / 32; ++qb) {
+      const int q0 = m0 + 32 * qb;
+      bool active = wave_valid && q0 < sq;
+      if (p.wr >= 0) active = active && (wk0 <= q0 + 31 + shift + p.wr);
+      if (p.wl >= 0) active = active && (wk1 >= q0 + shift - p.wl);
+      if (!active) continue;
+
+      // S[query][key] = Q.K^T ; dP[query][key] = dO.V^T   (column = key = lane)
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int coff = row_off + qb * 32 * ROW_BYTES + (((2 * ks + hi) ^ rswz) << 4);
+        const u32x4 qa = *(const u32x4 FA_LDS*)(qbuf + coff);
+        s = T::mfma(bitcast_u32x4<V8>(qa), kf[ks], s);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int coff = row_off + qb * 32 * ROW_BYTES + (((2 * ks + hi) ^ rswz) << 4);
+        const u32x4 da = *(const u32x4 FA_LDS*)(dobuf + coff);
+        const u32x4 vb = *(const u32x4 FA_LDS*)(lds + row_off + wave * 32 * ROW_BYTES + (((2 * ks + hi) ^ rswz) << 4));
+        dp = T::mfma(bitcast_u32x4<V8>(da), bitcast_u32x4<V8>(vb), dp);
+      }
+
+      if (p.alibi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qrow = q0 + acc_row(r, hi);
+          s[r] = s[r] * p.scale - slope * fabsf((float)(qrow + shift - my_key));
+        }
+      }
+      bool need_mask = false;
+      if (p.wr >= 0) need_mask = need_mask || (wk1 > q0 + shift + p.wr);
+      if (p.wl >= 0) need_mask = need_mask || (wk0 < q0 + 31 + shift - p.wl);
+      if (need_mask) {
+        const int rel_lo = (p.wr >= 0) ? (my_key - shift - p.wr - q0 - 4 * hi) : -(1 << 30);
+        const int rel_hi = (p.wl >= 0) ? (my_key - shift + p.wl - q0 - 4 * hi) : (1 << 30);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int off = acc_row(r, 0);
+          s[r] = ((off >= rel_lo) && (off <= rel_hi)) ? s[r] : -INFINITY;
+        }
+      }
+
+      // P = exp2(S*c - LSE*log2e); dS = P * (dP - delta): rows are queries acc_row(r,hi)
+      V8 pfrag[2], dsfrag[2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int qoff = (cur * BMQ + qb * 32 + 8 * g + 4 * hi) * 4;
+        const f32x4 l4 = *(const f32x4 FA_LDS*)(lds + OFF_LSE + qoff);
+        const f32x4 d4 = *(const f32x4 FA_LDS*)(lds + OFF_DEL + qoff);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          const float pv = fast_exp2(__builtin_fmaf(s[r], cs, -l4[j]));
+          const float dsv = pv * (dp[r] - d4[j]);
+          pfrag[r >> 3][r & 7] = (E)pv;
+          dsfrag[r >> 3][r & 7] = (E)dsv;
+        }
+      }
+
+      // dV^T[d][key] += dO^T[d][query] . P[query][key] ;  dK^T[d][key] += Q^T[d][query] . dS[query][key]
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const int base = (qb * 32 + 16 * t) * ROW_BYTES;
+          const s16x4 d_lo = lds_read_tr16(dobuf + base + tr_off[db][0]);
+          const s16x4 d_hi = lds_read_tr16(dobuf + base + tr_off[db][1]);
+          dv_acc[db] = T::mfma(combine_tr<V8>(d_lo, d_hi), pfrag[t], dv_acc[db]);
+          const s16x4 q_lo4 = lds_read_tr16(qbuf + base + tr_off[db][0]);
+          const s16x4 q_hi4 = lds_read_tr16(qbuf + base + tr_off[db][1]);
+          dk_acc[db] = T::mfma(combine_tr<V8>(q_lo4, q_hi4), dsfrag[t], dk_acc[db]);
+        }
+      }
+    }
+
+    if (has_next) store_item(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: dK = scale * acc, dV = acc; every key row of the block is written (zeros included) --
+  if (!key_valid) return;
+  E* dkrow = (E*)p.dk + dk_boff + (k_row0 + my_key) * p.dk_rs + (int64_t)hk * p.dk_hs;
+  E* dvrow = (E*)p.dv + dv_boff + (k_row0 + my_key) * p.dv_rs + (int64_t)hk * p.dv_hs;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      V4 a, c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = (E)(dk_acc[db][4 * g + j] * p.scale);
+        c[j] = (E)(dv_acc[db][4 * g + j]);
+      }
+      *reinterpret_cast<V4*>(dkrow + 32 * db + 8 * g + 4 * hi) = a;
+      *reinterpret_cast<V4*>(dvrow + 32 * db + 8 * g + 4 * hi) = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ
+// ------------------------------------------------------------------------------------------------
+template <typename E, int D>
+__global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
+  using T = ElemTraits<E>;
+  using V8 = typename T::v8;
+  using V4 = typename T::v4;
+  constexpr int NW = 8, NT = NW * 64;
+  constexpr int BM = NW * 32, BN = 64;
+  constexpr int CPR = D / 8, ROW_BYTES = D * 2, TILE_BYTES = BN * ROW_BYTES;
+  constexpr int KS = D / 16, DB = D / 32;
+  constexpr int LD = (BN * CPR) / NT;
+  static_assert(LD >= 1, "tile too small for the workgroup");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char FA_LDS* lds = (char FA_LDS*)smem;  // K0 | K1 | V0 | V1
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, qi = lane & 31;
+
+  const int total = p.nmb * p.b * p.h;
+  const int w = xcd_remap(blockIdx.x, total);
+  const int bh = w / p.nmb;
+  const int mbr = w - bh * p.nmb;
+  const int m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
+  const int b = bh / p.h, h = bh - b * p.h, hk = h / p.hk_ratio;
+
+  int sq = p.sq, sk = p.sk;
+  int64_t q_row0 = 0, k_row0 = 0;
+  int64_t q_boff = (int64_t)b * p.q_bs, do_boff = (int64_t)b * p.do_bs, dq_boff = (int64_t)b * p.dq_bs;
+  int64_t k_boff = (int64_t)b * p.k_bs, v_boff = (int64_t)b * p.v_bs;
+  if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; dq_boff = 0; }
+  if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
+  const int m0 = m_block * BM;
+  if (m0 >= sq) return;
+
+  const E* __restrict__ kp = (const E*)p.k + k_boff + k_row0 * p.k_rs + (int64_t)hk * p.k_hs;
+  const E* __restrict__ vp = (const E*)p.v + v_boff + k_row0 * p.v_rs + (int64_t)hk * p.v_hs;
+
+  const int shift = sk - sq;
+  const int blk_last = min(m0 + BM, sq) - 1;
+  int kmax = sk - 1, kmin = 0;
+  if (p.wr >= 0) kmax = min(kmax, blk_last + shift + p.wr);
+  if (p.wl >= 0) kmin = max(0, m0 + shift - p.wl);
+  const int n_min = kmin / BN;
+  const int n_max = (kmax >= kmin) ? (kmax / BN + 1) : n_min;
+
+  const int w_row0 = m0 + wave * 32;
+  const int w_row1 = min(w_row0 + 31, sq - 1);
+  const bool wave_valid = w_row0 < sq;
+  const int w_kmax = (p.wr >= 0) ? min(sk - 1, w_row1 + shift + p.wr) : sk - 1;
+  const int w_kmin = (p.wl >= 0) ? max(0, w_row0 + shift - p.wl) : 0;
+  const int w_full_hi = (p.wr >= 0) ? min(sk - 1, w_row0 + shift + p.wr) : sk - 1;
+  const int w_full_lo = (p.wl >= 0) ? (w_row1 + shift - p.wl) : 0;
+  const int my_row = w_row0 + qi;
+  const bool row_valid = my_row < sq;
+  const int lim_hi = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
+  const int lim_lo = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
+
+  const float cs = p.alibi ? kLog2e : p.scale_log2;
+  const float slope = p.alibi ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
+
+  // Q and dO fragments (B operands), LSE and delta (lane-local scalars)
+  V8 qf[KS], dof[KS];
+  {
+    const E* qrow = (const E*)p.q + q_boff + (q_row0 + my_row) * p.q_rs + (int64_t)h * p.q_hs + 8 * hi;
+    const E* dorow = (const E*)p.dout + do_boff + (q_row0 + my_row) * p.do_rs + (int64_t)h * p.do_hs + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = bitcast_u32x4<V8>(ld_global_16B(qrow + 16 * ks, row_valid));
+      dof[ks] = bitcast_u32x4<V8>(ld_global_16B(dorow + 16 * ks, row_valid));
+    }
+  }
+  float lse_l = INFINITY, delta_l = 0.f;
+  if (row_valid) {
+    const int64_t base = p.cu_q ? ((int64_t)h * p.total_q + q_row0) : (((int64_t)b * p.h + h) * p.sq);
+    lse_l = p.lse[base + my_row] * kLog2e;
+    delta_l = p.delta[base + my_row];
+  }
+
+  u32x4 kreg[LD], vreg[LD];
+  auto load_tile = [&](int n) {
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / CPR, ch = idx % CPR;
+      const int key = n * BN + row;
+      const bool ok = key < sk;
+      kreg[i] = ld_global_16B(kp + (int64_t)key * p.k_rs + ch * 8, ok);
+      vreg[i] = ld_global_16B(vp + (int64_t)key * p.v_rs + ch * 8, ok);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / CPR, ch = idx % CPR;
+      *(u32x4 FA_LDS*)(lds + buf * TILE_BYTES + tile_off<D>(row, ch)) = kreg[i];
+      *(u32x4 FA_LDS*)(lds + (2 + buf) * TILE_BYTES + tile_off<D>(row, ch)) = vreg[i];
+    }
+  };
+
+  const int row_off = qi * ROW_BYTES;
+  const int rswz = swz16<D>(qi);
+  const int tr_i = lane & 15, tr_half = (lane >> 4) & 1, tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
+  int tr_off[DB][2];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int row = 8 * s + 4 * hi + tr_rr;
+      tr_off[db][s] = tile_off<D>(row, 4 * db + 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
+    }
+
+  f32x16 dq_acc[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq_acc[db][r] = 0.f;
+
+  if (n_min < n_max) {
+    load_tile(n_min);
+    store_tile(0);
+    __syncthreads();
+  }
+
+  for (int n = n_min; n < n_max; ++n) {
+    const int cur = (n - n_min) & 1;
+    const int kv0 = n * BN;
+    const bool has_next = n + 1 < n_max;
+    if (has_next) load_tile(n + 1);
+
+    const bool active = wave_valid && (kv0 <= w_kmax) && (kv0 + BN - 1 >= w_kmin);
+    if (active) {
+      const char FA_LDS* kbuf = lds + cur * TILE_BYTES;
+      const char FA_LDS* vbuf = lds + (2 + cur) * TILE_BYTES;
+      const bool need_mask = (kv0 + BN - 1 > w_full_hi) || (kv0 < w_full_lo);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        // S^T[key][query] = K.Q^T ; dP^T[key][query] = V.dO^T   (column = query = lane)
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int coff = row_off + kb * 32 * ROW_BYTES + (((2 * ks + hi) ^ rswz) << 4);
+          const u32x4 ka = *(const u32x4 FA_LDS*)(kbuf + coff);
+          s = T::mfma(bitcast_u32x4<V8>(ka), qf[ks], s);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int coff = row_off + kb * 32 * ROW_BYTES + (((2 * ks + hi) ^ rswz) << 4);
+          const u32x4 va = *(const u32x4 FA_LDS*)(vbuf + coff);
+          dp = T::mfma(bitcast_u32x4<V8>(va), dof[ks], dp);
+        }
+        if (p.alibi) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + 32 * kb + acc_row(r, hi);
+            s[r] = s[r] * p.scale - slope * fabsf((float)(my_row + shift - key));
+          }
+        }
+        if (need_mask) {
+          const int rel_hi = lim_hi - kv0 - 32 * kb - 4 * hi;
+          const int rel_lo = lim_lo - kv0 - 32 * kb - 4 * hi;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int off = acc_row(r, 0);
+            s[r] = ((off <= rel_hi) && (off >= rel_lo)) ? s[r] : -INFINITY;
+          }
+        }
+        V8 dsfrag[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fast_exp2(__builtin_fmaf(s[r], cs, -lse_l));
+          dsfrag[r >> 3][r & 7] = (E)(pv * (dp[r] - delta_l));
+        }
+        // dQ^T[d][query] += K^T[d][key] . dS^T[key][query]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int db = 0; db < DB; ++db) {
+            const int base = (kb * 32 + 16 * t) * ROW_BYTES;
+            const s16x4 lo = lds_read_tr16(kbuf + base + tr_off[db][0]);
+            const s16x4 hi4 = lds_read_tr16(kbuf + base + tr_off[db][1]);
+            dq_acc[db] = T::mfma(combine_tr<V8>(lo, hi4), dsfrag[t], dq_acc[db]);
+          }
+        }
+      }
+    }
+    if (has_next) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  if (!row_valid) return;
+  E* dqrow = (E*)p.dq + dq_boff + (q_row0 + my_row) * p.dq_rs + (int64_t)h * p.dq_hs;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      V4 a;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = (E)(dq_acc[db][4 * g + j] * p.scale);
+      *reinterpret_cast<V4*>(dqrow + 32 * db + 8 * g + 4 * hi) = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+int bwd_block_m() { return 256; }
+int bwd_block_n() { return 256; }
+
+template <typename E, int D>
+static int launch_delta_t(const BwdK& p, hipStream_t stream) {
+  constexpr int ROWS = 256 / (D / 8);
+  dim3 grid((p.sq + ROWS - 1) / ROWS, p.h, p.b);
+  hipLaunchKernelGGL((fa_bwd_delta_kernel<E, D>), grid, dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <typename E, int D>
+static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
+  constexpr int smem = 256 * D * 2 + 4 * 64 * D * 2 + 4 * 64 * 4;
+  auto kern = fa_bwd_dkdv_kernel<E, D>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
+    attr_done = true;
+  }
+  dim3 grid(p.nnb, p.h_k, p.b);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <typename E, int D>
+static int launch_dq_t(const BwdK& p, hipStream_t stream) {
+  constexpr int smem = 4 * 64 * D * 2;
+  auto kern = fa_bwd_dq_kernel<E, D>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
+    attr_done = true;
+  }
+  const long long total = (long long)p.nmb * p.b * p.h;
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), smem, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+#define FA_BWD_DISPATCH(fn)                                            \
+  if (dtype_bf16) {                                                    \
+    if (d == 128) return fn<__bf16, 128>(p, stream);                   \
+    if (d == 64) return fn<__bf16, 64>(p, stream);                     \
+  } else {                                                             \
+    if (d == 128) return fn<_Float16, 128>(p, stream);                 \
+    if (d == 64) return fn<_Float16, 64>(p, stream);                   \
+  }                                                                    \
+  return -2;
+
+int launch_bwd_delta(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_delta_t) }
+int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_dkdv_t) }
+int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_dq_t) }
+
 }  // namespace fa
