@@ -1,0 +1,352 @@
+// PyTorch-ROCm extension module `flash_attn_2_cuda`: the backend module the reference's Python layer
+// imports (flash_attn/flash_attn_interface.py:13-23) -- fwd / varlen_fwd / bwd / varlen_bwd /
+// fwd_kvcache with the positional signatures of csrc/flash_attn/flash_api.cpp:368-382, :538-561,
+// :800-820, :1010-1035, :1243-1264 (pybind block :1535-1542).
+//
+// This file is glue only: tensor validation (TORCH_CHECK messages follow the reference where its
+// tests match on them), output allocation from the caching allocator, current-stream lookup, and one
+// call into the C ABI of libfa_gfx950.so (include/fa_gfx950.h).  No kernels, no math.
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/utils/pybind.h>
+#include <torch/extension.h>
+
+#include <optional>
+#include <vector>
+
+#include "fa_gfx950.h"
+
+namespace {
+
+using at::Tensor;
+using OptTensor = std::optional<at::Tensor>;
+
+#define CHECK_DEVICE(x) TORCH_CHECK((x).is_cuda(), #x " must be on CUDA")
+#define CHECK_LAST_CONTIG(x) TORCH_CHECK((x).stride(-1) == 1, #x " must have contiguous last dimension")
+#define CHECK_SHAPE(x, ...) TORCH_CHECK((x).sizes() == at::IntArrayRef({__VA_ARGS__}), #x " must have shape (" #__VA_ARGS__ ")")
+
+void fa_check(int rc) { TORCH_CHECK(rc == FA_OK, fa_last_error()); }
+
+void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+
+int dtype_code(const Tensor& q) {
+  TORCH_CHECK(q.dtype() == at::kHalf || q.dtype() == at::kBFloat16, "FlashAttention only support fp16 and bf16 data type");
+  return q.dtype() == at::kBFloat16 ? FA_DTYPE_BF16 : FA_DTYPE_FP16;
+}
+
+int native_head_dim(int64_t d) {
+  if (d <= 64) return 64;
+  TORCH_CHECK(d <= 128, "libfa_gfx950: head dimension ", d, " > 128 is not built yet");
+  return 128;
+}
+
+Tensor pad_d(const Tensor& x, int64_t d_to) {
+  const int64_t d = x.size(-1);
+  if (d == d_to) return x;
+  return at::constant_pad_nd(x, {0, d_to - d}, 0);
+}
+
+void common_checks(const Tensor& q, const Tensor& k, const Tensor& v, double p_dropout, const OptTensor& alibi,
+                   const std::optional<at::Generator>& gen) {
+  TORCH_CHECK(!gen.has_value(), "Passing a `generator` argument is no longer supported; seed the default generator instead");
+  TORCH_CHECK(p_dropout == 0.0, "libfa_gfx950: dropout > 0 is not built (feature-gated like FLASHATTENTION_DISABLE_DROPOUT)");
+  CHECK_DEVICE(q); CHECK_DEVICE(k); CHECK_DEVICE(v);
+  TORCH_CHECK(k.dtype() == q.dtype() && v.dtype() == q.dtype(), "query, key and value must have the same dtype");
+  TORCH_CHECK(q.stride(-1) == 1 && k.stride(-1) == 1 && v.stride(-1) == 1, "Input tensor must have contiguous last dimension");
+  if (alibi.has_value()) {
+    TORCH_CHECK(alibi->dtype() == at::kFloat, "ALiBi slopes must have dtype fp32");
+    CHECK_DEVICE(*alibi);
+    TORCH_CHECK(alibi->stride(-1) == 1, "ALiBi slopes tensor must have contiguous last dimension");
+  }
+}
+
+void set_alibi(const OptTensor& alibi, int64_t B, int64_t H, const float*& ptr, int64_t& bs) {
+  ptr = nullptr;
+  bs = 0;
+  if (!alibi.has_value()) return;
+  TORCH_CHECK(alibi->sizes() == at::IntArrayRef({H}) || alibi->sizes() == at::IntArrayRef({B, H}),
+              "ALiBi slopes must have shape (nheads,) or (batch_size, nheads)");
+  ptr = alibi->data_ptr<float>();
+  bs = alibi->dim() == 2 ? alibi->stride(0) : 0;
+}
+
+std::vector<Tensor> mha_fwd(Tensor& q, const Tensor& k, const Tensor& v, OptTensor& out_, OptTensor& alibi_slopes_,
+                            const double p_dropout, const double softmax_scale, bool is_causal, int64_t window_size_left,
+                            int64_t window_size_right, const double softcap, const bool return_softmax,
+                            std::optional<at::Generator> gen_) {
+  common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
+  TORCH_CHECK(!return_softmax, "return_softmax is only supported when p_dropout > 0.0");
+  TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.dim() == 4, "q, k, v must be 4-D (batch, seqlen, nheads, headdim)");
+  const int64_t B = q.size(0), Sq = q.size(1), H = q.size(2), D = q.size(3), Sk = k.size(1), Hk = k.size(2);
+  TORCH_CHECK(B > 0, "batch size must be positive");
+  TORCH_CHECK(D <= 256, "FlashAttention forward only supports head dimension at most 256");
+  TORCH_CHECK(D % 8 == 0, "query, key, value, and out_ must have a head_size that is a multiple of 8");
+  TORCH_CHECK(H % Hk == 0, "Number of heads in key/value must divide number of heads in query");
+  CHECK_SHAPE(k, B, Sk, Hk, D);
+  CHECK_SHAPE(v, B, Sk, Hk, D);
+  c10::DeviceGuard guard(q.device());
+  const int64_t Dn = native_head_dim(D);
+  const Tensor qp = pad_d(q, Dn), kp = pad_d(k, Dn), vp = pad_d(v, Dn);
+  Tensor out;
+  if (out_.has_value()) {
+    TORCH_CHECK(out_->dtype() == q.dtype(), "Output must have the same dtype as inputs");
+    CHECK_DEVICE(*out_); CHECK_LAST_CONTIG(*out_); CHECK_SHAPE(*out_, B, Sq, H, D);
+  }
+  out = (out_.has_value() && Dn == D) ? *out_ : at::empty({B, Sq, H, Dn}, q.options());
+  Tensor lse = at::empty({B, H, Sq}, q.options().dtype(at::kFloat));
+  Tensor rng_state = at::empty({2}, q.options().dtype(at::kLong));
+  Tensor p = at::empty({0}, q.options());
+  if (Sk == 0) {  // flash_api.cpp:524-528
+    out.zero_();
+    lse.fill_(std::numeric_limits<float>::infinity());
+  } else if (Sq > 0) {
+    FaFwdParams a{};
+    a.q = qp.data_ptr(); a.k = kp.data_ptr(); a.v = vp.data_ptr(); a.o = out.data_ptr(); a.softmax_lse = lse.data_ptr<float>();
+    a.q_batch_stride = qp.stride(0); a.q_row_stride = qp.stride(1); a.q_head_stride = qp.stride(2);
+    a.k_batch_stride = kp.stride(0); a.k_row_stride = kp.stride(1); a.k_head_stride = kp.stride(2);
+    a.v_batch_stride = vp.stride(0); a.v_row_stride = vp.stride(1); a.v_head_stride = vp.stride(2);
+    a.o_batch_stride = out.stride(0); a.o_row_stride = out.stride(1); a.o_head_stride = out.stride(2);
+    set_alibi(alibi_slopes_, B, H, a.alibi_slopes, a.alibi_batch_stride);
+    a.b = B; a.h = H; a.h_k = Hk; a.d = Dn; a.seqlen_q = Sq; a.seqlen_k = Sk; a.total_q = B * Sq;
+    a.dtype = dtype_code(q);
+    a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
+    a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap;
+    fa_check(fa_fwd(&a, cur_stream(q)));
+  }
+  if (Dn != D) {
+    Tensor res = out.slice(-1, 0, D);
+    if (out_.has_value()) { out_->copy_(res); res = *out_; }
+    out = res;
+  }
+  return {out, lse, p, rng_state};
+}
+
+std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, OptTensor& out_, const Tensor& cu_seqlens_q,
+                                   const Tensor& cu_seqlens_k, OptTensor& seqused_k, OptTensor& leftpad_k_,
+                                   OptTensor& block_table_, OptTensor& alibi_slopes_, int64_t max_seqlen_q,
+                                   const int64_t max_seqlen_k, const double p_dropout, const double softmax_scale,
+                                   const bool zero_tensors, bool is_causal, int64_t window_size_left, int64_t window_size_right,
+                                   const double softcap, const bool return_softmax, std::optional<at::Generator> gen_,
+                                   const int64_t num_splits) {
+  common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
+  TORCH_CHECK(!return_softmax, "return_softmax is only supported when p_dropout > 0.0");
+  TORCH_CHECK(!block_table_.has_value(), "libfa_gfx950: paged KV (block_table) is not built");
+  TORCH_CHECK(!leftpad_k_.has_value(), "libfa_gfx950: leftpad_k is not built");
+  TORCH_CHECK(num_splits <= 1, "num_splits > 1 is not supported");
+  TORCH_CHECK(cu_seqlens_q.dtype() == at::kInt, "cu_seqlens_q must have dtype int32");
+  TORCH_CHECK(cu_seqlens_k.dtype() == at::kInt, "cu_seqlens_k must have dtype int32");
+  CHECK_DEVICE(cu_seqlens_q); CHECK_DEVICE(cu_seqlens_k);
+  TORCH_CHECK(cu_seqlens_q.is_contiguous() && cu_seqlens_k.is_contiguous(), "cu_seqlens_q/k must be contiguous");
+  TORCH_CHECK(q.dim() == 3 && k.dim() == 3 && v.dim() == 3, "q, k, v must be 3-D (total, nheads, headdim)");
+  const int64_t total_q = q.size(0), H = q.size(1), D = q.size(2), total_k = k.size(0), Hk = k.size(1);
+  const int64_t B = cu_seqlens_q.numel() - 1;
+  TORCH_CHECK(B > 0, "batch size must be positive");
+  CHECK_SHAPE(cu_seqlens_q, B + 1);
+  CHECK_SHAPE(cu_seqlens_k, B + 1);
+  TORCH_CHECK(D <= 256 && D % 8 == 0, "head_size must be a multiple of 8 and at most 256");
+  TORCH_CHECK(H % Hk == 0, "Number of heads in key/value must divide number of heads in query");
+  CHECK_SHAPE(k, total_k, Hk, D);
+  CHECK_SHAPE(v, total_k, Hk, D);
+  if (seqused_k.has_value()) {
+    TORCH_CHECK(seqused_k->dtype() == at::kInt, "seqused_k must have dtype int32");
+    CHECK_DEVICE(*seqused_k);
+    TORCH_CHECK(seqused_k->is_contiguous(), "seqused_k must be contiguous");
+    CHECK_SHAPE(*seqused_k, B);
+  }
+  c10::DeviceGuard guard(q.device());
+  const int64_t Dn = native_head_dim(D);
+  const Tensor qp = pad_d(q, Dn), kp = pad_d(k, Dn), vp = pad_d(v, Dn);
+  if (out_.has_value()) {
+    TORCH_CHECK(out_->dtype() == q.dtype(), "Output must have the same dtype as inputs");
+    CHECK_DEVICE(*out_); CHECK_LAST_CONTIG(*out_); CHECK_SHAPE(*out_, total_q, H, D);
+  }
+  Tensor out = (out_.has_value() && Dn == D) ? *out_ : at::empty({total_q, H, Dn}, q.options());
+  Tensor lse = at::empty({H, total_q}, q.options().dtype(at::kFloat));
+  Tensor rng_state = at::empty({2}, q.options().dtype(at::kLong));
+  Tensor p = at::empty({0}, q.options());
+  if (zero_tensors) {  // flash_api.cpp:693-697
+    out.zero_();
+    lse.fill_(-std::numeric_limits<float>::infinity());
+  }
+  if (max_seqlen_k == 0 || total_k == 0) {
+    out.zero_();
+    lse.fill_(std::numeric_limits<float>::infinity());
+  } else if (total_q > 0 && max_seqlen_q > 0) {
+    FaFwdParams a{};
+    a.q = qp.data_ptr(); a.k = kp.data_ptr(); a.v = vp.data_ptr(); a.o = out.data_ptr(); a.softmax_lse = lse.data_ptr<float>();
+    a.q_row_stride = qp.stride(0); a.q_head_stride = qp.stride(1);
+    a.k_row_stride = kp.stride(0); a.k_head_stride = kp.stride(1);
+    a.v_row_stride = vp.stride(0); a.v_head_stride = vp.stride(1);
+    a.o_row_stride = out.stride(0); a.o_head_stride = out.stride(1);
+    a.cu_seqlens_q = cu_seqlens_q.data_ptr<int>(); a.cu_seqlens_k = cu_seqlens_k.data_ptr<int>();
+    a.seqused_k = seqused_k.has_value() ? seqused_k->data_ptr<int>() : nullptr;
+    set_alibi(alibi_slopes_, B, H, a.alibi_slopes, a.alibi_batch_stride);
+    a.b = B; a.h = H; a.h_k = Hk; a.d = Dn; a.seqlen_q = (int)max_seqlen_q; a.seqlen_k = (int)max_seqlen_k; a.total_q = total_q;
+    a.dtype = dtype_code(q);
+    a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
+    a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap;
+    fa_check(fa_varlen_fwd(&a, cur_stream(q)));
+  }
+  if (Dn != D) {
+    Tensor res = out.slice(-1, 0, D);
+    if (out_.has_value()) { out_->copy_(res); res = *out_; }
+    out = res;
+  }
+  return {out, lse, p, rng_state};
+}
+
+Tensor grad_buffer(const OptTensor& g_, const Tensor& like, const char* name) {
+  if (!g_.has_value()) return at::empty_like(like);
+  TORCH_CHECK(g_->dtype() == like.dtype(), name, " must have the same dtype as q");
+  TORCH_CHECK(g_->is_cuda(), name, " must be on CUDA");
+  TORCH_CHECK(g_->stride(-1) == 1, name, " must have contiguous last dimension");
+  TORCH_CHECK(g_->sizes() == like.sizes(), name, " has the wrong shape");
+  return *g_;
+}
+
+struct BwdBufs {
+  Tensor dout, q, k, v, out, dq, dk, dv;  // tensors handed to the kernels (padded copies when D is not native)
+};
+
+void run_bwd(FaBwdParams& a, const Tensor& q, bool varlen) {
+  const int64_t ws = fa_bwd_workspace_bytes(&a);
+  Tensor wsbuf;
+  if (ws > 0) {
+    wsbuf = at::empty({ws}, q.options().dtype(at::kByte));
+    a.workspace = wsbuf.data_ptr();
+    a.workspace_bytes = ws;
+  }
+  fa_check(varlen ? fa_varlen_bwd(&a, cur_stream(q)) : fa_bwd(&a, cur_stream(q)));
+}
+
+void fill_bwd_ptrs(FaBwdParams& a, const BwdBufs& t, const Tensor& lse, Tensor& delta) {
+  a.dout = t.dout.data_ptr(); a.q = t.q.data_ptr(); a.k = t.k.data_ptr(); a.v = t.v.data_ptr(); a.o = t.out.data_ptr();
+  a.softmax_lse = lse.data_ptr<float>();
+  a.dq = t.dq.data_ptr(); a.dk = t.dk.data_ptr(); a.dv = t.dv.data_ptr(); a.softmax_d = delta.data_ptr<float>();
+}
+
+#define SET3(nm, T_) a.nm##_batch_stride = (T_).stride(0); a.nm##_row_stride = (T_).stride(1); a.nm##_head_stride = (T_).stride(2);
+#define SET2(nm, T_) a.nm##_row_stride = (T_).stride(0); a.nm##_head_stride = (T_).stride(1);
+
+std::vector<Tensor> mha_bwd(const Tensor& dout, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& out,
+                            const Tensor& softmax_lse, OptTensor& dq_, OptTensor& dk_, OptTensor& dv_, OptTensor& alibi_slopes_,
+                            const double p_dropout, const double softmax_scale, const bool is_causal, int64_t window_size_left,
+                            int64_t window_size_right, const double softcap, const bool deterministic,
+                            std::optional<at::Generator> gen_, OptTensor& rng_state) {
+  common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
+  CHECK_DEVICE(dout); CHECK_DEVICE(out); CHECK_DEVICE(softmax_lse);
+  TORCH_CHECK(dout.dtype() == q.dtype() && out.dtype() == q.dtype(), "query and dout/out must have the same dtype");
+  TORCH_CHECK(out.stride(-1) == 1, "out tensor must have contiguous last dimension");
+  TORCH_CHECK(dout.stride(-1) == 1, "dout tensor must have contiguous last dimension");
+  TORCH_CHECK(softmax_lse.dtype() == at::kFloat && softmax_lse.is_contiguous(), "softmax_lse must be contiguous fp32");
+  const int64_t B = q.size(0), Sq = q.size(1), H = q.size(2), D = q.size(3), Sk = k.size(1), Hk = k.size(2);
+  TORCH_CHECK(B > 0, "batch size must be positive");
+  TORCH_CHECK(D % 8 == 0, "head_size should be a multiple of 8");
+  TORCH_CHECK(D <= 256, "FlashAttention backward only supports head dimension at most 256");
+  TORCH_CHECK(H % Hk == 0, "Number of heads in key/value must divide number of heads in query");
+  CHECK_SHAPE(k, B, Sk, Hk, D); CHECK_SHAPE(v, B, Sk, Hk, D); CHECK_SHAPE(out, B, Sq, H, D); CHECK_SHAPE(dout, B, Sq, H, D);
+  CHECK_SHAPE(softmax_lse, B, H, Sq);
+  c10::DeviceGuard guard(q.device());
+  Tensor dq = grad_buffer(dq_, q, "dq"), dk = grad_buffer(dk_, k, "dk"), dv = grad_buffer(dv_, v, "dv");
+  Tensor delta = at::empty({B, H, Sq}, q.options().dtype(at::kFloat));  // ROCm shape convention (mha_bwd.cpp:340)
+  if (Sq == 0 || Sk == 0) {  // flash_api.cpp:992-999
+    dq.zero_(); dk.zero_(); dv.zero_(); delta.zero_();
+    return {dq, dk, dv, delta};
+  }
+  const int64_t Dn = native_head_dim(D);
+  BwdBufs t{pad_d(dout, Dn), pad_d(q, Dn), pad_d(k, Dn), pad_d(v, Dn), pad_d(out, Dn), dq, dk, dv};
+  if (Dn != D) {
+    t.dq = at::empty({B, Sq, H, Dn}, q.options());
+    t.dk = at::empty({B, Sk, Hk, Dn}, q.options());
+    t.dv = at::empty({B, Sk, Hk, Dn}, q.options());
+  }
+  FaBwdParams a{};
+  fill_bwd_ptrs(a, t, softmax_lse, delta);
+  SET3(do, t.dout) SET3(q, t.q) SET3(k, t.k) SET3(v, t.v) SET3(o, t.out) SET3(dq, t.dq) SET3(dk, t.dk) SET3(dv, t.dv)
+  set_alibi(alibi_slopes_, B, H, a.alibi_slopes, a.alibi_batch_stride);
+  a.b = B; a.h = H; a.h_k = Hk; a.d = Dn; a.seqlen_q = Sq; a.seqlen_k = Sk; a.total_q = B * Sq; a.total_k = B * Sk;
+  a.dtype = dtype_code(q);
+  a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
+  a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap; a.deterministic = deterministic;
+  run_bwd(a, q, false);
+  if (Dn != D) {
+    dq.copy_(t.dq.slice(-1, 0, D)); dk.copy_(t.dk.slice(-1, 0, D)); dv.copy_(t.dv.slice(-1, 0, D));
+  }
+  return {dq, dk, dv, delta};
+}
+
+std::vector<Tensor> mha_varlen_bwd(const Tensor& dout, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& out,
+                                   const Tensor& softmax_lse, OptTensor& dq_, OptTensor& dk_, OptTensor& dv_,
+                                   const Tensor& cu_seqlens_q, const Tensor& cu_seqlens_k, OptTensor& alibi_slopes_,
+                                   const int64_t max_seqlen_q, const int64_t max_seqlen_k, const double p_dropout,
+                                   const double softmax_scale, const bool zero_tensors, const bool is_causal,
+                                   int64_t window_size_left, int64_t window_size_right, const double softcap,
+                                   const bool deterministic, std::optional<at::Generator> gen_, OptTensor& rng_state) {
+  common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
+  CHECK_DEVICE(dout); CHECK_DEVICE(out); CHECK_DEVICE(softmax_lse); CHECK_DEVICE(cu_seqlens_q); CHECK_DEVICE(cu_seqlens_k);
+  TORCH_CHECK(dout.dtype() == q.dtype() && out.dtype() == q.dtype(), "query and dout/out must have the same dtype");
+  TORCH_CHECK(cu_seqlens_q.dtype() == at::kInt && cu_seqlens_k.dtype() == at::kInt, "cu_seqlens_q/k must have dtype int32");
+  TORCH_CHECK(cu_seqlens_q.is_contiguous() && cu_seqlens_k.is_contiguous(), "cu_seqlens_q/k must be contiguous");
+  TORCH_CHECK(out.stride(-1) == 1 && dout.stride(-1) == 1, "out/dout tensor must have contiguous last dimension");
+  TORCH_CHECK(softmax_lse.dtype() == at::kFloat && softmax_lse.is_contiguous(), "softmax_lse must be contiguous fp32");
+  const int64_t total_q = q.size(0), H = q.size(1), D = q.size(2), total_k = k.size(0), Hk = k.size(1);
+  const int64_t B = cu_seqlens_q.numel() - 1;
+  TORCH_CHECK(B > 0, "batch size must be positive");
+  TORCH_CHECK(D % 8 == 0 && D <= 256, "head_size should be a multiple of 8 and at most 256");
+  TORCH_CHECK(H % Hk == 0, "Number of heads in key/value must divide number of heads in query");
+  CHECK_SHAPE(k, total_k, Hk, D); CHECK_SHAPE(v, total_k, Hk, D); CHECK_SHAPE(out, total_q, H, D); CHECK_SHAPE(dout, total_q, H, D);
+  CHECK_SHAPE(cu_seqlens_q, B + 1); CHECK_SHAPE(cu_seqlens_k, B + 1);
+  CHECK_SHAPE(softmax_lse, H, total_q);
+  c10::DeviceGuard guard(q.device());
+  Tensor dq = grad_buffer(dq_, q, "dq"), dk = grad_buffer(dk_, k, "dk"), dv = grad_buffer(dv_, v, "dv");
+  Tensor delta = at::empty({H, total_q}, q.options().dtype(at::kFloat));
+  if (zero_tensors) { dq.zero_(); dk.zero_(); dv.zero_(); delta.zero_(); }  // flash_api.cpp:1171-1176
+  if (max_seqlen_q == 0 || total_q == 0 || total_k == 0) {
+    dq.zero_(); dk.zero_(); dv.zero_(); delta.zero_();
+    return {dq, dk, dv, delta};
+  }
+  const int64_t Dn = native_head_dim(D);
+  BwdBufs t{pad_d(dout, Dn), pad_d(q, Dn), pad_d(k, Dn), pad_d(v, Dn), pad_d(out, Dn), dq, dk, dv};
+  if (Dn != D) {
+    t.dq = at::empty({total_q, H, Dn}, q.options());
+    t.dk = at::empty({total_k, Hk, Dn}, q.options());
+    t.dv = at::empty({total_k, Hk, Dn}, q.options());
+  }
+  FaBwdParams a{};
+  fill_bwd_ptrs(a, t, softmax_lse, delta);
+  SET2(do, t.dout) SET2(q, t.q) SET2(k, t.k) SET2(v, t.v) SET2(o, t.out) SET2(dq, t.dq) SET2(dk, t.dk) SET2(dv, t.dv)
+  a.cu_seqlens_q = cu_seqlens_q.data_ptr<int>(); a.cu_seqlens_k = cu_seqlens_k.data_ptr<int>();
+  set_alibi(alibi_slopes_, B, H, a.alibi_slopes, a.alibi_batch_stride);
+  a.b = B; a.h = H; a.h_k = Hk; a.d = Dn; a.seqlen_q = (int)max_seqlen_q; a.seqlen_k = (int)max_seqlen_k;
+  a.total_q = total_q; a.total_k = total_k;
+  a.dtype = dtype_code(q);
+  a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
+  a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap; a.deterministic = deterministic;
+  run_bwd(a, q, true);
+  if (Dn != D) {
+    dq.copy_(t.dq.slice(-1, 0, D)); dk.copy_(t.dk.slice(-1, 0, D)); dv.copy_(t.dv.slice(-1, 0, D));
+  }
+  return {dq, dk, dv, delta};
+}
+
+std::vector<Tensor> mha_fwd_kvcache(pybind11::args, pybind11::kwargs) {
+  TORCH_CHECK(false, "libfa_gfx950: fwd_kvcache (split-KV decode / paged KV) is not built yet");
+  return {};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "MI355X-native FlashAttention backend (gfx950 HIP kernels behind the flash_attn_2_cuda module API)";
+  m.def("fwd", &mha_fwd, "Forward pass");
+  m.def("varlen_fwd", &mha_varlen_fwd, "Forward pass (variable length)", pybind11::arg("q"), pybind11::arg("k"), pybind11::arg("v"),
+        pybind11::arg("out_"), pybind11::arg("cu_seqlens_q"), pybind11::arg("cu_seqlens_k"), pybind11::arg("seqused_k"),
+        pybind11::arg("leftpad_k_"), pybind11::arg("block_table_"), pybind11::arg("alibi_slopes_"), pybind11::arg("max_seqlen_q"),
+        pybind11::arg("max_seqlen_k"), pybind11::arg("p_dropout"), pybind11::arg("softmax_scale"), pybind11::arg("zero_tensors"),
+        pybind11::arg("is_causal"), pybind11::arg("window_size_left"), pybind11::arg("window_size_right"), pybind11::arg("softcap"),
+        pybind11::arg("return_softmax"), pybind11::arg("gen_"), pybind11::arg("num_splits") = 0);
+  m.def("bwd", &mha_bwd, "Backward pass");
+  m.def("varlen_bwd", &mha_varlen_bwd, "Backward pass (variable length)");
+  m.def("fwd_kvcache", &mha_fwd_kvcache, "Forward pass, with KV-cache");
+}

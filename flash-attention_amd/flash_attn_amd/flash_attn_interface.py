@@ -1,0 +1,202 @@
+"""Host-side mirror of the reference's public attention API for the MI355X backend.
+
+Same names, argument meaning and error behaviour as ``flash_attn/flash_attn_interface.py``
+(reference :1019-1482): ``flash_attn_func``, ``flash_attn_varlen_func``, the qkv-/kv-packed
+variants, and the raw ``_flash_attn_forward`` / ``_flash_attn_backward`` (+ varlen) wrappers.
+All compute goes to the gfx950 library through the backend module (``flash_attn_2_cuda`` torch
+extension when built, else the ctypes binder) -- there is no PyTorch fallback.
+
+A user of the reference can also keep importing ``flash_attn`` itself: with
+``flash-attention_amd/`` on ``sys.path`` the reference package picks up our ``flash_attn_2_cuda``
+unmodified.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+try:  # the C++ torch extension is the primary binder
+    import flash_attn_2_cuda as flash_attn_gpu  # type: ignore
+except ImportError:  # same C ABI through ctypes (raises if libfa_gfx950.so is missing)
+    from . import backend as flash_attn_gpu  # type: ignore
+
+__all__ = [
+    "flash_attn_func", "flash_attn_varlen_func", "flash_attn_qkvpacked_func", "flash_attn_kvpacked_func",
+    "flash_attn_varlen_qkvpacked_func", "flash_attn_varlen_kvpacked_func", "flash_attn_with_kvcache",
+    "_flash_attn_forward", "_flash_attn_backward", "_flash_attn_varlen_forward", "_flash_attn_varlen_backward",
+]
+
+
+def _unit_stride_last(x):
+    return x.contiguous() if x is not None and x.stride(-1) != 1 else x
+
+
+def _pad_head_dim(*ts):
+    """Head dims that are not a multiple of 8 are zero-padded (reference :851-854)."""
+    d = ts[0].shape[-1]
+    if d % 8 == 0:
+        return ts
+    pad = 8 - d % 8
+    return tuple(torch.nn.functional.pad(t, [0, pad]) for t in ts)
+
+
+def _flash_attn_forward(q, k, v, dropout_p, softmax_scale, causal, window_size_left, window_size_right,
+                        softcap, alibi_slopes, return_softmax):
+    q, k, v = (_unit_stride_last(t) for t in (q, k, v))
+    out, lse, s_dmask, rng_state = flash_attn_gpu.fwd(
+        q, k, v, None, alibi_slopes, dropout_p, softmax_scale, causal, window_size_left, window_size_right,
+        softcap, return_softmax, None)
+    return out, lse, s_dmask, rng_state
+
+
+def _flash_attn_varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
+                               softmax_scale, causal, window_size_left=-1, window_size_right=-1, softcap=0.0,
+                               alibi_slopes=None, return_softmax=False, block_table=None, leftpad_k=None,
+                               seqused_k=None, zero_tensors=False):
+    q, k, v = (_unit_stride_last(t) for t in (q, k, v))
+    out, lse, s_dmask, rng_state = flash_attn_gpu.varlen_fwd(
+        q, k, v, None, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k, block_table, alibi_slopes, max_seqlen_q,
+        max_seqlen_k, dropout_p, softmax_scale, zero_tensors, causal, window_size_left, window_size_right, softcap,
+        return_softmax, None)
+    return out, lse, s_dmask, rng_state
+
+
+def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, dropout_p, softmax_scale, causal,
+                         window_size_left, window_size_right, softcap, alibi_slopes, deterministic, rng_state=None):
+    dout, q, k, v, out = (_unit_stride_last(t) for t in (dout, q, k, v, out))
+    dq, dk, dv, softmax_d = flash_attn_gpu.bwd(
+        dout, q, k, v, out, softmax_lse, dq, dk, dv, alibi_slopes, dropout_p, softmax_scale, causal,
+        window_size_left, window_size_right, softcap, deterministic, None, rng_state)
+    return softmax_d
+
+
+def _flash_attn_varlen_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
+                                max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, window_size_left,
+                                window_size_right, softcap, alibi_slopes, deterministic, rng_state=None,
+                                zero_tensors=False):
+    dout, q, k, v, out = (_unit_stride_last(t) for t in (dout, q, k, v, out))
+    dq, dk, dv, softmax_d = flash_attn_gpu.varlen_bwd(
+        dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, alibi_slopes, max_seqlen_q,
+        max_seqlen_k, dropout_p, softmax_scale, zero_tensors, causal, window_size_left, window_size_right, softcap,
+        deterministic, None, rng_state)
+    return softmax_d
+
+
+class _AttnFn(torch.autograd.Function):
+    """Fixed-length attention with separate q, k, v (reference FlashAttnFunc :828-911)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
+                return_softmax, is_grad_enabled):
+        needs_grad = is_grad_enabled and any(t.requires_grad for t in (q, k, v))
+        if softmax_scale is None:
+            softmax_scale = q.shape[-1] ** (-0.5)
+        d_orig = q.shape[-1]
+        q, k, v = _pad_head_dim(q, k, v)
+        out_p, lse, s_dmask, rng_state = _flash_attn_forward(
+            q, k, v, dropout_p, softmax_scale, causal, window_size[0], window_size[1], softcap, alibi_slopes,
+            return_softmax and dropout_p > 0)
+        if needs_grad:
+            ctx.save_for_backward(q, k, v, out_p, lse, rng_state)
+            ctx.cfg = (dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic, d_orig)
+        out = out_p[..., :d_orig]
+        return out if not return_softmax else (out, lse, s_dmask)
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        q, k, v, out, lse, rng_state = ctx.saved_tensors
+        dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic, d_orig = ctx.cfg
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        (dout_p,) = _pad_head_dim(dout) if dout.shape[-1] % 8 else (dout,)
+        _flash_attn_backward(dout_p, q, k, v, out, lse, dq, dk, dv, dropout_p, softmax_scale, causal, window_size[0],
+                             window_size[1], softcap, alibi_slopes, deterministic, rng_state)
+        return (dq[..., :d_orig], dk[..., :d_orig], dv[..., :d_orig]) + (None,) * 9
+
+
+class _VarlenAttnFn(torch.autograd.Function):
+    """Packed variable-length attention (reference FlashAttnVarlenFunc :914-1016)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal,
+                window_size, softcap, alibi_slopes, deterministic, return_softmax, block_table, is_grad_enabled):
+        needs_grad = is_grad_enabled and any(t.requires_grad for t in (q, k, v))
+        if softmax_scale is None:
+            softmax_scale = q.shape[-1] ** (-0.5)
+        d_orig = q.shape[-1]
+        q, k, v = _pad_head_dim(q, k, v)
+        out_p, lse, s_dmask, rng_state = _flash_attn_varlen_forward(
+            q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal,
+            window_size[0], window_size[1], softcap, alibi_slopes, return_softmax and dropout_p > 0, block_table)
+        if needs_grad:
+            ctx.save_for_backward(q, k, v, out_p, lse, cu_seqlens_q, cu_seqlens_k, rng_state)
+            ctx.cfg = (max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                       deterministic, d_orig)
+        out = out_p[..., :d_orig]
+        return out if not return_softmax else (out, lse, s_dmask)
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        q, k, v, out, lse, cu_q, cu_k, rng_state = ctx.saved_tensors
+        mq, mk, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic, d_orig = ctx.cfg
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        (dout_p,) = _pad_head_dim(dout) if dout.shape[-1] % 8 else (dout,)
+        _flash_attn_varlen_backward(dout_p, q, k, v, out, lse, dq, dk, dv, cu_q, cu_k, mq, mk, dropout_p, softmax_scale,
+                                    causal, window_size[0], window_size[1], softcap, alibi_slopes, deterministic, rng_state)
+        return (dq[..., :d_orig], dk[..., :d_orig], dv[..., :d_orig]) + (None,) * 14
+
+
+def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                    alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """q (B,Sq,H,D); k, v (B,Sk,Hk,D) with H % Hk == 0 (MQA/GQA).  Causal / window masks are aligned to the
+    bottom-right corner; ``window_size=(l, r)`` lets query i see keys [i+Sk-Sq-l, i+Sk-Sq+r].
+    Returns out (B,Sq,H,D) (and softmax_lse (B,H,Sq), S_dmask when ``return_attn_probs``)."""
+    return _AttnFn.apply(q, k, v, dropout_p, softmax_scale, causal, tuple(window_size), softcap, alibi_slopes,
+                         deterministic, return_attn_probs, torch.is_grad_enabled())
+
+
+def flash_attn_kvpacked_func(q, kv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                             alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """kv (B,Sk,2,Hk,D): strided views are passed straight to the kernels (no copy)."""
+    return flash_attn_func(q, kv[:, :, 0], kv[:, :, 1], dropout_p, softmax_scale, causal, window_size, softcap,
+                           alibi_slopes, deterministic, return_attn_probs)
+
+
+def flash_attn_qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                              alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """qkv (B,S,3,H,D)."""
+    return flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p, softmax_scale, causal, window_size,
+                           softcap, alibi_slopes, deterministic, return_attn_probs)
+
+
+def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
+                           softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+                           deterministic=False, return_attn_probs=False, block_table=None):
+    """q (total_q,H,D); k, v (total_k,Hk,D); cu_seqlens_* int32 (B+1) cumulative lengths on the device.
+    Returns out (total_q,H,D) (and softmax_lse (H,total_q) when ``return_attn_probs``)."""
+    return _VarlenAttnFn.apply(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
+                               causal, tuple(window_size), softcap, alibi_slopes, deterministic, return_attn_probs,
+                               block_table, torch.is_grad_enabled())
+
+
+def flash_attn_varlen_kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
+                                    softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
+                                    alibi_slopes=None, deterministic=False, return_attn_probs=False):
+    """kv (total_k,2,Hk,D)."""
+    return flash_attn_varlen_func(q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                                  dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
+                                  return_attn_probs)
+
+
+def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
+                                     window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
+                                     return_attn_probs=False):
+    """qkv (total,3,H,D)."""
+    return flash_attn_varlen_func(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, cu_seqlens, max_seqlen, max_seqlen,
+                                  dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
+                                  return_attn_probs)
+
+
+def flash_attn_with_kvcache(*args, **kwargs):
+    """Decode path (reference :1485-1627): next row of the scope table, not built yet."""
+    return flash_attn_gpu.fwd_kvcache(*args, **kwargs)

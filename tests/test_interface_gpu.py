@@ -1,0 +1,107 @@
+"""GPU tests of the drop-in boundary: the flash_attn_func / flash_attn_varlen_func autograd path over the
+flash_attn_2_cuda torch extension, and extension == ctypes binder bit-for-bit (same C ABI underneath)."""
+import numpy as np
+import pytest
+import torch
+
+from tests._util import attention_torch, max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fi():
+    from flash_attn_amd import flash_attn_interface
+    assert flash_attn_interface.flash_attn_gpu.__name__ == "flash_attn_2_cuda", "C++ extension must be the loaded backend on the GPU box"
+    return flash_attn_interface
+
+
+@pytest.mark.parametrize("d", [40, 59, 64, 96, 111, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_flash_attn_func_autograd(fi, d, causal):
+    torch.manual_seed(0)
+    B, Sq, Sk, H, Hk = 2, 217, 333, 6, 2
+    q = torch.randn(B, Sq, H, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    k = torch.randn(B, Sk, Hk, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    v = torch.randn(B, Sk, Hk, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    do = torch.randn(B, Sq, H, d, device="cuda", dtype=torch.bfloat16)
+    out = fi.flash_attn_func(q, k, v, causal=causal)
+    assert out.shape == (B, Sq, H, d)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+    qf, kf, vf = (t.detach().float().requires_grad_() for t in (q, k, v))
+    ref, _ = attention_torch(qf, kf, vf, causal, upcast=True)
+    rq, rk, rv = torch.autograd.grad(ref, (qf, kf, vf), do.float())
+    qb, kb, vb = (t.detach().clone().requires_grad_() for t in (q, k, v))
+    pt, _ = attention_torch(qb, kb, vb, causal, upcast=False, reorder=True)
+    pq, pk, pv = torch.autograd.grad(pt, (qb, kb, vb), do)
+    assert max_abs(out.float(), ref) <= 2 * max_abs(pt.float(), ref) + 1e-5
+    for got, r, p_ in ((dq, rq, pq), (dk, rk, pk), (dv, rv, pv)):
+        assert max_abs(got.float(), r) <= 3 * max_abs(p_.float(), r) + 1e-4
+
+
+def test_packed_variants_and_return_lse(fi):
+    torch.manual_seed(1)
+    qkv = torch.randn(2, 130, 3, 4, 64, device="cuda", dtype=torch.float16, requires_grad=True)
+    out, lse, _ = fi.flash_attn_qkvpacked_func(qkv, causal=True, return_attn_probs=True)
+    ref, lse_ref = attention_torch(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], True)
+    assert max_abs(out.float(), ref.float()) < 5e-3 and max_abs(lse, lse_ref) < 2e-3
+    (g,) = torch.autograd.grad(out, qkv, torch.ones_like(out))
+    assert g.shape == qkv.shape and not torch.isnan(g).any()
+    kv = torch.randn(2, 77, 2, 2, 64, device="cuda", dtype=torch.float16)
+    q = torch.randn(2, 50, 4, 64, device="cuda", dtype=torch.float16)
+    o2 = fi.flash_attn_kvpacked_func(q, kv, window_size=(10, 5))
+    r2, _ = attention_torch(q, kv[:, :, 0], kv[:, :, 1], False, (10, 5))
+    assert max_abs(o2.float(), r2.float()) < 5e-3
+
+
+def test_varlen_func_autograd_matches_padded(fi):
+    torch.manual_seed(2)
+    lens = [33, 128, 1, 200]
+    H, Hk, d = 4, 4, 128
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    q = torch.randn(sum(lens), H, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    k = torch.randn(sum(lens), Hk, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    v = torch.randn(sum(lens), Hk, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    do = torch.randn_like(q)
+    out = fi.flash_attn_varlen_func(q, k, v, cu, cu, max(lens), max(lens), causal=True)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), do)
+    for b in range(len(lens)):
+        s0, s1 = int(cu[b]), int(cu[b + 1])
+        qq, kk, vv = (t[None, s0:s1].detach().clone().requires_grad_() for t in (q, k, v))
+        o1 = fi.flash_attn_func(qq, kk, vv, causal=True)
+        g = torch.autograd.grad(o1, (qq, kk, vv), do[None, s0:s1])
+        assert torch.equal(out[s0:s1], o1[0])
+        assert torch.equal(dq[s0:s1], g[0][0]) and torch.equal(dk[s0:s1], g[1][0]) and torch.equal(dv[s0:s1], g[2][0])
+
+
+def test_extension_and_ctypes_binders_agree_bitwise():
+    import flash_attn_2_cuda as ext
+    from flash_attn_amd import backend as cty
+    torch.manual_seed(3)
+    q = torch.randn(2, 300, 8, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(2, 411, 2, 128, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    do = torch.randn_like(q)
+    sc = 128 ** -0.5
+    a = ext.fwd(q, k, v, None, None, 0.0, sc, True, -1, -1, 0.0, False, None)
+    b = cty.fwd(q, k, v, None, None, 0.0, sc, True, -1, -1, 0.0, False, None)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    ga = ext.bwd(do, q, k, v, a[0], a[1], None, None, None, None, 0.0, sc, True, -1, -1, 0.0, False, None, None)
+    gb = cty.bwd(do, q, k, v, b[0], b[1], None, None, None, None, 0.0, sc, True, -1, -1, 0.0, False, None, None)
+    for x, y in zip(ga, gb):
+        assert torch.equal(x, y)
+
+
+def test_extension_error_messages(fi):
+    import flash_attn_2_cuda as ext
+    q = torch.randn(1, 8, 2, 64, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="block_table"):
+        ext.varlen_fwd(q[0], q[0], q[0], None, torch.tensor([0, 8], dtype=torch.int32, device="cuda"),
+                       torch.tensor([0, 8], dtype=torch.int32, device="cuda"), None, None, torch.zeros(1, 1, dtype=torch.int32, device="cuda"),
+                       None, 8, 8, 0.0, 0.125, False, False, -1, -1, 0.0, False, None)
+    with pytest.raises(RuntimeError, match="num_splits > 1 is not supported"):
+        ext.varlen_fwd(q[0], q[0], q[0], None, torch.tensor([0, 8], dtype=torch.int32, device="cuda"),
+                       torch.tensor([0, 8], dtype=torch.int32, device="cuda"), None, None, None, None, 8, 8, 0.0, 0.125, False, False,
+                       -1, -1, 0.0, False, None, 2)
+    with pytest.raises(RuntimeError):
+        ext.fwd(q.float(), q.float(), q.float(), None, None, 0.0, 0.125, False, -1, -1, 0.0, False, None)
