@@ -7,6 +7,7 @@
 // (window/causal normalisation :155-162 and :422-427).  No ATen here: buffers are caller-owned.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -89,9 +90,26 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen) {
   k.scale = a->softmax_scale;
   k.scale_log2 = a->softmax_scale * 1.4426950408889634f;
   k.softcap = a->softcap;
+  // Deferred O rescale: the running max only moves when a row's max grew by more than this many log2
+  // units (P stays <= 2^thr; fp32 accumulators and the relative precision of bf16/fp16 P are unaffected).
+  // 0 reproduces the reference's rescale-on-any-growth rule exactly.  Default 8 (measured +4..10 %,
+  // parity suite unchanged); override with FA_RESCALE_THR.
+  {
+    const char* t = getenv("FA_RESCALE_THR");
+    k.rescale_thr = (t && *t) ? (float)atof(t) : 8.f;
+    if (!(k.rescale_thr >= 0.f) || k.rescale_thr > 16.f) k.rescale_thr = 0.f;
+  }
 
+  // Schedule (measured on MI355X, tools/ab_bench.py): 4 waves x 2 workgroups per CU de-phase naturally and
+  // win whenever a block has < ~128 key tiles; the 8-wave ping-pong schedule wins on longer key loops.
+  // 4 / 8 = lock-step kernel with 4 / 8 waves per workgroup, 16 = 8-wave ping-pong; FA_FWD_NW overrides.
   int nw = env_int("FA_FWD_NW", 0);
-  if (nw != 4 && nw != 8) nw = (a->seqlen_q <= 128) ? 4 : 8;
+  if (nw != 4 && nw != 8 && nw != 16) {
+    const bool right_bounded = (wr >= 0);
+    const long avg_keys = right_bounded ? (a->seqlen_k + 1) / 2 : a->seqlen_k;
+    const long span = (wl >= 0) ? std::min<long>(avg_keys, wl + (wr >= 0 ? wr : a->seqlen_k) + 256) : avg_keys;
+    nw = (a->d == 128 && span / 64 >= 128 && a->seqlen_q >= 512) ? 16 : 4;
+  }
   const int bm = fa::fwd_block_m(nw);
   k.nmb = (a->seqlen_q + bm - 1) / bm;
   const int rc = fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);

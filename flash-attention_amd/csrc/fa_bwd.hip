@@ -89,10 +89,8 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
   constexpr int KS = D / 16, DB = D / 32;
   constexpr int VBLK_BYTES = BNK * ROW_BYTES;
   constexpr int QT_BYTES = BMQ * ROW_BYTES;
-  constexpr int LDQ = (BMQ * CPR) / NT;  // 16-B chunks per thread per streamed tile (Q and dO each)
-  static_assert(LDQ >= 1, "tile too small for the workgroup");
-  // LDS: V block | Q0 | Q1 | dO0 | dO1 | lse0 lse1 | delta0 delta1
-  constexpr int OFF_Q = VBLK_BYTES, OFF_DO = OFF_Q + 2 * QT_BYTES, OFF_LSE = OFF_DO + 2 * QT_BYTES, OFF_DEL = OFF_LSE + 2 * BMQ * 4;
+  // LDS: V block | Q0 | Q1 | dO0 | dO1 | aux0 aux1   (aux = BMQ x LSE*log2e followed by BMQ x delta)
+  constexpr int OFF_Q = VBLK_BYTES, OFF_DO = OFF_Q + 2 * QT_BYTES, OFF_AUX = OFF_DO + 2 * QT_BYTES;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char FA_LDS* lds = (char FA_LDS*)smem;
@@ -151,56 +149,60 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
     }
   }
 
-  // ---- streamed tile staging --------------------------------------------------------------------
-  u32x4 qreg[LDQ], doreg[LDQ];
-  float lse_reg = 0.f, del_reg = 0.f;
+  // ---- streamed tile staging: Q / dO tiles go global -> LDS by DMA (global_load_lds, 1 KiB per wave
+  // instruction, no staging registers); the XOR swizzle is applied to the per-lane SOURCE address because
+  // the DMA destination is lane-linear.  Rows past the sequence end are clamped to the last row: their
+  // LSE is +inf, so P = dS = 0 and they contribute nothing.
+  constexpr int RPD = 1024 / ROW_BYTES;            // tile rows per DMA instruction
+  constexpr int NDMA = (BMQ * ROW_BYTES) / 1024;   // DMA instructions per tile
+  constexpr int DPW = NDMA / NW;                   // per wave
+  static_assert(NDMA % NW == 0 && DPW >= 1, "tile does not divide over the waves");
+  float aux_reg = 0.f;  // threads [0,BMQ): LSE*log2e of row tid; [BMQ,2BMQ): delta of row tid-BMQ
   auto item_head = [&](int it) { return hk * p.hk_ratio + it / nm; };
   auto item_m0 = [&](int it) { return (m_lo + it % nm) * BMQ; };
-  auto load_item = [&](int it) {
+  auto load_item = [&](int it, int buf) {
     const int h = item_head(it);
     const int m0 = item_m0(it);
     const E* qp = (const E*)p.q + q_boff + q_row0 * p.q_rs + (int64_t)h * p.q_hs;
     const E* dop = (const E*)p.dout + do_boff + q_row0 * p.do_rs + (int64_t)h * p.do_hs;
 #pragma unroll
-    for (int i = 0; i < LDQ; ++i) {
-      const int idx = tid + i * NT;
-      const int row = idx / CPR, ch = idx % CPR;
-      const bool ok = (m0 + row) < sq;
-      qreg[i] = ld_global_16B(qp + (int64_t)(m0 + row) * p.q_rs + ch * 8, ok);
-      doreg[i] = ld_global_16B(dop + (int64_t)(m0 + row) * p.do_rs + ch * 8, ok);
+    for (int i = 0; i < DPW; ++i) {
+      const int idx = wave * DPW + i;
+      const int row = idx * RPD + lane / CPR;
+      const int pc = lane % CPR;
+      const int grow = min(m0 + row, sq - 1);
+      const int c = pc ^ swz16<D>(row);
+      const E* qsrc = qp + (int64_t)grow * p.q_rs + c * 8;
+      const E* dsrc = dop + (int64_t)grow * p.do_rs + c * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)qsrc,
+                                       (void FA_LDS*)(lds + OFF_Q + buf * QT_BYTES + idx * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)dsrc,
+                                       (void FA_LDS*)(lds + OFF_DO + buf * QT_BYTES + idx * 1024), 16, 0, 0);
     }
     if (tid < 2 * BMQ) {
       const int r = tid & (BMQ - 1);
       const bool ok = (m0 + r) < sq;
       const int64_t base = p.cu_q ? ((int64_t)h * p.total_q + q_row0) : (((int64_t)b * p.h + h) * p.sq);
-      if (tid < BMQ) lse_reg = ok ? p.lse[base + m0 + r] * kLog2e : INFINITY;  // rows past the end: P = 0
-      else del_reg = ok ? p.delta[base + m0 + r] : 0.f;
+      const float* src = (tid < BMQ ? p.lse : p.delta) + base + m0 + r;
+      const float x = ok ? *src : 0.f;
+      aux_reg = (tid < BMQ) ? (ok ? x * kLog2e : INFINITY) : x;  // rows past the end: LSE = +inf => P = 0
     }
   };
   auto store_item = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < LDQ; ++i) {
-      const int idx = tid + i * NT;
-      const int row = idx / CPR, ch = idx % CPR;
-      *(u32x4 FA_LDS*)(lds + OFF_Q + buf * QT_BYTES + tile_off<D>(row, ch)) = qreg[i];
-      *(u32x4 FA_LDS*)(lds + OFF_DO + buf * QT_BYTES + tile_off<D>(row, ch)) = doreg[i];
-    }
-    if (tid < BMQ) *(float FA_LDS*)(lds + OFF_LSE + (buf * BMQ + tid) * 4) = lse_reg;
-    else if (tid < 2 * BMQ) *(float FA_LDS*)(lds + OFF_DEL + (buf * BMQ + tid - BMQ) * 4) = del_reg;
+    if (tid < 2 * BMQ) *(float FA_LDS*)(lds + OFF_AUX + (buf * 2 * BMQ + tid) * 4) = aux_reg;
   };
 
   // per-lane LDS read offsets
   const int row_off = tile_off<D>(ki, 0) - (swz16<D>(ki) << 4);  // = ki * ROW_BYTES
   const int rswz = swz16<D>(ki);
   const int tr_i = lane & 15, tr_half = (lane >> 4) & 1, tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
-  int tr_off[DB][2];
+  // offset(db, s) = tr_base[s] ^ (db << 6): the d-block index only enters through XOR on the 64-B chunk bits
+  int tr_base[2];
 #pragma unroll
-  for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int row = 8 * s + 4 * hi + tr_rr;
-      tr_off[db][s] = tile_off<D>(row, 4 * db + 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
-    }
+  for (int s = 0; s < 2; ++s) {
+    const int row = 8 * s + 4 * hi + tr_rr;
+    tr_base[s] = tile_off<D>(row, 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
+  }
 
   f32x16 dk_acc[DB], dv_acc[DB];
 #pragma unroll
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
   const float cs = p.alibi ? kLog2e : p.scale_log2;
 
   if (n_items > 0) {
-    load_item(0);
+    load_item(0, 0);
     store_item(0);
   }
   __syncthreads();
@@ -219,13 +221,13 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
   for (int it = 0; it < n_items; ++it) {
     const int cur = it & 1;
     const bool has_next = it + 1 < n_items;
-    if (has_next) load_item(it + 1);
+    if (has_next) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
     const int m0 = item_m0(it);
     const float slope = p.alibi ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
     const char FA_LDS* qbuf = lds + OFF_Q + cur * QT_BYTES;
     const char FA_LDS* dobuf = lds + OFF_DO + cur * QT_BYTES;
 
-#pragma unroll
+#pragma unroll 1
     for (int qb = 0; qb < BMQ / 32; ++qb) {
       const int q0 = m0 + 32 * qb;
       bool active = wave_valid && q0 < sq;
@@ -275,9 +277,9 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
       V8 pfrag[2], dsfrag[2];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int qoff = (cur * BMQ + qb * 32 + 8 * g + 4 * hi) * 4;
-        const f32x4 l4 = *(const f32x4 FA_LDS*)(lds + OFF_LSE + qoff);
-        const f32x4 d4 = *(const f32x4 FA_LDS*)(lds + OFF_DEL + qoff);
+        const int qoff = (cur * 2 * BMQ + qb * 32 + 8 * g + 4 * hi) * 4;
+        const f32x4 l4 = *(const f32x4 FA_LDS*)(lds + OFF_AUX + qoff);
+        const f32x4 d4 = *(const f32x4 FA_LDS*)(lds + OFF_AUX + BMQ * 4 + qoff);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
@@ -294,11 +296,11 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
           const int base = (qb * 32 + 16 * t) * ROW_BYTES;
-          const s16x4 d_lo = lds_read_tr16(dobuf + base + tr_off[db][0]);
-          const s16x4 d_hi = lds_read_tr16(dobuf + base + tr_off[db][1]);
+          const s16x4 d_lo = lds_read_tr16(dobuf + base + (tr_base[0] ^ (db << 6)));
+          const s16x4 d_hi = lds_read_tr16(dobuf + base + (tr_base[1] ^ (db << 6)));
           dv_acc[db] = T::mfma(combine_tr<V8>(d_lo, d_hi), pfrag[t], dv_acc[db]);
-          const s16x4 q_lo4 = lds_read_tr16(qbuf + base + tr_off[db][0]);
-          const s16x4 q_hi4 = lds_read_tr16(qbuf + base + tr_off[db][1]);
+          const s16x4 q_lo4 = lds_read_tr16(qbuf + base + (tr_base[0] ^ (db << 6)));
+          const s16x4 q_hi4 = lds_read_tr16(qbuf + base + (tr_base[1] ^ (db << 6)));
           dk_acc[db] = T::mfma(combine_tr<V8>(q_lo4, q_hi4), dsfrag[t], dk_acc[db]);
         }
       }
@@ -434,14 +436,13 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
   const int row_off = qi * ROW_BYTES;
   const int rswz = swz16<D>(qi);
   const int tr_i = lane & 15, tr_half = (lane >> 4) & 1, tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
-  int tr_off[DB][2];
+  // offset(db, s) = tr_base[s] ^ (db << 6): the d-block index only enters through XOR on the 64-B chunk bits
+  int tr_base[2];
 #pragma unroll
-  for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int row = 8 * s + 4 * hi + tr_rr;
-      tr_off[db][s] = tile_off<D>(row, 4 * db + 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
-    }
+  for (int s = 0; s < 2; ++s) {
+    const int row = 8 * s + 4 * hi + tr_rr;
+    tr_base[s] = tile_off<D>(row, 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
+  }
 
   f32x16 dq_acc[DB];
 #pragma unroll
@@ -512,8 +513,8 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
 #pragma unroll
           for (int db = 0; db < DB; ++db) {
             const int base = (kb * 32 + 16 * t) * ROW_BYTES;
-            const s16x4 lo = lds_read_tr16(kbuf + base + tr_off[db][0]);
-            const s16x4 hi4 = lds_read_tr16(kbuf + base + tr_off[db][1]);
+            const s16x4 lo = lds_read_tr16(kbuf + base + (tr_base[0] ^ (db << 6)));
+            const s16x4 hi4 = lds_read_tr16(kbuf + base + (tr_base[1] ^ (db << 6)));
             dq_acc[db] = T::mfma(combine_tr<V8>(lo, hi4), dsfrag[t], dq_acc[db]);
           }
         }

@@ -48,6 +48,20 @@ FA_DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // value held by lane (l ^ 32)
 FA_DEVINL float xchg_half(float x) { return __shfl_xor(x, 32); }
 
+// max / sum of a value with the one held by lane (l ^ 32), via v_permlane32_swap (no LDS round trip):
+// with vdst = src = x the swap returns {r0, r1} where lanes 0-31 see (own, other) and lanes 32-63
+// see (other, own) -- verified by probe_gfx950.hip -- so any symmetric combine needs no select.
+FA_DEVINL float half_max(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+FA_DEVINL float half_sum(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 // 16-byte global load of 8 consecutive 16-bit elements; zeros when !valid.
 FA_DEVINL u32x4 ld_global_16B(const void* p, bool valid) {
   u32x4 z = {0u, 0u, 0u, 0u};

@@ -6,33 +6,49 @@
 //
 //   * one workgroup = NW waves, each wave owns 32 query rows for the whole key loop
 //     (BM = 32*NW rows per workgroup); K/V tiles of BN = 64 keys are staged once per
-//     workgroup through LDS (register-staged, double buffered, one barrier per tile);
+//     workgroup through LDS (register-staged, double buffered);
 //   * both contractions run "swapped" on v_mfma_f32_32x32x16: S^T[key][query] and
 //     O^T[d][query].  In the accumulator layout column = lane&31, so EVERY per-query quantity
-//     (running max m, running sum l, rescale factor, LSE) is lane-local: the row max is a
-//     31-op in-register reduction plus one exchange with lane^32, and the O rescale is a
-//     per-lane scalar multiply;
+//     (running max m, running sum l, rescale factor, LSE) is lane-local: the row max is an
+//     in-register reduction plus one exchange with lane^32 (v_permlane32_swap), and the O rescale
+//     is a per-lane scalar multiply;
 //   * P^T needs no shuffle to become the next MFMA's B operand: the k-index permutation the
 //     accumulator layout induces on the keys is applied to V instead, by choosing which 4-key
 //     groups each ds_read_b64_tr_b16 (LDS transpose read) fetches;
 //   * K tile rows are XOR-swizzled at 16-B granularity (conflict-free ds_read_b128 A operands),
-//     V tile rows at 64-B granularity (conflict-free transpose reads);
+//     V tile rows at 64-B granularity (conflict-free transpose reads); measured
+//     SQ_LDS_BANK_CONFLICT = 0 (profiles/r01_pmc_v1.txt);
+//   * the issue port, not the matrix pipe, is the scarce resource (one VALU slot ~ 4 cycles, an
+//     MFMA 32): the key loop is unrolled by two so every LDS address is a loop-invariant register
+//     plus an immediate, global tile loads use a scalar base + 32-bit lane offset, and the O
+//     rescale is skipped unless some row's maximum grew by more than `rescale_thr` (log2 units;
+//     0 = rescale on any growth, exactly the reference's update rule);
 //   * causal / sliding-window / key-length masks are evaluated from per-lane key limits only on
 //     tiles that straddle a boundary; tiles entirely outside a wave's visible range are skipped
 //     per wave, and the block's key range is clipped (reference flash_fwd_kernel.h:90-94);
 //   * 1-D grid with an XCD-aware remap so all query blocks of one (batch, head) -- and the
 //     query heads sharing a KV head -- run on one XCD and share its L2; heavy (long-key-range)
 //     blocks are scheduled first when the mask is right-bounded.
+//
+// Two schedules of the same pieces (template parameter PP):
+//   PP = false  lock-step: per tile {prefetch next tile, QK^T, softmax, PV, store, barrier};
+//   PP = true   ping-pong (8 waves): the tile is split into a VALU interval SM(j) and a matrix
+//               interval MF(j) = {S_{j+1} = K_{j+1}.Q^T, O += V_j^T.P_j}; waves 4-7 run the same
+//               stream one interval late, so each SIMD always has one wave in each kind of interval.
+#include <type_traits>
+
 #include "fa_device.h"
 #include "fa_kernel_params.h"
 #include "fa_launch.h"
 
 namespace fa {
 
-template <int D> FA_DEVINL int k_swz(int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); }
-template <int D> FA_DEVINL int v_swz(int row) { return D == 128 ? (row & 3) : ((row >> 1) & 1); }
+template <int D> FA_DEVINL constexpr int k_swz(int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); }
+template <int D> FA_DEVINL constexpr int v_swz(int row) { return D == 128 ? (row & 3) : ((row >> 1) & 1); }
 
-template <typename E, int D, int NW>
+template <int N> using IC = std::integral_constant<int, N>;
+
+template <typename E, int D, int NW, bool XFORM, bool PP>
 __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
@@ -45,6 +61,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   constexpr int DB = D / 32;           // 32-wide d blocks of the output
   static_assert(D == 64 || D == 128, "head dims built natively: 64, 128");
   static_assert(LD >= 1 && (BN * CPR) % NT == 0, "tile does not divide over the workgroup");
+  static_assert(!PP || NW == 8, "ping-pong schedule pairs waves w and w+4");
   constexpr float kLn2 = 0.6931471805599453f, kLog2e = 1.4426950408889634f;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,6 +118,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   if (p.wl >= 0) kmin = max(0, m0 + shift - p.wl);
   const int n_min = kmin / BN;
   const int n_max = (kmax >= kmin) ? (kmax / BN + 1) : n_min;
+  const int n_tiles = n_max - n_min;
 
   const int w_row0 = m0 + wave * 32;
   const int w_row1 = min(w_row0 + 31, sq - 1);
@@ -115,9 +133,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   const int lim_hi = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
   const int lim_lo = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
 
-  const bool transform = (p.softcap > 0.f) || (p.alibi != nullptr);
-  const float cs = transform ? kLog2e : p.scale_log2;  // multiplier taking S to the log2 domain
-  const float slope = p.alibi ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
+  // XFORM (softcap / ALiBi) is a compile-time variant so the common kernel carries none of it
+  const float cs = XFORM ? kLog2e : p.scale_log2;  // multiplier taking S to the log2 domain
+  const float slope = (XFORM && p.alibi) ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
+  const float thr = p.rescale_thr;
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane = query row, 8 consecutive d per k-step -----
   V8 qf[KS];
@@ -127,41 +146,52 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
     for (int ks = 0; ks < KS; ++ks) qf[ks] = bitcast_u32x4<V8>(ld_global_16B(qrow + 16 * ks, row_valid));
   }
 
-  // ---- staging: global -> registers -> LDS -------------------------------------------------------
+  // ---- staging: global -> registers -> LDS.  Tile n of K starts at the uniform address
+  // kp + n*BN*k_rs; each thread adds a fixed 32-bit byte offset (scalar-base + lane-offset loads). ----
   u32x4 kreg[LD], vreg[LD];
-  auto load_tile = [&](int n) {
+  unsigned kvoff_k[LD], kvoff_v[LD];
+  int st_k[LD], st_v[LD], ld_row[LD];
 #pragma unroll
-    for (int i = 0; i < LD; ++i) {
-      const int idx = tid + i * NT;
-      const int row = idx / CPR, ch = idx % CPR;
-      const int key = n * BN + row;
-      const bool ok = key < sk;
-      kreg[i] = ld_global_16B(kp + (int64_t)key * p.k_rs + ch * 8, ok);
-      vreg[i] = ld_global_16B(vp + (int64_t)key * p.v_rs + ch * 8, ok);
-    }
+  for (int i = 0; i < LD; ++i) {
+    const int idx = tid + i * NT;
+    const int row = idx / CPR, ch = idx % CPR;
+    ld_row[i] = row;
+    kvoff_k[i] = (unsigned)(row * (int)p.k_rs + ch * 8) * 2u;
+    kvoff_v[i] = (unsigned)(row * (int)p.v_rs + ch * 8) * 2u;
+    st_k[i] = row * ROW_BYTES + ((ch ^ k_swz<D>(row)) << 4);
+    st_v[i] = row * ROW_BYTES + (((((ch >> 2) ^ v_swz<D>(row)) << 2) | (ch & 3)) << 4);
+  }
+  auto load_k = [&](int n) __attribute__((always_inline)) {
+    const char* base = (const char*)(kp + (int64_t)n * BN * p.k_rs);
+#pragma unroll
+    for (int i = 0; i < LD; ++i) kreg[i] = ld_global_16B(base + kvoff_k[i], n * BN + ld_row[i] < sk);
   };
-  auto store_tile = [&](int buf) {
-    char FA_LDS* kb_ = lds + buf * TILE_BYTES;
-    char FA_LDS* vb_ = lds + (2 + buf) * TILE_BYTES;
+  auto load_v = [&](int n) __attribute__((always_inline)) {
+    const char* base = (const char*)(vp + (int64_t)n * BN * p.v_rs);
 #pragma unroll
-    for (int i = 0; i < LD; ++i) {
-      const int idx = tid + i * NT;
-      const int row = idx / CPR, ch = idx % CPR;
-      *(u32x4 FA_LDS*)(kb_ + row * ROW_BYTES + ((ch ^ k_swz<D>(row)) << 4)) = kreg[i];
-      *(u32x4 FA_LDS*)(vb_ + row * ROW_BYTES + (((((ch >> 2) ^ v_swz<D>(row)) << 2) | (ch & 3)) << 4)) = vreg[i];
-    }
+    for (int i = 0; i < LD; ++i) vreg[i] = ld_global_16B(base + kvoff_v[i], n * BN + ld_row[i] < sk);
+  };
+  auto store_k = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int i = 0; i < LD; ++i) *(u32x4 FA_LDS*)(lds + buf * TILE_BYTES + st_k[i]) = kreg[i];
+  };
+  auto store_v = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int i = 0; i < LD; ++i) *(u32x4 FA_LDS*)(lds + (2 + buf) * TILE_BYTES + st_v[i]) = vreg[i];
   };
 
-  // per-lane LDS read offsets
-  const int kread_base = qi * ROW_BYTES;          // + 32*kb rows, chunk (2ks+hi) ^ kswz
-  const int kswz = k_swz<D>(qi);
+  // ---- per-lane LDS read addresses (loop invariant; buffers and sub-tiles are immediates) ----------
+  int kaddr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = qi * ROW_BYTES + (((2 * ks + hi) ^ k_swz<D>(qi)) << 4);
   const int tr_i = lane & 15, tr_half = (lane >> 4) & 1;
   const int tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
-  const int vswz = v_swz<D>(tr_rr);
-  int vread_base[DB];
+  int vaddr[DB];
 #pragma unroll
   for (int db = 0; db < DB; ++db)
-    vread_base[db] = (4 * hi + tr_rr) * ROW_BYTES + ((db ^ vswz) << 6) + tr_half * 32 + tr_cc * 8;
+    vaddr[db] = (4 * hi + tr_rr) * ROW_BYTES + ((db ^ v_swz<D>(tr_rr)) << 6) + tr_half * 32 + tr_cc * 8;
 
   // ---- online-softmax state (per lane = per query row; both half-waves keep identical m) ----------
   f32x16 o_acc[DB];
@@ -170,129 +200,222 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  f32x16 s[2];
+  V8 pf[4];
 
-  if (n_min < n_max) {
-    load_tile(n_min);
-    store_tile(0);
-    __syncthreads();
-  }
+  auto tile_active = [&](int j) __attribute__((always_inline)) {  // j relative to n_min
+    const int kv0 = (n_min + j) * BN;
+    return wave_valid && (j < n_tiles) && (kv0 <= w_kmax) && (kv0 + BN - 1 >= w_kmin);
+  };
 
-  for (int n = n_min; n < n_max; ++n) {
-    const int cur = (n - n_min) & 1;
-    const int kv0 = n * BN;
-    const bool has_next = (n + 1 < n_max);
-    if (has_next) load_tile(n + 1);  // lands while this tile is being computed
-
-    const bool active = wave_valid && (kv0 <= w_kmax) && (kv0 + BN - 1 >= w_kmin);
-    if (active) {
-      const char FA_LDS* kbuf = lds + cur * TILE_BYTES;
-      const char FA_LDS* vbuf = lds + (2 + cur) * TILE_BYTES;
-
-      // S^T[key][query] for the two 32-key halves of the tile
-      f32x16 s[2];
+  // S^T[key][query] of the tile in K buffer `buf`; operand reads run PF k-steps ahead of their MFMAs
+  auto qk = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+    const char FA_LDS* kbuf = lds + buf * TILE_BYTES;
+    constexpr int PF = 3;
+    u32x4 kfrag[PF][2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+    for (int ks = 0; ks < PF - 1 && ks < KS; ++ks)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      for (int kb = 0; kb < 2; ++kb) kfrag[ks % PF][kb] = *(const u32x4 FA_LDS*)(kbuf + kaddr[ks] + kb * 32 * ROW_BYTES);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
+      const int nx = ks + PF - 1;
+      if (nx < KS) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const u32x4 kraw = *(const u32x4 FA_LDS*)(kbuf + kread_base + kb * 32 * ROW_BYTES + (((2 * ks + hi) ^ kswz) << 4));
-          s[kb] = T::mfma(bitcast_u32x4<V8>(kraw), qf[ks], s[kb]);
+        for (int kb = 0; kb < 2; ++kb) kfrag[nx % PF][kb] = *(const u32x4 FA_LDS*)(kbuf + kaddr[nx] + kb * 32 * ROW_BYTES);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this step's MFMAs (hipcc otherwise sinks it to the use)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 c = s[kb];
+        if (ks == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[r] = 0.f;
         }
+        s[kb] = T::mfma(bitcast_u32x4<V8>(kfrag[ks % PF][kb]), qf[ks], c);
       }
+    }
+  };
 
-      if (transform) {  // softcap / ALiBi: move to the scaled domain first (reference utils.h:395-409, alibi.h)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float y = s[kb][r] * p.scale;
-            if (p.softcap > 0.f) y = p.softcap * tanhf(y / p.softcap);
-            if (p.alibi) {
-              const int key = kv0 + 32 * kb + acc_row(r, hi);
-              y -= slope * fabsf((float)(my_row + shift - key));
-            }
-            s[kb][r] = y;
-          }
-      }
-
-      const bool need_mask = (kv0 + BN - 1 > w_full_hi) || (kv0 < w_full_lo);
-      if (need_mask) {  // reference mask.h:172-203 predicate, evaluated on accumulator coordinates
-        const int rel_hi = lim_hi - kv0 - 4 * hi;
-        const int rel_lo = lim_lo - kv0 - 4 * hi;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int off = 32 * kb + acc_row(r, 0);
-            const bool vis = (off <= rel_hi) && (off >= rel_lo);
-            s[kb][r] = vis ? s[kb][r] : -INFINITY;
-          }
-      }
-
-      // row max: in-lane over 32 keys, then the other half-wave's 32 keys
-      float tmax = s[0][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[0][r]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[1][r]);
-      tmax = fmaxf(tmax, xchg_half(tmax));
-
-      const float m_new = fmaxf(m_run, tmax);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far (softmax.h:76,154-156)
-      const float alpha = fast_exp2((m_run - m_use) * cs);
-      const float neg_mc = -m_use * cs;
-      m_run = m_new;
-
-      float psum = 0.f;
+  // mask + online softmax of s -> pf (P^T as B operand), updates m_run / l_run / o_acc scale
+  auto softmax_step = [&](int j) __attribute__((always_inline)) {
+    const int kv0 = (n_min + j) * BN;
+    if constexpr (XFORM) {  // softcap / ALiBi: move to the scaled domain first (reference utils.h:395-409, alibi.h)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pv = fast_exp2(__builtin_fmaf(s[kb][r], cs, neg_mc));
-          s[kb][r] = pv;
-          psum += pv;
+          float y = s[kb][r] * p.scale;
+          if (p.softcap > 0.f) y = p.softcap * tanhf(y / p.softcap);
+          if (p.alibi) {
+            const int key = kv0 + 32 * kb + acc_row(r, hi);
+            y -= slope * fabsf((float)(my_row + shift - key));
+          }
+          s[kb][r] = y;
         }
-      l_run = l_run * alpha + psum;
-
-      if (!__all(alpha == 1.f)) {
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
-      }
-
-      // P^T as B operand: k-step (kb,t) <-> accumulator registers 8t..8t+7 of s[kb]
-      V8 pf[4];
+    }
+    const bool need_mask = (kv0 + BN - 1 > w_full_hi) || (kv0 < w_full_lo);
+    if (need_mask) {  // reference mask.h:172-203 predicate, evaluated on accumulator coordinates
+      const int rel_hi = lim_hi - kv0 - 4 * hi;
+      const int rel_lo = lim_lo - kv0 - 4 * hi;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pf[kb * 2 + t][j] = (E)s[kb][8 * t + j];
-
-      // O^T[d][query] += V^T[d][key] . P^T[key][query]
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-          const char FA_LDS* a0 = vbuf + vread_base[db] + (16 * kt) * ROW_BYTES;
-          const s16x4 lo = lds_read_tr16(a0);
-          const s16x4 hi4 = lds_read_tr16(a0 + 8 * ROW_BYTES);
-          o_acc[db] = T::mfma(combine_tr<V8>(lo, hi4), pf[kt], o_acc[db]);
+        for (int r = 0; r < 16; ++r) {
+          const int off = 32 * kb + acc_row(r, 0);
+          const bool vis = (off <= rel_hi) && (off >= rel_lo);
+          s[kb][r] = vis ? s[kb][r] : -INFINITY;
         }
+    }
+    // row max: in-lane over 32 keys, then the other half-wave's 32 keys
+    float tmax = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[1][r]);
+    tmax = half_max(tmax);
+
+    // Running max moves only when it grew by more than thr (log2 units): P <= 2^thr stays exactly
+    // representable relative to the row sum; thr = 0 is the reference's update rule (softmax.h:136-167).
+    const float m_new = fmaxf(m_run, tmax);
+    const bool grow = (m_new - m_run) * cs > thr;  // first visible key: -inf -> finite is always "grow"
+    if (__any(grow)) {
+      const float m_upd = grow ? m_new : m_run;
+      const float m_safe = (m_upd == -INFINITY) ? 0.f : m_upd;
+      const float alpha = grow ? fast_exp2((m_run - m_safe) * cs) : 1.f;
+      m_run = m_upd;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+    }
+    const float neg_mc = (m_run == -INFINITY) ? 0.f : -m_run * cs;  // fully masked so far (softmax.h:76,154-156)
+    float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = fast_exp2(__builtin_fmaf(s[kb][r], cs, neg_mc));
+        const float p1 = fast_exp2(__builtin_fmaf(s[kb][r + 1], cs, neg_mc));
+        s[kb][r] = p0;
+        s[kb][r + 1] = p1;
+        psum0 += p0;
+        psum1 += p1;
+      }
+    l_run += psum0 + psum1;
+    // P^T as B operand: k-step (kb,t) <-> accumulator registers 8t..8t+7 of s[kb]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) pf[kb * 2 + t][jj] = (E)s[kb][8 * t + jj];
+  };
+
+  // O^T[d][query] += V^T[d][key] . P^T[key][query]; transpose reads run PFV MFMAs ahead
+  auto pv = [&](auto bufc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+    const char FA_LDS* vbuf = lds + (2 + buf) * TILE_BYTES;
+    constexpr int NOP = 4 * DB, PFV = 4;
+    s16x4 vlo[PFV], vhi[PFV];
+#pragma unroll
+    for (int i = 0; i < PFV - 1 && i < NOP; ++i) {
+      vlo[i % PFV] = lds_read_tr16(vbuf + vaddr[i % DB] + (16 * (i / DB)) * ROW_BYTES);
+      vhi[i % PFV] = lds_read_tr16(vbuf + vaddr[i % DB] + (16 * (i / DB) + 8) * ROW_BYTES);
+    }
+#pragma unroll
+    for (int i = 0; i < NOP; ++i) {
+      const int nx = i + PFV - 1;
+      if (nx < NOP) {
+        vlo[nx % PFV] = lds_read_tr16(vbuf + vaddr[nx % DB] + (16 * (nx / DB)) * ROW_BYTES);
+        vhi[nx % PFV] = lds_read_tr16(vbuf + vaddr[nx % DB] + (16 * (nx / DB) + 8) * ROW_BYTES);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      o_acc[i % DB] = T::mfma(combine_tr<V8>(vlo[i % PFV], vhi[i % PFV]), pf[i / DB], o_acc[i % DB]);
+    }
+  };
+
+  if constexpr (!PP) {
+    // ------------------------------ lock-step schedule ------------------------------
+    if (n_tiles > 0) {
+      load_k(n_min);
+      load_v(n_min);
+      store_k(IC<0>{});
+      store_v(IC<0>{});
+      __syncthreads();
+    }
+    auto step = [&](auto bufc, int j) __attribute__((always_inline)) {
+      constexpr int buf = decltype(bufc)::value;
+      const bool has_next = (j + 1 < n_tiles);
+      if (has_next) {  // lands while this tile is being computed
+        load_k(n_min + j + 1);
+        load_v(n_min + j + 1);
+      }
+      if (tile_active(j)) {
+        qk(bufc);
+        softmax_step(j);
+        pv(bufc);
+      }
+      if (has_next) {
+        store_k(IC<buf ^ 1>{});
+        store_v(IC<buf ^ 1>{});
+      }
+      __syncthreads();
+    };
+    for (int j = 0; j < n_tiles; j += 2) {
+      step(IC<0>{}, j);
+      if (j + 1 < n_tiles) step(IC<1>{}, j + 1);
+    }
+  } else {
+    // ------------------------------ ping-pong schedule ------------------------------
+    // Early half (waves 0-3):  B0 [QK0] B1 [SM0] B2 [MF0] B3 [SM1] B4 [MF1] ... ; late half the same, one
+    // barrier later.  MF(j) reads K_{j+1} (kbuf[(j+1)&1]) and V_j (vbuf[j&1]) and stores K_{j+2} over K_j and
+    // V_{j+1} over V_{j-1}: the early half's stores start two barriers after the late half's last read of the
+    // old contents, and the first reader of the new contents (MF(j+1), early half) starts after the late
+    // half's stores have been fenced by a barrier.
+    const bool late = wave >= 4;
+    if (n_tiles > 0) {
+      load_k(n_min);
+      load_v(n_min);
+      store_k(IC<0>{});
+      store_v(IC<0>{});
+      if (n_tiles > 1) {
+        load_k(n_min + 1);
+        store_k(IC<1>{});
       }
     }
-
-    if (has_next) store_tile(cur ^ 1);
     __syncthreads();
+    if (late) __builtin_amdgcn_s_barrier();  // run one interval behind waves 0-3
+    if (tile_active(0)) qk(IC<0>{});
+    __syncthreads();
+    auto step = [&](auto bufc, int j) __attribute__((always_inline)) {  // buf = j & 1
+      constexpr int buf = decltype(bufc)::value;
+      // SM(j): VALU interval
+      const bool pre_k = (j + 2 < n_tiles), pre_v = (j + 1 < n_tiles);
+      if (pre_k) load_k(n_min + j + 2);
+      if (pre_v) load_v(n_min + j + 1);
+      const bool act = tile_active(j);
+      if (act) softmax_step(j);
+      __syncthreads();
+      // MF(j): matrix interval
+      if (tile_active(j + 1)) qk(IC<buf ^ 1>{});
+      if (act) pv(bufc);
+      if (pre_k) store_k(bufc);           // K_{j+2} replaces K_j
+      if (pre_v) store_v(IC<buf ^ 1>{});  // V_{j+1} replaces V_{j-1}
+      __syncthreads();
+    };
+    for (int j = 0; j < n_tiles; j += 2) {
+      step(IC<0>{}, j);
+      if (j + 1 < n_tiles) step(IC<1>{}, j + 1);
+    }
+    if (!late) __builtin_amdgcn_s_barrier();  // keep barrier counts equal across the workgroup
   }
 
   // ---- epilogue: normalise, store O (bf16/fp16) and LSE -------------------------------------------
   if (!wave_valid) return;
-  const float l_tot = l_run + xchg_half(l_run);
+  const float l_tot = half_sum(l_run);
   const bool dead = (l_tot == 0.f) || (l_tot != l_tot);  // no visible key (softmax.h:179-180)
   const float inv = dead ? 1.f : 1.f / l_tot;
   if (row_valid) {
@@ -303,17 +426,17 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
       for (int g = 0; g < 4; ++g) {
         V4 ov;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ov[j] = (E)(o_acc[db][4 * g + j] * inv);
+        for (int jj = 0; jj < 4; ++jj) ov[jj] = (E)(o_acc[db][4 * g + jj] * inv);
         *reinterpret_cast<V4*>(orow + 32 * db + 8 * g + 4 * hi) = ov;
       }
     if (hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
   }
 }
 
-template <typename E, int D, int NW>
+template <typename E, int D, int NW, bool XFORM, bool PP>
 static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2;
-  auto kern = fa_fwd_kernel<E, D, NW>;
+  auto kern = fa_fwd_kernel<E, D, NW, XFORM, PP>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
@@ -325,17 +448,28 @@ static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int fwd_block_m(int nw) { return 32 * nw; }
+int fwd_block_m(int nw) { return nw == 16 ? 256 : 32 * nw; }
 
+template <typename E, int D>
+static int launch_fwd_ed(const FwdK& p, int nw, hipStream_t stream) {
+  const bool xf = (p.softcap > 0.f) || (p.alibi != nullptr);
+  if (nw == 16) return xf ? launch_fwd_t<E, D, 8, true, true>(p, stream) : launch_fwd_t<E, D, 8, false, true>(p, stream);
+  if (nw == 8) return xf ? launch_fwd_t<E, D, 8, true, false>(p, stream) : launch_fwd_t<E, D, 8, false, false>(p, stream);
+  if (nw == 4) return xf ? launch_fwd_t<E, D, 4, true, false>(p, stream) : launch_fwd_t<E, D, 4, false, false>(p, stream);
+  return -2;
+}
+
+// nw: 4 / 8 = lock-step schedule with 4 / 8 waves per workgroup, 16 = 8-wave ping-pong schedule
 int launch_fwd(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream) {
-#define FA_FWD_CASE(E_, D_, NW_) \
-  if (d == D_ && nw == NW_) return launch_fwd_t<E_, D_, NW_>(p, stream);
+  // the scalar-base + 32-bit lane-offset tile loads need one tile's extent to fit 32 bits
+  if ((uint64_t)64 * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 31)) return -2;
   if (dtype_bf16) {
-    FA_FWD_CASE(__bf16, 128, 8) FA_FWD_CASE(__bf16, 128, 4) FA_FWD_CASE(__bf16, 64, 8) FA_FWD_CASE(__bf16, 64, 4)
+    if (d == 128) return launch_fwd_ed<__bf16, 128>(p, nw, stream);
+    if (d == 64) return launch_fwd_ed<__bf16, 64>(p, nw, stream);
   } else {
-    FA_FWD_CASE(_Float16, 128, 8) FA_FWD_CASE(_Float16, 128, 4) FA_FWD_CASE(_Float16, 64, 8) FA_FWD_CASE(_Float16, 64, 4)
+    if (d == 128) return launch_fwd_ed<_Float16, 128>(p, nw, stream);
+    if (d == 64) return launch_fwd_ed<_Float16, 64>(p, nw, stream);
   }
-#undef FA_FWD_CASE
   return -2;
 }
 

@@ -28,6 +28,7 @@ struct FwdK {
   float scale;               // softmax_scale
   float scale_log2;          // softmax_scale * log2(e)
   float softcap;             // 0 = off
+  float rescale_thr;         // O rescale deferred until a row max grows by more than this (log2 units)
 };
 
 struct BwdK {

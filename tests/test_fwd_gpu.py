@@ -145,3 +145,48 @@ def test_run_to_run_bitwise_deterministic(be):
     for _ in range(20):
         o, l = _fwd(be, q, k, v, True)
         assert torch.equal(o, o0) and torch.equal(l, l0)
+
+
+@pytest.mark.parametrize("thr", ["0", "8"])
+@pytest.mark.parametrize("nw", ["4", "8", "16"])
+def test_rescale_branch_is_forced_and_exact(be, monkeypatch, thr, nw):
+    """The deferred-rescale branch is rare on random data: force it.  One key per 64-key tile is spiked against
+    one query row so that the row's maximum jumps by far more than any threshold at a chosen tile, for every
+    schedule and for threshold 0 (reference rule) and 8 (default); checked against the fp64 oracle on the
+    FULL tensor (a wrong rescale corrupts whole rows, not the spiked element only)."""
+    from oracle import attention_oracle as orc
+    monkeypatch.setenv("FA_RESCALE_THR", thr)
+    monkeypatch.setenv("FA_FWD_NW", nw)
+    torch.manual_seed(11)
+    B, S, H, D = 1, 1024, 2, 128
+    q = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16)
+    for i, row in enumerate(range(5, S, 97)):  # rows spread over all waves / halves
+        tile = (3 * i + 2) % (S // 64)
+        key = tile * 64 + (7 * i) % 64
+        k[0, key, :, :] = (q[0, row, :, :].float() * (1.0 + 0.25 * i)).to(torch.bfloat16)  # q.k ~ |q|^2 >> others
+    out, lse = _fwd(be, q, k, v)
+    ref, lse_ref = orc.attention_fwd(q, k, v)
+    ref = torch.from_numpy(ref).cuda()
+    assert max_abs(out.float(), ref) < 2e-2
+    assert max_abs(lse, torch.from_numpy(lse_ref).cuda().float()) < 2e-3
+    # same inputs, threshold 0 vs this threshold agree to rounding
+    monkeypatch.setenv("FA_RESCALE_THR", "0")
+    out0, lse0 = _fwd(be, q, k, v)
+    assert max_abs(out.float(), out0.float()) < 1.6e-2 and max_abs(lse, lse0) < 1e-4
+
+
+def test_threshold_accuracy_budget(be, monkeypatch):
+    """Error against the fp64 oracle with the default threshold stays within 1.5x of threshold 0."""
+    from oracle import attention_oracle as orc
+    torch.manual_seed(12)
+    q = torch.randn(2, 777, 4, 128, device="cuda", dtype=torch.bfloat16) * 2
+    k = torch.randn(2, 1111, 4, 128, device="cuda", dtype=torch.bfloat16) * 2
+    v = torch.randn_like(k) * 4
+    ref = torch.from_numpy(orc.attention_fwd(q, k, v, causal=True)[0]).cuda()
+    errs = {}
+    for thr in ("0", "8"):
+        monkeypatch.setenv("FA_RESCALE_THR", thr)
+        errs[thr] = max_abs(_fwd(be, q, k, v, True)[0].float(), ref)
+    assert errs["8"] <= 1.5 * errs["0"] + 1e-3, errs
