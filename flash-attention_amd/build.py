@@ -52,7 +52,7 @@ def _sources(names):
 
 def build_lib(force=False):
     hdrs = _sources(["fa_device.h", "fa_kernel_params.h", "fa_launch.h"]) + [os.path.join(ROOT, "include", "fa_gfx950.h")]
-    units = ["fa_fwd.hip", "fa_bwd.hip", "fa_api.cpp"]
+    units = ["fa_fwd.hip", "fa_fwd_il.hip", "fa_bwd.hip", "fa_api.cpp"]
     objs = []
     for u in units:
         src = os.path.join(CSRC, u)

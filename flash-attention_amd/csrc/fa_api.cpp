@@ -104,15 +104,19 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen) {
   // win whenever a block has < ~128 key tiles; the 8-wave ping-pong schedule wins on longer key loops.
   // 4 / 8 = lock-step kernel with 4 / 8 waves per workgroup, 16 = 8-wave ping-pong; FA_FWD_NW overrides.
   int nw = env_int("FA_FWD_NW", 0);
-  if (nw != 4 && nw != 8 && nw != 16) {
+  if (nw != 4 && nw != 8 && nw != 16 && nw != 34 && nw != 38) {
     const bool right_bounded = (wr >= 0);
     const long avg_keys = right_bounded ? (a->seqlen_k + 1) / 2 : a->seqlen_k;
     const long span = (wl >= 0) ? std::min<long>(avg_keys, wl + (wr >= 0 ? wr : a->seqlen_k) + 256) : avg_keys;
     nw = (a->d == 128 && span / 64 >= 128 && a->seqlen_q >= 512) ? 16 : 4;
   }
-  const int bm = fa::fwd_block_m(nw);
+  // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
+  const bool il = (nw == 34 || nw == 38) && !(a->softcap > 0.f) && !a->alibi_slopes;
+  if ((nw == 34 || nw == 38) && !il) nw -= 30;
+  const int bm = il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
   k.nmb = (a->seqlen_q + bm - 1) / bm;
-  const int rc = fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
+  const int rc = il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, a->d, nw - 30, (hipStream_t)stream)
+                    : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
   if (rc != 0) return fail(FA_ERR_LAUNCH, "forward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   return FA_OK;

@@ -174,10 +174,8 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
       const int c = pc ^ swz16<D>(row);
       const E* qsrc = qp + (int64_t)grow * p.q_rs + c * 8;
       const E* dsrc = dop + (int64_t)grow * p.do_rs + c * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)qsrc,
-                                       (void FA_LDS*)(lds + OFF_Q + buf * QT_BYTES + idx * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)dsrc,
-                                       (void FA_LDS*)(lds + OFF_DO + buf * QT_BYTES + idx * 1024), 16, 0, 0);
+      lds_dma_16B(qsrc, lds + OFF_Q + buf * QT_BYTES + idx * 1024);
+      lds_dma_16B(dsrc, lds + OFF_DO + buf * QT_BYTES + idx * 1024);
     }
     if (tid < 2 * BMQ) {
       const int r = tid & (BMQ - 1);
@@ -216,6 +214,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
     load_item(0, 0);
     store_item(0);
   }
+  lds_dma_wait_all();
   __syncthreads();
 
   for (int it = 0; it < n_items; ++it) {
@@ -307,6 +306,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
     }
 
     if (has_next) store_item(cur ^ 1);
+    lds_dma_wait_all();
     __syncthreads();
   }
 

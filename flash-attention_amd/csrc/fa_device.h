@@ -81,6 +81,22 @@ template <typename V8> FA_DEVINL V8 combine_tr(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(V8, x);
 }
 
+// LDS-DMA: 16 bytes per lane, global -> LDS, destination = wave-uniform LDS byte address + 16 * lane.
+// Issued from inline asm on purpose: hipcc's waitcnt pass treats an in-flight __builtin_amdgcn_global_load_lds
+// as aliasing every later LDS read and drains it (s_waitcnt vmcnt(0)) at the first ds_read, which serialises
+// the prefetch with the compute it was meant to overlap.  The asm form is invisible to that pass, so the
+// kernel owns the wait: call lds_dma_wait_all() before the barrier that publishes the tile.
+// M0 (DMA destination base) is saved and restored inside the statement (cdna_hip_programming.md 5.7).
+FA_DEVINL void lds_dma_16B(const void* gsrc, const char FA_LDS* lds_dst_uniform) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)lds_dst_uniform);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+FA_DEVINL void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // XCD-aware bijective remap of a 1-D grid: consecutive work items land on the same XCD
 // (block b is observed to run on XCD b % 8; performance only, never correctness).
 FA_DEVINL int xcd_remap(int bid, int total) {

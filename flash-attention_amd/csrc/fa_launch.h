@@ -9,6 +9,8 @@ namespace fa {
 // failure) or -2 (no kernel built for this dtype/head-dim/nw).
 int launch_fwd(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream);
 int fwd_block_m(int nw);
+// Software-pipelined forward (fa_fwd_il.hip); nw = 4 or 8 waves per workgroup.  No softcap / ALiBi variant.
+int launch_fwd_il(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream);
 
 // Backward: delta = rowsum(dO*O) pre-pass, dK/dV kernel (loops over query blocks),
 // dQ kernel (loops over key blocks).  Same return convention.
