@@ -100,15 +100,20 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen) {
     if (!(k.rescale_thr >= 0.f) || k.rescale_thr > 16.f) k.rescale_thr = 0.f;
   }
 
-  // Schedule (measured on MI355X, tools/ab_bench.py): 4 waves x 2 workgroups per CU de-phase naturally and
-  // win whenever a block has < ~128 key tiles; the 8-wave ping-pong schedule wins on longer key loops.
-  // 4 / 8 = lock-step kernel with 4 / 8 waves per workgroup, 16 = 8-wave ping-pong; FA_FWD_NW overrides.
+  // Schedule (measured on MI355X, tools/ab_bench.py; FA_FWD_NW overrides):
+  //   34 / 38 = software-pipelined kernel (fa_fwd_il.hip) with 4 / 8 waves per workgroup,
+  //   4 / 8   = lock-step kernel with 4 / 8 waves, 16 = 8-wave ping-pong (fa_fwd.hip).
+  // The pipelined kernel wins once a query block walks >= ~16 key tiles; below that the 4-wave lock-step
+  // kernel (two workgroups per CU hide each other's prologue/epilogue) is faster.  D = 64 has half the MFMA
+  // work per softmax element, so it prefers 4-wave workgroups throughout.
   int nw = env_int("FA_FWD_NW", 0);
   if (nw != 4 && nw != 8 && nw != 16 && nw != 34 && nw != 38) {
     const bool right_bounded = (wr >= 0);
     const long avg_keys = right_bounded ? (a->seqlen_k + 1) / 2 : a->seqlen_k;
     const long span = (wl >= 0) ? std::min<long>(avg_keys, wl + (wr >= 0 ? wr : a->seqlen_k) + 256) : avg_keys;
-    nw = (a->d == 128 && span / 64 >= 128 && a->seqlen_q >= 512) ? 16 : 4;
+    const long tiles = span / 64;
+    if (a->d == 128) nw = (tiles >= 16 && a->seqlen_q >= 512) ? 38 : 4;
+    else nw = (tiles >= 8 && a->seqlen_q >= 256) ? 34 : 4;
   }
   // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
   const bool il = (nw == 34 || nw == 38) && !(a->softcap > 0.f) && !a->alibi_slopes;

@@ -16,7 +16,12 @@
 //
 // One iteration of the tile loop = two steps = one 64-key K tile and the previous V tile, double-buffered
 // in LDS exactly as in the lock-step kernel (64 KB), one barrier per iteration.
+#include <cstdlib>
 #include <type_traits>
+
+#ifndef FA_IL_AHEAD
+#define FA_IL_AHEAD 4  // LDS operand reads issued this many MFMA slots ahead (LDS latency ~130-200 cycles, slot ~35)
+#endif
 
 #include "fa_device.h"
 #include "fa_kernel_params.h"
@@ -29,8 +34,9 @@ template <int D> FA_DEVINL constexpr int v_swz_il(int row) { return D == 128 ? (
 
 template <int N> using ICi = std::integral_constant<int, N>;
 
-template <typename E, int D, int NW>
+template <typename E, int D, int NW, int SCHED>
 __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
+  constexpr int sched_mode = SCHED;
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   using V4 = typename T::v4;
@@ -241,29 +247,112 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   };
   // Row max of the NEXT step's scores and the rescale decision.  Everything still at the old scale is
   // rescaled here exactly once: O, l and (if do_pend) the pending fp32 probabilities of this step.
-  auto decide = [&](const f32x16& s_nxt, f32x16& pend, bool do_pend) __attribute__((always_inline)) {
+  auto row_max_grow = [&](const f32x16& s_nxt, float& m_new) __attribute__((always_inline)) {
     float tmax = fmaxf(fmaxf(s_nxt[0], s_nxt[1]), s_nxt[2]);
 #pragma unroll
     for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, s_nxt[r]), s_nxt[r + 1]);
     tmax = fmaxf(tmax, s_nxt[15]);
     tmax = half_max(tmax);
+    m_new = fmaxf(m_run, tmax);
+    return (m_new - m_run) * cs > thr;
+  };
+  auto rescale = [&](bool grow, float m_new, f32x16& pend, bool do_pend) __attribute__((always_inline)) {
+    const float m_upd = grow ? m_new : m_run;
+    const float m_safe = (m_upd == -INFINITY) ? 0.f : m_upd;
+    const float alpha = grow ? fast_exp2((m_run - m_safe) * cs) : 1.f;
+    m_run = m_upd;
+    l_run *= alpha;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+    if (do_pend) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pend[r] *= alpha;
+    }
+  };
+
+  int qa[KS];  // loop-invariant Q fragment addresses
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qa[ks] = qbase ^ (ks << 5);
+
+  // Hand-placed fast step (SCHED >= 2; SCHED = how many slots ahead the operand reads run): the step is written as 16 (KS + 2*DB) slots, each = the LDS reads two
+  // slots ahead, one MFMA, and that slot's share of the VALU work; slots are pinned with sched_barrier(0).
+  //   slots 0 .. KS-1      : S_{i+1} += K.Q^T (k-step g)   +  exp/sum of 16/KS elements of S_i
+  //   slots KS .. KS+2DB-1 : O += V^T.P_{i-1}  (op g)      +  the row-max tree of S_{i+1} (from slot KS+2 on,
+  //                          when the last QK^T MFMA has retired)
+  auto fast_step = [&](auto halfc, const int (&ka)[KS], const int (&va)[DB], f32x16& s_cur, f32x16& s_nxt,
+                       const V8 (&pf_prev)[2], V8 (&pf_cur)[2]) __attribute__((always_inline)) {
+    constexpr int half = decltype(halfc)::value;
+    constexpr int NOP = 2 * DB, EPG = 16 / KS, AHEAD = (sched_mode >= 2 ? sched_mode : 2), RING = AHEAD + 1;
+    constexpr int HOFF = half * 32 * ROW_BYTES;
+    u32x4 kfr[RING], qfr[RING];
+    s16x4 vlo[RING], vhi[RING];
+    auto rd_kq = [&](int ks) __attribute__((always_inline)) {
+      kfr[ks % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[ks] + HOFF);
+      qfr[ks % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(qa[ks]);
+    };
+    auto rd_v = [&](int op) __attribute__((always_inline)) {
+      const char FA_LDS* a0 = (const char FA_LDS*)(unsigned long)(unsigned)(va[op % DB] + HOFF + (16 * (op / DB)) * ROW_BYTES);
+      vlo[op % RING] = lds_read_tr16(a0);
+      vhi[op % RING] = lds_read_tr16(a0 + 8 * ROW_BYTES);
+    };
+    // operand reads run AHEAD slots in front of their MFMA over the whole 16-slot sequence
+    auto rd_slot = [&](int slot) __attribute__((always_inline)) {
+      if (slot < KS) rd_kq(slot);
+      else if (slot < KS + NOP) rd_v(slot - KS);
+    };
+    const float neg_mc = (m_run == -INFINITY) ? 0.f : -m_run * cs;
+    float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) rd_slot(g);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < KS; ++g) {
+      rd_slot(g + AHEAD);
+      f32x16 c = s_nxt;
+      if (g == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+      }
+      s_nxt = T::mfma(bitcast_u32x4<V8>(kfr[g % RING]), bitcast_u32x4<V8>(qfr[g % RING]), c);
+#pragma unroll
+      for (int e = 0; e < EPG; e += 2) {
+        const int r = g * EPG + e;
+        const float p0 = fast_exp2(__builtin_fmaf(s_cur[r], cs, neg_mc));
+        const float p1 = fast_exp2(__builtin_fmaf(s_cur[r + 1], cs, neg_mc));
+        s_cur[r] = p0;
+        s_cur[r + 1] = p1;
+        ps0 += p0;
+        ps1 += p1;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    l_run += ps0 + ps1;
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < NOP; ++g) {
+      rd_slot(KS + g + AHEAD);
+      o_acc[g % DB] = T::mfma(combine_tr<V8>(vlo[g % RING], vhi[g % RING]), pf_prev[g / DB], o_acc[g % DB]);
+      if (g >= 2) {  // row-max tree, spread over the remaining slots (2 values per max3)
+        constexpr int SLOTS = NOP - 2;
+        constexpr int PER = (8 + SLOTS - 1) / SLOTS;  // max3 ops per slot
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+          const int q = (g - 2) * PER + t;
+          if (q < 8) tmax = fmaxf(fmaxf(tmax, s_nxt[2 * q]), s_nxt[2 * q + 1]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    tmax = half_max(tmax);
     const float m_new = fmaxf(m_run, tmax);
     const bool grow = (m_new - m_run) * cs > thr;
-    if (__any(grow)) {
-      const float m_upd = grow ? m_new : m_run;
-      const float m_safe = (m_upd == -INFINITY) ? 0.f : m_upd;
-      const float alpha = grow ? fast_exp2((m_run - m_safe) * cs) : 1.f;
-      m_run = m_upd;
-      l_run *= alpha;
+    if (__any(grow)) rescale(grow, m_new, s_cur, true);
 #pragma unroll
-      for (int db = 0; db < DB; ++db)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
-      if (do_pend) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pend[r] *= alpha;
-      }
-    }
+      for (int jj = 0; jj < 8; ++jj) pf_cur[t][jj] = (E)s_cur[8 * t + jj];
   };
 
   // One pipeline step.  s_cur: scores of step i (masked, decision already taken) -> becomes P_i in place;
@@ -293,7 +382,9 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     if (do_pv) pv_half(pf_prev, vb_lane, halfc);
     if (do_qk) {
       if (!FAST && step_needs_mask(i + 1)) apply_mask(s_nxt, i + 1);
-      decide(s_nxt, s_cur, do_sm);
+      float m_new;
+      const bool grow = row_max_grow(s_nxt, m_new);
+      if (__any(grow)) rescale(grow, m_new, s_cur, do_sm);
     }
     if (do_sm) {
 #pragma unroll
@@ -351,9 +442,19 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
       const int kb_lane = kbase ^ ((u & 1) * TILE_BYTES);
       const int vb_lane = vbase ^ ((2 + ((u & 1) ^ 1)) * TILE_BYTES);
       // step 2u-1: S_{2u} from the first half of K_u, PV of step 2u-2 from the first half of V_{u-1}
-      step(ICi<1>{}, ICi<0>{}, kb_lane, vb_lane, 2 * u - 1, sA, sB, pfA, pfB);
-      // step 2u: S_{2u+1} from the second half of K_u, PV of step 2u-1 from the second half of V_{u-1}
-      step(ICi<1>{}, ICi<1>{}, kb_lane, vb_lane, 2 * u, sB, sA, pfB, pfA);
+      if constexpr (sched_mode >= 2) {
+        int ka[KS], va[DB];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ka[ks] = kb_lane ^ (ks << 5);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) va[db] = vb_lane ^ (db << 6);
+        fast_step(ICi<0>{}, ka, va, sA, sB, pfA, pfB);
+        fast_step(ICi<1>{}, ka, va, sB, sA, pfB, pfA);
+      } else {
+        step(ICi<1>{}, ICi<0>{}, kb_lane, vb_lane, 2 * u - 1, sA, sB, pfA, pfB);
+        // step 2u: S_{2u+1} from the second half of K_u, PV of step 2u-1 from the second half of V_{u-1}
+        step(ICi<1>{}, ICi<1>{}, kb_lane, vb_lane, 2 * u, sB, sA, pfB, pfA);
+      }
       iter_tail();
     }
     for (; u <= n_tiles; ++u) {
@@ -385,13 +486,15 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   }
 }
 
-template <typename E, int D, int NW>
+template <typename E, int D, int NW, int SCHED>
 static int launch_fwd_il_t(const FwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2 + NW * 32 * D * 2;
-  auto kern = fa_fwd_il_kernel<E, D, NW>;
+  auto kern = fa_fwd_il_kernel<E, D, NW, SCHED>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
+    hipFuncAttributes fattr;  // the kernel addresses LDS by byte offset: the dynamic segment must start at 0
+    if (hipFuncGetAttributes(&fattr, (const void*)kern) != hipSuccess || fattr.sharedSizeBytes != 0) return -1;
     attr_done = true;
   }
   const long long total = (long long)p.nmb * p.b * p.h;
@@ -402,9 +505,13 @@ static int launch_fwd_il_t(const FwdK& p, hipStream_t stream) {
 
 // nw = 4 or 8 waves per workgroup (query block = 32*nw rows)
 int launch_fwd_il(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream) {
+  // FA_IL_SCHED=0: compiler-ordered steady-state step; default: hand-placed slots, operand reads 4 slots ahead
+  static const int sched = [] { const char* e = getenv("FA_IL_SCHED"); return e ? atoi(e) : 4; }();
   if ((uint64_t)64 * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 31)) return -2;
   if (p.softcap > 0.f || p.alibi != nullptr) return -2;
-#define FA_IL_CASE(E_, D_, NW_) if (d == D_ && nw == NW_) return launch_fwd_il_t<E_, D_, NW_>(p, stream);
+#define FA_IL_CASE(E_, D_, NW_)                                                                       \
+  if (d == D_ && nw == NW_)                                                                           \
+    return sched == 0 ? launch_fwd_il_t<E_, D_, NW_, 0>(p, stream) : launch_fwd_il_t<E_, D_, NW_, 4>(p, stream);
   if (dtype_bf16) {
     FA_IL_CASE(__bf16, 128, 8) FA_IL_CASE(__bf16, 128, 4) FA_IL_CASE(__bf16, 64, 8) FA_IL_CASE(__bf16, 64, 4)
   } else {
