@@ -281,9 +281,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   //   slots 0 .. KS-1      : S_{i+1} += K.Q^T (k-step g)   +  exp/sum of 16/KS elements of S_i
   //   slots KS .. KS+2DB-1 : O += V^T.P_{i-1}  (op g)      +  the row-max tree of S_{i+1} (from slot KS+2 on,
   //                          when the last QK^T MFMA has retired)
-  auto fast_step = [&](auto halfc, const int (&ka)[KS], const int (&va)[DB], f32x16& s_cur, f32x16& s_nxt,
-                       const V8 (&pf_prev)[2], V8 (&pf_cur)[2]) __attribute__((always_inline)) {
+  auto fast_step = [&](auto halfc, auto maskc, int i_nxt, const int (&ka)[KS], const int (&va)[DB], f32x16& s_cur,
+                       f32x16& s_nxt, const V8 (&pf_prev)[2], V8 (&pf_cur)[2]) __attribute__((always_inline)) {
     constexpr int half = decltype(halfc)::value;
+    constexpr bool MASK = decltype(maskc)::value != 0;  // step i_nxt straddles a mask boundary
     constexpr int NOP = 2 * DB, EPG = 16 / KS, AHEAD = (sched_mode >= 2 ? sched_mode : 2), RING = AHEAD + 1;
     constexpr int HOFF = half * 32 * ROW_BYTES;
     u32x4 kfr[RING], qfr[RING];
@@ -330,16 +331,32 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     }
     l_run += ps0 + ps1;
     float tmax = -INFINITY;
+    int rel_hi = 0, rel_lo = 0;
+    if constexpr (MASK) {
+      const int k0 = key_base + 32 * i_nxt;
+      rel_hi = lim_hi - k0 - 4 * hi;
+      rel_lo = lim_lo - k0 - 4 * hi;
+    }
 #pragma unroll
     for (int g = 0; g < NOP; ++g) {
       rd_slot(KS + g + AHEAD);
       o_acc[g % DB] = T::mfma(combine_tr<V8>(vlo[g % RING], vhi[g % RING]), pf_prev[g / DB], o_acc[g % DB]);
-      if (g >= 2) {  // row-max tree, spread over the remaining slots (2 values per max3)
-        constexpr int SLOTS = NOP - 2;
+      if constexpr (MASK) {  // mask.h:172-203 predicate on the freshly produced scores, spread over the first slots
+        if (g >= 1 && g < 1 + 2) {
+#pragma unroll
+          for (int r = (g - 1) * 8; r < (g - 1) * 8 + 8; ++r) {
+            const int off = acc_row(r, 0);
+            s_nxt[r] = ((off <= rel_hi) && (off >= rel_lo)) ? s_nxt[r] : -INFINITY;
+          }
+        }
+      }
+      if (g >= (MASK ? 3 : 2)) {  // row-max tree, spread over the remaining slots (2 values per max3)
+        constexpr int G0 = MASK ? 3 : 2;
+        constexpr int SLOTS = NOP - G0;
         constexpr int PER = (8 + SLOTS - 1) / SLOTS;  // max3 ops per slot
 #pragma unroll
         for (int t = 0; t < PER; ++t) {
-          const int q = (g - 2) * PER + t;
+          const int q = (g - G0) * PER + t;
           if (q < 8) tmax = fmaxf(fmaxf(tmax, s_nxt[2 * q]), s_nxt[2 * q + 1]);
         }
       }
@@ -404,18 +421,17 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   // K_{u+1} and V_u are DMA'd during the iteration into the buffers it does not read.
   // Buffer selection is folded into the per-lane LDS bases by XOR (tile offsets do not overlap the lane bits).
   //
-  // A wave's iterations split into generic head / branch-free middle / generic tail.  An iteration is "fast"
-  // when steps 2u-2 .. 2u+1 are all active for this wave and steps 2u, 2u+1 need no mask; activity and
-  // mask-freedom are intervals of the step index, so the fast iterations are one contiguous range
-  // [uf_lo, uf_hi] (different per wave -- every iteration still has exactly one barrier).
+  // A wave's iterations split into generic head / steady-state middle / generic tail.  An iteration is "fast"
+  // when steps 2u-2 .. 2u+1 are all active for this wave (pipeline full); activity is an interval of the step
+  // index, so the fast iterations are one contiguous range [uf_lo, uf_hi] (different per wave -- every
+  // iteration still has exactly one barrier).  Fast iterations whose steps straddle a mask boundary use the
+  // same pipelined step with the mask predicate added.
   int uf_lo = 1, uf_hi = 0;
   if (wave_valid && n_tiles > 0) {
     const int a_lo = max(0, (w_kmin - key_base) >> 5);
     const int a_hi = min(n_steps - 1, (w_kmax - key_base) >> 5);
-    const int f_lo = (w_full_lo - key_base + 31) >> 5;
-    const int f_hi = (w_full_hi - 31 - key_base) >> 5;
-    uf_lo = max((a_lo + 3) >> 1, (f_lo + 1) >> 1);
-    uf_hi = min((a_hi - 1) >> 1, (f_hi - 1) >> 1);
+    uf_lo = (a_lo + 3) >> 1;
+    uf_hi = (a_hi - 1) >> 1;
   }
   auto iter_head = [&](int u) __attribute__((always_inline)) {
     const int par = u & 1;
@@ -437,26 +453,39 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
       step(ICi<0>{}, ICi<1>{}, kb_lane, vb_lane, 2 * u, sB, sA, pfB, pfA);
       iter_tail();
     }
-    for (; u <= uf_hi; ++u) {  // branch-free steady state
-      iter_head(u);
-      const int kb_lane = kbase ^ ((u & 1) * TILE_BYTES);
-      const int vb_lane = vbase ^ ((2 + ((u & 1) ^ 1)) * TILE_BYTES);
-      // step 2u-1: S_{2u} from the first half of K_u, PV of step 2u-2 from the first half of V_{u-1}
+    // steady state, split so that every loop body is a single straight-line variant:
+    //   [uf_lo, um_lo) masked (window's left edge) | [um_lo, um_hi] unmasked | (um_hi, uf_hi] masked (causal diagonal)
+    auto fast_iter = [&](auto maskc, int uu) __attribute__((always_inline)) {
+      iter_head(uu);
+      const int kb_lane = kbase ^ ((uu & 1) * TILE_BYTES);
+      const int vb_lane = vbase ^ ((2 + ((uu & 1) ^ 1)) * TILE_BYTES);
       if constexpr (sched_mode >= 2) {
         int ka[KS], va[DB];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) ka[ks] = kb_lane ^ (ks << 5);
 #pragma unroll
         for (int db = 0; db < DB; ++db) va[db] = vb_lane ^ (db << 6);
-        fast_step(ICi<0>{}, ka, va, sA, sB, pfA, pfB);
-        fast_step(ICi<1>{}, ka, va, sB, sA, pfB, pfA);
-      } else {
-        step(ICi<1>{}, ICi<0>{}, kb_lane, vb_lane, 2 * u - 1, sA, sB, pfA, pfB);
+        // step 2u-1: S_{2u} from the first half of K_u, PV of step 2u-2 from the first half of V_{u-1}
+        fast_step(ICi<0>{}, maskc, 2 * uu, ka, va, sA, sB, pfA, pfB);
         // step 2u: S_{2u+1} from the second half of K_u, PV of step 2u-1 from the second half of V_{u-1}
-        step(ICi<1>{}, ICi<1>{}, kb_lane, vb_lane, 2 * u, sB, sA, pfB, pfA);
+        fast_step(ICi<1>{}, maskc, 2 * uu + 1, ka, va, sB, sA, pfB, pfA);
+      } else {
+        constexpr int F = decltype(maskc)::value ? 0 : 1;  // compiler-ordered variant: masked iterations use the generic step
+        step(ICi<F>{}, ICi<0>{}, kb_lane, vb_lane, 2 * uu - 1, sA, sB, pfA, pfB);
+        step(ICi<F>{}, ICi<1>{}, kb_lane, vb_lane, 2 * uu, sB, sA, pfB, pfA);
       }
       iter_tail();
+    };
+    int um_lo = uf_lo, um_hi = uf_hi;
+    {
+      const int f_lo = (w_full_lo - key_base + 31) >> 5;   // first step with no left-masked key
+      const int f_hi = (w_full_hi - 31 - key_base) >> 5;   // last step with no right-masked key
+      um_lo = max(uf_lo, (f_lo + 1) >> 1);
+      um_hi = min(uf_hi, (f_hi - 1) >> 1);
     }
+    for (; u <= uf_hi && u < um_lo; ++u) fast_iter(ICi<1>{}, u);
+    for (; u <= um_hi; ++u) fast_iter(ICi<0>{}, u);
+    for (; u <= uf_hi; ++u) fast_iter(ICi<1>{}, u);
     for (; u <= n_tiles; ++u) {
       iter_head(u);
       const int kb_lane = kbase ^ ((u & 1) * TILE_BYTES);
