@@ -99,8 +99,16 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, ki = lane & 31;
 
-  // grid: x = key block (low blocks first: they see the most queries under a causal mask), y = kv head, z = batch
-  const int n_block = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  // 1-D grid, XCD-aware remap: each XCD (workgroup id mod 8) walks a contiguous range of (batch, kv head,
+  // key block) items, so it sees every key-block index equally often.  (With a plain (n, h, b) grid XCD x
+  // would only ever get key blocks n = x mod 8 -- under a causal mask a 2.4x work imbalance between XCDs.)
+  // Within a head the low key blocks come first: they see the most queries under a causal mask.
+  const int total = p.nnb * p.h_k * p.b;
+  const int w = xcd_remap(blockIdx.x, total);
+  const int bhk = w / p.nnb;
+  const int n_block = w - bhk * p.nnb;
+  const int b = bhk / p.h_k;
+  const int hk = bhk - b * p.h_k;
   int sq = p.sq, sk = p.sk;
   int64_t q_row0 = 0, k_row0 = 0;
   int64_t q_boff = (int64_t)b * p.q_bs, do_boff = (int64_t)b * p.do_bs;
@@ -560,8 +568,8 @@ static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
     attr_done = true;
   }
-  dim3 grid(p.nnb, p.h_k, p.b);
-  hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p);
+  const long long total = (long long)p.nnb * p.h_k * p.b;
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
