@@ -103,23 +103,25 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen) {
   // Schedule (measured on MI355X, tools/ab_bench.py; FA_FWD_NW overrides):
   //   34 / 38 = software-pipelined kernel (fa_fwd_il.hip) with 4 / 8 waves per workgroup,
   //   4 / 8   = lock-step kernel with 4 / 8 waves, 16 = 8-wave ping-pong (fa_fwd.hip).
-  // The pipelined kernel wins once a query block walks >= ~16 key tiles; below that the 4-wave lock-step
-  // kernel (two workgroups per CU hide each other's prologue/epilogue) is faster.  D = 64 has half the MFMA
-  // work per softmax element, so it prefers 4-wave workgroups throughout.
+  // 8-wave pipelined workgroups (Q block in LDS, one workgroup per CU) win on long key loops (>= ~48 tiles per
+  // query block); 4-wave pipelined workgroups (Q fragments in registers, two workgroups per CU hide each other's
+  // prologue/epilogue) win on shorter loops and under causal masks at S <= 8k.  D = 64 has half the MFMA work
+  // per softmax element and prefers 4-wave workgroups throughout.
   int nw = env_int("FA_FWD_NW", 0);
   if (nw != 4 && nw != 8 && nw != 16 && nw != 34 && nw != 38) {
     const bool right_bounded = (wr >= 0);
     const long avg_keys = right_bounded ? (a->seqlen_k + 1) / 2 : a->seqlen_k;
     const long span = (wl >= 0) ? std::min<long>(avg_keys, wl + (wr >= 0 ? wr : a->seqlen_k) + 256) : avg_keys;
     const long tiles = span / 64;
-    if (a->d == 128) nw = (tiles >= 16 && a->seqlen_q >= 512) ? 38 : 4;
-    else nw = (tiles >= 8 && a->seqlen_q >= 256) ? 34 : 4;
+    if (a->d == 128) nw = (tiles >= 48 && a->seqlen_q >= 512) ? 38 : (a->seqlen_q > 128 ? 34 : 4);
+    else nw = (a->seqlen_q > 128) ? 34 : 4;
   }
   // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
   const bool il = (nw == 34 || nw == 38) && !(a->softcap > 0.f) && !a->alibi_slopes;
   if ((nw == 34 || nw == 38) && !il) nw -= 30;
   const int bm = il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
   k.nmb = (a->seqlen_q + bm - 1) / bm;
+  fa::choose_units(a->b * a->h_k, a->h / a->h_k, k.nmb, k.n_units, k.unit_size);
   const int rc = il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, a->d, nw - 30, (hipStream_t)stream)
                     : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
@@ -160,6 +162,8 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   k.softcap = a->softcap;
   k.nmb = (a->seqlen_q + fa::bwd_block_m() - 1) / fa::bwd_block_m();
   k.nnb = (a->seqlen_k + fa::bwd_block_n() - 1) / fa::bwd_block_n();
+  fa::choose_units(a->b * a->h_k, a->h / a->h_k, k.nmb, k.q_units, k.q_unit_size);
+  fa::choose_units(a->b * a->h_k, 1, k.nnb, k.k_units, k.k_unit_size);
   return FA_OK;
 }
 

@@ -99,12 +99,12 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, ki = lane & 31;
 
-  // 1-D grid, XCD-aware remap: each XCD (workgroup id mod 8) walks a contiguous range of (batch, kv head,
-  // key block) items, so it sees every key-block index equally often.  (With a plain (n, h, b) grid XCD x
+  // 1-D grid, XCD-aware mapping (xcd_interleave): (batch, kv head) units are dealt round-robin to the XCDs and
+  // each XCD walks all key blocks of its units, so it sees every key-block index equally often.  (With a plain (n, h, b) grid XCD x
   // would only ever get key blocks n = x mod 8 -- under a causal mask a 2.4x work imbalance between XCDs.)
   // Within a head the low key blocks come first: they see the most queries under a causal mask.
-  const int total = p.nnb * p.h_k * p.b;
-  const int w = xcd_remap(blockIdx.x, total);
+  const int w = xcd_interleave(blockIdx.x, p.k_units, p.k_unit_size);
+  if (w < 0) return;
   const int bhk = w / p.nnb;
   const int n_block = w - bhk * p.nnb;
   const int b = bhk / p.h_k;
@@ -359,8 +359,8 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, qi = lane & 31;
 
-  const int total = p.nmb * p.b * p.h;
-  const int w = xcd_remap(blockIdx.x, total);
+  const int w = xcd_interleave(blockIdx.x, p.q_units, p.q_unit_size);
+  if (w < 0) return;
   const int bh = w / p.nmb;
   const int mbr = w - bh * p.nmb;
   const int m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
@@ -568,7 +568,7 @@ static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
     attr_done = true;
   }
-  const long long total = (long long)p.nnb * p.h_k * p.b;
+  const long long total = units_grid(p.k_units, p.k_unit_size);
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -582,7 +582,7 @@ static int launch_dq_t(const BwdK& p, hipStream_t stream) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
     attr_done = true;
   }
-  const long long total = (long long)p.nmb * p.b * p.h;
+  const long long total = units_grid(p.q_units, p.q_unit_size);
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

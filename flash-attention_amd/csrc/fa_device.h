@@ -97,14 +97,18 @@ FA_DEVINL void lds_dma_16B(const void* gsrc, const char FA_LDS* lds_dst_uniform)
 }
 FA_DEVINL void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// XCD-aware bijective remap of a 1-D grid: consecutive work items land on the same XCD
-// (block b is observed to run on XCD b % 8; performance only, never correctness).
-FA_DEVINL int xcd_remap(int bid, int total) {
+// XCD-aware work mapping for 1-D grids.  Workgroup `bid` is observed to run on XCD bid % 8 (performance only,
+// never correctness).  Work items are numbered unit * unit_size + item; a *unit* (e.g. all query blocks of the
+// query heads sharing one KV head) must stay on one XCD so its K/V stay in that XCD's L2, and units are dealt to
+// the XCDs round-robin so every XCD sees every kind of unit (long and short sequences, light and heavy blocks).
+// Returns the work index or -1 for the padding workgroups of a partially filled last round.
+FA_DEVINL int xcd_interleave(int bid, int n_units, int unit_size) {
   constexpr int NX = 8;
-  if (total < NX * 2) return bid;
-  const int q = total / NX, r = total % NX;
   const int xcd = bid % NX, slot = bid / NX;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  const int j = slot / unit_size;
+  const int item = slot - j * unit_size;
+  const int unit = xcd + NX * j;
+  return unit < n_units ? unit * unit_size + item : -1;
 }
 
 }  // namespace fa

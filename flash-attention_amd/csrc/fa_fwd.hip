@@ -73,8 +73,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   const int hi = lane >> 5, qi = lane & 31;
 
   // ---- which (batch, head, query block) -------------------------------------------------------
-  const int total = p.nmb * p.b * p.h;
-  const int w = xcd_remap(blockIdx.x, total);
+  const int w = xcd_interleave(blockIdx.x, p.n_units, p.unit_size);
+  if (w < 0) return;
   const int bh = w / p.nmb;
   const int mbr = w - bh * p.nmb;
   const int m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
@@ -442,7 +442,7 @@ static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
     attr_done = true;
   }
-  const long long total = (long long)p.nmb * p.b * p.h;
+  const long long total = units_grid(p.n_units, p.unit_size);
   if (total <= 0) return 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;

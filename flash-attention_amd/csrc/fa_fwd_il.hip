@@ -37,6 +37,7 @@ template <int N> using ICi = std::integral_constant<int, N>;
 template <typename E, int D, int NW, int SCHED>
 __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   constexpr int sched_mode = SCHED;
+  constexpr bool QLDS = (NW == 8);  // 8 waves: Q block in LDS (1 workgroup/CU); 4 waves: Q fragments in registers (2 workgroups/CU)
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   using V4 = typename T::v4;
@@ -57,8 +58,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, qi = lane & 31;
 
-  const int total = p.nmb * p.b * p.h;
-  const int w = xcd_remap(blockIdx.x, total);
+  const int w = xcd_interleave(blockIdx.x, p.n_units, p.unit_size);
+  if (w < 0) return;
   const int bh = w / p.nmb;
   const int mbr = w - bh * p.nmb;
   const int m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
@@ -156,8 +157,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     }
   };
 
-  // Q block -> LDS once (its fragments are re-read per step instead of living in 32 registers)
-  {
+  // Q block -> LDS once (its fragments are re-read per step instead of living in 32 registers), or, for
+  // 4-wave workgroups, Q fragments in registers so that two workgroups fit one CU's LDS.
+  V8 qreg[QLDS ? 1 : KS];
+  if constexpr (QLDS) {
     const int64_t rs = p.q_rs;
     constexpr int QDMA = (BM * ROW_BYTES) / 1024 / NW;  // DMA instructions per wave
 #pragma unroll
@@ -167,6 +170,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
       const int c = d_pc ^ k_swz_il<D>(row);
       lds_dma_16B(qp + (int64_t)grow * rs + c * 8, lds + Q_OFF + (wave * QDMA + i) * 1024);
     }
+  } else {
+    const E* qrow = qp + (int64_t)my_row * p.q_rs + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qreg[ks] = bitcast_u32x4<V8>(ld_global_16B(qrow + 16 * ks, row_valid));
   }
   const int qbase = Q_OFF + (wave * 32 + qi) * ROW_BYTES + ((hi ^ k_swz_il<D>(qi)) << 4);
 
@@ -197,21 +204,21 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 #pragma unroll
     for (int ks = 0; ks < PF - 1 && ks < KS; ++ks) {
       kfrag[ks % PF] = *(const u32x4 FA_LDS*)(kbuf + (kb_lane ^ (ks << 5)));
-      qfrag[ks % PF] = *(const u32x4 FA_LDS*)(lds + (qbase ^ (ks << 5)));
+      if constexpr (QLDS) qfrag[ks % PF] = *(const u32x4 FA_LDS*)(lds + (qbase ^ (ks << 5)));
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int nx = ks + PF - 1;
       if (nx < KS) {
         kfrag[nx % PF] = *(const u32x4 FA_LDS*)(kbuf + (kb_lane ^ (nx << 5)));
-        qfrag[nx % PF] = *(const u32x4 FA_LDS*)(lds + (qbase ^ (nx << 5)));
+        if constexpr (QLDS) qfrag[nx % PF] = *(const u32x4 FA_LDS*)(lds + (qbase ^ (nx << 5)));
       }
       f32x16 c = s;
       if (ks == 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
       }
-      s = T::mfma(bitcast_u32x4<V8>(kfrag[ks % PF]), bitcast_u32x4<V8>(qfrag[ks % PF]), c);
+      s = T::mfma(bitcast_u32x4<V8>(kfrag[ks % PF]), QLDS ? bitcast_u32x4<V8>(qfrag[ks % PF]) : qreg[QLDS ? 0 : ks], c);
     }
   };
   // O^T += V^T(32 keys) . P^T : 2*DB MFMAs, transpose reads PFV MFMAs ahead
@@ -291,7 +298,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     s16x4 vlo[RING], vhi[RING];
     auto rd_kq = [&](int ks) __attribute__((always_inline)) {
       kfr[ks % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[ks] + HOFF);
-      qfr[ks % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(qa[ks]);
+      if constexpr (QLDS) qfr[ks % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(qa[ks]);
     };
     auto rd_v = [&](int op) __attribute__((always_inline)) {
       const char FA_LDS* a0 = (const char FA_LDS*)(unsigned long)(unsigned)(va[op % DB] + HOFF + (16 * (op / DB)) * ROW_BYTES);
@@ -316,7 +323,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
       }
-      s_nxt = T::mfma(bitcast_u32x4<V8>(kfr[g % RING]), bitcast_u32x4<V8>(qfr[g % RING]), c);
+      s_nxt = T::mfma(bitcast_u32x4<V8>(kfr[g % RING]), QLDS ? bitcast_u32x4<V8>(qfr[g % RING]) : qreg[QLDS ? 0 : g], c);
 #pragma unroll
       for (int e = 0; e < EPG; e += 2) {
         const int r = g * EPG + e;
@@ -517,7 +524,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 
 template <typename E, int D, int NW, int SCHED>
 static int launch_fwd_il_t(const FwdK& p, hipStream_t stream) {
-  constexpr int smem = 4 * 64 * D * 2 + NW * 32 * D * 2;
+  constexpr int smem = 4 * 64 * D * 2 + (NW == 8 ? NW * 32 * D * 2 : 0);
   auto kern = fa_fwd_il_kernel<E, D, NW, SCHED>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -526,7 +533,7 @@ static int launch_fwd_il_t(const FwdK& p, hipStream_t stream) {
     if (hipFuncGetAttributes(&fattr, (const void*)kern) != hipSuccess || fattr.sharedSizeBytes != 0) return -1;
     attr_done = true;
   }
-  const long long total = (long long)p.nmb * p.b * p.h;
+  const long long total = units_grid(p.n_units, p.unit_size);
   if (total <= 0) return 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -5,6 +5,17 @@
 
 namespace fa {
 
+// Choose the XCD mapping unit: prefer whole KV groups, fall back to heads, then to single blocks, whenever the
+// coarser unit count would leave XCDs idle (fewer than 16 units, or a ragged last round above 12 %).
+inline void choose_units(int n_groups, int heads_per_group, int blocks_per_head, int& n_units, int& unit_size) {
+  auto ok = [](int n) { return n >= 16 && ((n + 7) / 8 * 8 - n) * 8 <= n; };
+  if (ok(n_groups)) { n_units = n_groups; unit_size = heads_per_group * blocks_per_head; return; }
+  const int n_heads = n_groups * heads_per_group;
+  if (ok(n_heads)) { n_units = n_heads; unit_size = blocks_per_head; return; }
+  n_units = n_heads * blocks_per_head; unit_size = 1;
+}
+inline long long units_grid(int n_units, int unit_size) { return (long long)((n_units + 7) / 8) * 8 * unit_size; }
+
 // Forward.  `nw` = waves per workgroup (4 or 8); query block = 32*nw rows.  Returns 0, -1 (launch
 // failure) or -2 (no kernel built for this dtype/head-dim/nw).
 int launch_fwd(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream);

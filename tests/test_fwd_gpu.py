@@ -101,9 +101,13 @@ def test_strided_qkv_packed_views(be):
     assert torch.equal(out, out2) and torch.equal(lse, lse2)
 
 
+@pytest.mark.parametrize("nw", ["4", "8", "16", "34", "38"])
 @pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("causal", [False, True])
-def test_varlen_equals_per_sequence_bit_exact(be, d, causal):
+def test_varlen_equals_per_sequence_bit_exact(be, monkeypatch, d, causal, nw):
+    """cu_seqlens indexing check: with the schedule pinned (the default heuristic picks it from max_seqlen, which
+    differs between a packed batch and its single sequences), a varlen call is bit-identical to per-sequence calls."""
+    monkeypatch.setenv("FA_FWD_NW", nw)
     torch.manual_seed(2)
     lens_q = [0, 76, 34, 146, 1, 300, 257]
     lens_k = [5, 76, 1, 300, 77, 300, 255]
@@ -190,3 +194,21 @@ def test_threshold_accuracy_budget(be, monkeypatch):
         monkeypatch.setenv("FA_RESCALE_THR", thr)
         errs[thr] = max_abs(_fwd(be, q, k, v, True)[0].float(), ref)
     assert errs["8"] <= 1.5 * errs["0"] + 1e-3, errs
+
+
+def test_varlen_default_schedule_matches_per_sequence_within_rounding(be):
+    """Same check with the default schedule heuristic (which may pick different schedules for the packed call and
+    the single sequences): equal up to bf16 output rounding."""
+    torch.manual_seed(21)
+    lens = [513, 77, 1200, 300]
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    q = torch.randn(sum(lens), 4, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(sum(lens), 2, 128, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    out, lse, _, _ = be.varlen_fwd(q, k, v, None, cu, cu, None, None, None, None, max(lens), max(lens), 0.0, 128 ** -0.5, False, True,
+                                   -1, -1, 0.0, False, None)
+    for b in range(len(lens)):
+        s0, s1 = int(cu[b]), int(cu[b + 1])
+        o1, l1 = _fwd(be, q[None, s0:s1], k[None, s0:s1], v[None, s0:s1], True)
+        assert max_abs(out[s0:s1].float(), o1[0].float()) < 1.6e-2
+        assert max_abs(lse[:, s0:s1], l1[0]) < 1e-4
