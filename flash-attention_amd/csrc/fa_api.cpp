@@ -121,7 +121,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen) {
   if ((nw == 34 || nw == 38) && !il) nw -= 30;
   const int bm = il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
   k.nmb = (a->seqlen_q + bm - 1) / bm;
-  fa::choose_units(a->b * a->h_k, a->h / a->h_k, k.nmb, k.n_units, k.unit_size);
+  fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb, k.n_units, k.unit_size, k.unit_hpx);
   const int rc = il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, a->d, nw - 30, (hipStream_t)stream)
                     : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
@@ -162,8 +162,8 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   k.softcap = a->softcap;
   k.nmb = (a->seqlen_q + fa::bwd_block_m() - 1) / fa::bwd_block_m();
   k.nnb = (a->seqlen_k + fa::bwd_block_n() - 1) / fa::bwd_block_n();
-  fa::choose_units(a->b * a->h_k, a->h / a->h_k, k.nmb, k.q_units, k.q_unit_size);
-  fa::choose_units(a->b * a->h_k, 1, k.nnb, k.k_units, k.k_unit_size);
+  fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb, k.q_units, k.q_unit_size, k.q_unit_hpx);
+  fa::choose_units(a->b, a->h_k, 1, k.nnb, k.k_units, k.k_unit_size, k.k_unit_hpx);
   return FA_OK;
 }
 

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
   // each XCD walks all key blocks of its units, so it sees every key-block index equally often.  (With a plain (n, h, b) grid XCD x
   // would only ever get key blocks n = x mod 8 -- under a causal mask a 2.4x work imbalance between XCDs.)
   // Within a head the low key blocks come first: they see the most queries under a causal mask.
-  const int w = xcd_interleave(blockIdx.x, p.k_units, p.k_unit_size);
+  const int w = xcd_interleave(blockIdx.x, p.k_units, p.k_unit_size, p.k_unit_hpx);
   if (w < 0) return;
   const int bhk = w / p.nnb;
   const int n_block = w - bhk * p.nnb;
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, qi = lane & 31;
 
-  const int w = xcd_interleave(blockIdx.x, p.q_units, p.q_unit_size);
+  const int w = xcd_interleave(blockIdx.x, p.q_units, p.q_unit_size, p.q_unit_hpx);
   if (w < 0) return;
   const int bh = w / p.nmb;
   const int mbr = w - bh * p.nmb;

@@ -99,15 +99,25 @@ FA_DEVINL void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memor
 
 // XCD-aware work mapping for 1-D grids.  Workgroup `bid` is observed to run on XCD bid % 8 (performance only,
 // never correctness).  Work items are numbered unit * unit_size + item; a *unit* (e.g. all query blocks of the
-// query heads sharing one KV head) must stay on one XCD so its K/V stay in that XCD's L2, and units are dealt to
-// the XCDs round-robin so every XCD sees every kind of unit (long and short sequences, light and heavy blocks).
+// query heads sharing one KV head) must stay on one XCD so its K/V stay in that XCD's L2.  Units are dealt so
+// that every XCD sees every sequence (packed batches have very uneven sequences):
+//   hpx > 0 : units are (batch, kv-head) pairs with kv-heads-per-batch = 8 * hpx; XCD x owns kv heads
+//             [x*hpx, (x+1)*hpx) of EVERY batch entry (adjacent heads stay together: their rows are adjacent in
+//             HBM, which measurably helps the fabric);
+//   hpx = 0 : units dealt round-robin (unit u -> XCD u % 8).
 // Returns the work index or -1 for the padding workgroups of a partially filled last round.
-FA_DEVINL int xcd_interleave(int bid, int n_units, int unit_size) {
+FA_DEVINL int xcd_interleave(int bid, int n_units, int unit_size, int hpx) {
   constexpr int NX = 8;
   const int xcd = bid % NX, slot = bid / NX;
   const int j = slot / unit_size;
   const int item = slot - j * unit_size;
-  const int unit = xcd + NX * j;
+  int unit;
+  if (hpx > 0) {
+    const int bb = j / hpx;
+    unit = bb * (NX * hpx) + xcd * hpx + (j - bb * hpx);
+  } else {
+    unit = xcd + NX * j;
+  }
   return unit < n_units ? unit * unit_size + item : -1;
 }
 

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   const int hi = lane >> 5, qi = lane & 31;
 
   // ---- which (batch, head, query block) -------------------------------------------------------
-  const int w = xcd_interleave(blockIdx.x, p.n_units, p.unit_size);
+  const int w = xcd_interleave(blockIdx.x, p.n_units, p.unit_size, p.unit_hpx);
   if (w < 0) return;
   const int bh = w / p.nmb;
   const int mbr = w - bh * p.nmb;

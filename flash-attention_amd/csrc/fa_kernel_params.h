@@ -24,7 +24,7 @@ struct FwdK {
   int32_t sq, sk;            // fixed: exact; varlen: max
   int32_t total_q;
   int32_t nmb;               // query blocks per sequence (grid sizing)
-  int32_t n_units, unit_size;  // XCD work mapping (fa_device.h xcd_interleave); grid = 8*ceil(n_units/8)*unit_size
+  int32_t n_units, unit_size, unit_hpx;  // XCD work mapping (fa_device.h xcd_interleave); grid = 8*ceil(n_units/8)*unit_size
   int32_t wl, wr;            // normalised window, < 0 = unbounded
   float scale;               // softmax_scale
   float scale_log2;          // softmax_scale * log2(e)
@@ -59,8 +59,8 @@ struct BwdK {
   int32_t sq, sk;
   int32_t total_q, total_k;
   int32_t nmb, nnb;          // query / key blocks per sequence
-  int32_t q_units, q_unit_size;  // XCD work mapping of the dQ kernel
-  int32_t k_units, k_unit_size;  // XCD work mapping of the dK/dV kernel
+  int32_t q_units, q_unit_size, q_unit_hpx;  // XCD work mapping of the dQ kernel
+  int32_t k_units, k_unit_size, k_unit_hpx;  // XCD work mapping of the dK/dV kernel
   int32_t wl, wr;
   float scale;
   float scale_log2;

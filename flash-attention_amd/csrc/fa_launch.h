@@ -5,9 +5,13 @@
 
 namespace fa {
 
-// Choose the XCD mapping unit: prefer whole KV groups, fall back to heads, then to single blocks, whenever the
-// coarser unit count would leave XCDs idle (fewer than 16 units, or a ragged last round above 12 %).
-inline void choose_units(int n_groups, int heads_per_group, int blocks_per_head, int& n_units, int& unit_size) {
+// Choose the XCD mapping (see xcd_interleave): whole KV groups split by head range when the KV head count is a
+// multiple of 8; otherwise round-robin over KV groups, falling back to heads and then to single blocks whenever
+// the coarser unit count would leave XCDs idle (fewer than 16 units, or a ragged last round above 12 %).
+inline void choose_units(int batch, int kv_heads, int heads_per_group, int blocks_per_head, int& n_units, int& unit_size, int& hpx) {
+  const int n_groups = batch * kv_heads;
+  hpx = 0;
+  if (kv_heads % 8 == 0) { n_units = n_groups; unit_size = heads_per_group * blocks_per_head; hpx = kv_heads / 8; return; }
   auto ok = [](int n) { return n >= 16 && ((n + 7) / 8 * 8 - n) * 8 <= n; };
   if (ok(n_groups)) { n_units = n_groups; unit_size = heads_per_group * blocks_per_head; return; }
   const int n_heads = n_groups * heads_per_group;
