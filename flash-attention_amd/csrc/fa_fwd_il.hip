@@ -19,6 +19,9 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef FA_ABL
+#define FA_ABL 0  // timing ablations of the steady-state step (results become wrong): see tools/ablate_fwd.sh
+#endif
 #ifndef FA_IL_AHEAD
 #define FA_IL_AHEAD 4  // LDS operand reads issued this many MFMA slots ahead (LDS latency ~130-200 cycles, slot ~35)
 #endif
@@ -307,8 +310,13 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     };
     // operand reads run AHEAD slots in front of their MFMA over the whole 16-slot sequence
     auto rd_slot = [&](int slot) __attribute__((always_inline)) {
+#if FA_ABL == 4
+      if (slot == 0) { rd_kq(0); } else if (slot == KS) { rd_v(0); } else if (slot < KS) { kfr[slot % RING] = kfr[0]; qfr[slot % RING] = qfr[0]; }
+      else if (slot < KS + NOP) { vlo[(slot - KS) % RING] = vlo[0]; vhi[(slot - KS) % RING] = vhi[0]; }
+#else
       if (slot < KS) rd_kq(slot);
       else if (slot < KS + NOP) rd_v(slot - KS);
+#endif
     };
     const float neg_mc = (m_run == -INFINITY) ? 0.f : -m_run * cs;
     float ps0 = 0.f, ps1 = 0.f;
@@ -323,12 +331,20 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
       }
+#if FA_ABL != 3
       s_nxt = T::mfma(bitcast_u32x4<V8>(kfr[g % RING]), QLDS ? bitcast_u32x4<V8>(qfr[g % RING]) : qreg[QLDS ? 0 : g], c);
+#else
+      asm volatile("" ::"v"(kfr[g % RING]), "v"(qfr[g % RING]));
+#endif
 #pragma unroll
       for (int e = 0; e < EPG; e += 2) {
         const int r = g * EPG + e;
+#if FA_ABL == 1
+        const float p0 = s_cur[r] * cs, p1 = s_cur[r + 1] * cs;
+#else
         const float p0 = fast_exp2(__builtin_fmaf(s_cur[r], cs, neg_mc));
         const float p1 = fast_exp2(__builtin_fmaf(s_cur[r + 1], cs, neg_mc));
+#endif
         s_cur[r] = p0;
         s_cur[r + 1] = p1;
         ps0 += p0;
@@ -347,7 +363,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 #pragma unroll
     for (int g = 0; g < NOP; ++g) {
       rd_slot(KS + g + AHEAD);
+#if FA_ABL != 2
       o_acc[g % DB] = T::mfma(combine_tr<V8>(vlo[g % RING], vhi[g % RING]), pf_prev[g / DB], o_acc[g % DB]);
+#else
+      asm volatile("" ::"v"(vlo[g % RING]), "v"(vhi[g % RING]));
+#endif
       if constexpr (MASK) {  // mask.h:172-203 predicate on the freshly produced scores, spread over the first slots
         if (g >= 1 && g < 1 + 2) {
 #pragma unroll
@@ -357,7 +377,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
           }
         }
       }
-      if (g >= (MASK ? 3 : 2)) {  // row-max tree, spread over the remaining slots (2 values per max3)
+      if (FA_ABL != 6 && g >= (MASK ? 3 : 2)) {  // row-max tree, spread over the remaining slots (2 values per max3)
         constexpr int G0 = MASK ? 3 : 2;
         constexpr int SLOTS = NOP - G0;
         constexpr int PER = (8 + SLOTS - 1) / SLOTS;  // max3 ops per slot
@@ -441,6 +461,9 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     uf_hi = (a_hi - 1) >> 1;
   }
   auto iter_head = [&](int u) __attribute__((always_inline)) {
+#if FA_ABL == 5
+    if (u > 1) return;
+#endif
     const int par = u & 1;
     if (u + 1 < n_tiles) dma_tile(ICi<0>{}, par ^ 1, u + 1);
     if (u < n_tiles) dma_tile(ICi<1>{}, par, u);
