@@ -117,7 +117,8 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen) {
     else nw = (a->seqlen_q > 128) ? 34 : 4;
   }
   // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
-  const bool il = (nw == 34 || nw == 38) && !(a->softcap > 0.f) && !a->alibi_slopes;
+  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes;
+  const bool il = (nw == 34 || nw == 38) && plain;
   if ((nw == 34 || nw == 38) && !il) nw -= 30;
   const int bm = il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
   k.nmb = (a->seqlen_q + bm - 1) / bm;
