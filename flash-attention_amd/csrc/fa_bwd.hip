@@ -20,6 +20,8 @@
 // Arithmetic follows the reference: P = exp2(S*scale*log2e - LSE*log2e) (flash_bwd_kernel.h:536),
 // dS = P*(dP - delta) (:584-595), P and dS rounded to the input dtype before their contractions,
 // softmax_scale applied once at the end (:733, flash_bwd_preprocess_kernel.h:250).
+#include <cstdlib>
+
 #include "fa_device.h"
 #include "fa_kernel_params.h"
 #include "fa_launch.h"
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
 // ------------------------------------------------------------------------------------------------
 // dK / dV
 // ------------------------------------------------------------------------------------------------
-template <typename E, int D>
+template <typename E, int D, bool ALIBI>
 __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk_acc[db][r] = 0.f; dv_acc[db][r] = 0.f; }
 
-  const float cs = p.alibi ? kLog2e : p.scale_log2;
+  const float cs = ALIBI ? kLog2e : p.scale_log2;
 
   if (n_items > 0) {
     load_item(0, 0);
@@ -230,11 +232,11 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
     const bool has_next = it + 1 < n_items;
     if (has_next) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
     const int m0 = item_m0(it);
-    const float slope = p.alibi ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
+    const float slope = ALIBI ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
     const char FA_LDS* qbuf = lds + OFF_Q + cur * QT_BYTES;
     const char FA_LDS* dobuf = lds + OFF_DO + cur * QT_BYTES;
 
-#pragma unroll 1
+#pragma unroll
     for (int qb = 0; qb < BMQ / 32; ++qb) {
       const int q0 = m0 + 32 * qb;
       bool active = wave_valid && q0 < sq;
@@ -260,7 +262,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
         dp = T::mfma(bitcast_u32x4<V8>(da), bitcast_u32x4<V8>(vb), dp);
       }
 
-      if (p.alibi) {
+      if constexpr (ALIBI) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int qrow = q0 + acc_row(r, hi);
@@ -340,17 +342,15 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
 // ------------------------------------------------------------------------------------------------
 // dQ
 // ------------------------------------------------------------------------------------------------
-template <typename E, int D>
-__global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
+template <typename E, int D, int NW, bool ALIBI>
+__global__ void __launch_bounds__(NW * 64, 2) fa_bwd_dq_kernel(const BwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   using V4 = typename T::v4;
-  constexpr int NW = 8, NT = NW * 64;
+  constexpr int NT = NW * 64;
   constexpr int BM = NW * 32, BN = 64;
   constexpr int CPR = D / 8, ROW_BYTES = D * 2, TILE_BYTES = BN * ROW_BYTES;
   constexpr int KS = D / 16, DB = D / 32;
-  constexpr int LD = (BN * CPR) / NT;
-  static_assert(LD >= 1, "tile too small for the workgroup");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char FA_LDS* lds = (char FA_LDS*)smem;  // K0 | K1 | V0 | V1
@@ -398,8 +398,8 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
   const int lim_hi = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
   const int lim_lo = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
 
-  const float cs = p.alibi ? kLog2e : p.scale_log2;
-  const float slope = p.alibi ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
+  const float cs = ALIBI ? kLog2e : p.scale_log2;
+  const float slope = ALIBI ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
 
   // Q and dO fragments (B operands), LSE and delta (lane-local scalars)
   V8 qf[KS], dof[KS];
@@ -419,25 +419,18 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
     delta_l = p.delta[base + my_row];
   }
 
-  u32x4 kreg[LD], vreg[LD];
-  auto load_tile = [&](int n) {
+  // K/V tiles: global -> LDS by DMA (source-side swizzle, rows past the last key clamped; see fa_fwd_il.hip)
+  constexpr int RPD = 1024 / ROW_BYTES, NDMA = TILE_BYTES / 1024, DPW = NDMA / NW;
+  static_assert(NDMA % NW == 0 && DPW >= 1, "tile does not divide over the waves");
+  auto load_tile = [&](int n, int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < LD; ++i) {
-      const int idx = tid + i * NT;
-      const int row = idx / CPR, ch = idx % CPR;
-      const int key = n * BN + row;
-      const bool ok = key < sk;
-      kreg[i] = ld_global_16B(kp + (int64_t)key * p.k_rs + ch * 8, ok);
-      vreg[i] = ld_global_16B(vp + (int64_t)key * p.v_rs + ch * 8, ok);
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < LD; ++i) {
-      const int idx = tid + i * NT;
-      const int row = idx / CPR, ch = idx % CPR;
-      *(u32x4 FA_LDS*)(lds + buf * TILE_BYTES + tile_off<D>(row, ch)) = kreg[i];
-      *(u32x4 FA_LDS*)(lds + (2 + buf) * TILE_BYTES + tile_off<D>(row, ch)) = vreg[i];
+    for (int i = 0; i < DPW; ++i) {
+      const int idx = wave * DPW + i;
+      const int row = idx * RPD + lane / CPR;
+      const int c = (lane % CPR) ^ swz16<D>(row);
+      const int key = min(n * BN + row, sk - 1);
+      lds_dma_16B(kp + (int64_t)key * p.k_rs + c * 8, lds + buf * TILE_BYTES + idx * 1024);
+      lds_dma_16B(vp + (int64_t)key * p.v_rs + c * 8, lds + (2 + buf) * TILE_BYTES + idx * 1024);
     }
   };
 
@@ -459,8 +452,8 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
     for (int r = 0; r < 16; ++r) dq_acc[db][r] = 0.f;
 
   if (n_min < n_max) {
-    load_tile(n_min);
-    store_tile(0);
+    load_tile(n_min, 0);
+    lds_dma_wait_all();
     __syncthreads();
   }
 
@@ -468,7 +461,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
     const int cur = (n - n_min) & 1;
     const int kv0 = n * BN;
     const bool has_next = n + 1 < n_max;
-    if (has_next) load_tile(n + 1);
+    if (has_next) load_tile(n + 1, cur ^ 1);  // lands in the other buffers while this tile is computed
 
     const bool active = wave_valid && (kv0 <= w_kmax) && (kv0 + BN - 1 >= w_kmin);
     if (active) {
@@ -493,7 +486,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
           const u32x4 va = *(const u32x4 FA_LDS*)(vbuf + coff);
           dp = T::mfma(bitcast_u32x4<V8>(va), dof[ks], dp);
         }
-        if (p.alibi) {
+        if constexpr (ALIBI) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kv0 + 32 * kb + acc_row(r, hi);
@@ -528,7 +521,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
         }
       }
     }
-    if (has_next) store_tile(cur ^ 1);
+    lds_dma_wait_all();
     __syncthreads();
   }
 
@@ -548,7 +541,10 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dq_kernel(const BwdK p) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-int bwd_block_m() { return 256; }
+int bwd_block_m() {
+  static const int nw = [] { const char* e = getenv("FA_BWD_DQ_NW"); const int v = e ? atoi(e) : 4; return (v == 8) ? 8 : 4; }();
+  return 32 * nw;
+}
 int bwd_block_n() { return 256; }
 
 template <typename E, int D>
@@ -559,10 +555,10 @@ static int launch_delta_t(const BwdK& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <typename E, int D>
-static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
+template <typename E, int D, bool ALIBI>
+static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
   constexpr int smem = 256 * D * 2 + 4 * 64 * D * 2 + 4 * 64 * 4;
-  auto kern = fa_bwd_dkdv_kernel<E, D>;
+  auto kern = fa_bwd_dkdv_kernel<E, D, ALIBI>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
@@ -574,17 +570,27 @@ static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
 }
 
 template <typename E, int D>
-static int launch_dq_t(const BwdK& p, hipStream_t stream) {
+static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
+  return p.alibi ? launch_dkdv_a<E, D, true>(p, stream) : launch_dkdv_a<E, D, false>(p, stream);
+}
+
+template <typename E, int D, int NW, bool ALIBI>
+static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2;
-  auto kern = fa_bwd_dq_kernel<E, D>;
+  auto kern = fa_bwd_dq_kernel<E, D, NW, ALIBI>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
     attr_done = true;
   }
   const long long total = units_grid(p.q_units, p.q_unit_size);
-  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), smem, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+template <typename E, int D>
+static int launch_dq_t(const BwdK& p, hipStream_t stream) {
+  if (p.alibi) return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, true>(p, stream) : launch_dq_nw<E, D, 4, true>(p, stream);
+  return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, false>(p, stream) : launch_dq_nw<E, D, 4, false>(p, stream);
 }
 
 #define FA_BWD_DISPATCH(fn)                                            \
