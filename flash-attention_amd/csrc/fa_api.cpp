@@ -139,7 +139,6 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   if (varlen != (a->cu_seqlens_q != nullptr) || varlen != (a->cu_seqlens_k != nullptr))
     return fail(FA_ERR_INVALID_ARGUMENT, varlen ? "fa_varlen_bwd needs cu_seqlens_q and cu_seqlens_k"
                                                 : "fa_bwd takes fixed-length batches (cu_seqlens must be NULL)");
-  if (a->softcap > 0.f) return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: softcap backward is not built yet");
   k = fa::BwdK{};
   k.dout = a->dout; k.q = a->q; k.k = a->k; k.v = a->v; k.o = a->o; k.lse = a->softmax_lse;
   k.dq = a->dq; k.dk = a->dk; k.dv = a->dv; k.delta = a->softmax_d;

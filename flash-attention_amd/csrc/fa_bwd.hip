@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
 // ------------------------------------------------------------------------------------------------
 // dK / dV
 // ------------------------------------------------------------------------------------------------
-template <typename E, int D, bool ALIBI>
+template <typename E, int D, bool XFORM>
 __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk_acc[db][r] = 0.f; dv_acc[db][r] = 0.f; }
 
-  const float cs = ALIBI ? kLog2e : p.scale_log2;
+  const float cs = XFORM ? kLog2e : p.scale_log2;
 
   if (n_items > 0) {
     load_item(0, 0);
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
     const bool has_next = it + 1 < n_items;
     if (has_next) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
     const int m0 = item_m0(it);
-    const float slope = ALIBI ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
+    const float slope = (XFORM && p.alibi) ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
     const char FA_LDS* qbuf = lds + OFF_Q + cur * QT_BYTES;
     const char FA_LDS* dobuf = lds + OFF_DO + cur * QT_BYTES;
 
@@ -262,11 +262,20 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
         dp = T::mfma(bitcast_u32x4<V8>(da), bitcast_u32x4<V8>(vb), dp);
       }
 
-      if constexpr (ALIBI) {
+      f32x16 dcap;  // d(softcap*tanh(x/softcap))/dx = 1 - tanh^2 (reference flash_bwd_kernel.h:588 / utils.h:395-409)
+      if constexpr (XFORM) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int qrow = q0 + acc_row(r, hi);
-          s[r] = s[r] * p.scale - slope * fabsf((float)(qrow + shift - my_key));
+          float y = s[r] * p.scale;
+          dcap[r] = 1.f;
+          if (p.softcap > 0.f) {
+            const float t = tanhf(y / p.softcap);
+            y = p.softcap * t;
+            dcap[r] = 1.f - t * t;
+          }
+          if (p.alibi) y -= slope * fabsf((float)(qrow + shift - my_key));
+          s[r] = y;
         }
       }
       bool need_mask = false;
@@ -293,7 +302,8 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           const float pv = fast_exp2(__builtin_fmaf(s[r], cs, -l4[j]));
-          const float dsv = pv * (dp[r] - d4[j]);
+          float dsv = pv * (dp[r] - d4[j]);
+          if constexpr (XFORM) dsv *= dcap[r];
           pfrag[r >> 3][r & 7] = (E)pv;
           dsfrag[r >> 3][r & 7] = (E)dsv;
         }
@@ -342,7 +352,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
 // ------------------------------------------------------------------------------------------------
 // dQ
 // ------------------------------------------------------------------------------------------------
-template <typename E, int D, int NW, bool ALIBI>
+template <typename E, int D, int NW, bool XFORM>
 __global__ void __launch_bounds__(NW * 64, 2) fa_bwd_dq_kernel(const BwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
@@ -398,8 +408,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_bwd_dq_kernel(const BwdK p) {
   const int lim_hi = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
   const int lim_lo = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
 
-  const float cs = ALIBI ? kLog2e : p.scale_log2;
-  const float slope = ALIBI ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
+  const float cs = XFORM ? kLog2e : p.scale_log2;
+  const float slope = (XFORM && p.alibi) ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
 
   // Q and dO fragments (B operands), LSE and delta (lane-local scalars)
   V8 qf[KS], dof[KS];
@@ -486,11 +496,20 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_bwd_dq_kernel(const BwdK p) {
           const u32x4 va = *(const u32x4 FA_LDS*)(vbuf + coff);
           dp = T::mfma(bitcast_u32x4<V8>(va), dof[ks], dp);
         }
-        if constexpr (ALIBI) {
+        f32x16 dcap;
+        if constexpr (XFORM) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kv0 + 32 * kb + acc_row(r, hi);
-            s[r] = s[r] * p.scale - slope * fabsf((float)(my_row + shift - key));
+            float y = s[r] * p.scale;
+            dcap[r] = 1.f;
+            if (p.softcap > 0.f) {
+              const float t = tanhf(y / p.softcap);
+              y = p.softcap * t;
+              dcap[r] = 1.f - t * t;
+            }
+            if (p.alibi) y -= slope * fabsf((float)(my_row + shift - key));
+            s[r] = y;
           }
         }
         if (need_mask) {
@@ -506,7 +525,9 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_bwd_dq_kernel(const BwdK p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pv = fast_exp2(__builtin_fmaf(s[r], cs, -lse_l));
-          dsfrag[r >> 3][r & 7] = (E)(pv * (dp[r] - delta_l));
+          float dsv = pv * (dp[r] - delta_l);
+          if constexpr (XFORM) dsv *= dcap[r];
+          dsfrag[r >> 3][r & 7] = (E)dsv;
         }
         // dQ^T[d][query] += K^T[d][key] . dS^T[key][query]
 #pragma unroll
@@ -555,10 +576,10 @@ static int launch_delta_t(const BwdK& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <typename E, int D, bool ALIBI>
+template <typename E, int D, bool XFORM>
 static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
   constexpr int smem = 256 * D * 2 + 4 * 64 * D * 2 + 4 * 64 * 4;
-  auto kern = fa_bwd_dkdv_kernel<E, D, ALIBI>;
+  auto kern = fa_bwd_dkdv_kernel<E, D, XFORM>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
@@ -571,13 +592,13 @@ static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
 
 template <typename E, int D>
 static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
-  return p.alibi ? launch_dkdv_a<E, D, true>(p, stream) : launch_dkdv_a<E, D, false>(p, stream);
+  return (p.alibi || p.softcap > 0.f) ? launch_dkdv_a<E, D, true>(p, stream) : launch_dkdv_a<E, D, false>(p, stream);
 }
 
-template <typename E, int D, int NW, bool ALIBI>
+template <typename E, int D, int NW, bool XFORM>
 static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2;
-  auto kern = fa_bwd_dq_kernel<E, D, NW, ALIBI>;
+  auto kern = fa_bwd_dq_kernel<E, D, NW, XFORM>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
@@ -589,7 +610,7 @@ static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
 }
 template <typename E, int D>
 static int launch_dq_t(const BwdK& p, hipStream_t stream) {
-  if (p.alibi) return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, true>(p, stream) : launch_dq_nw<E, D, 4, true>(p, stream);
+  if (p.alibi || p.softcap > 0.f) return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, true>(p, stream) : launch_dq_nw<E, D, 4, true>(p, stream);
   return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, false>(p, stream) : launch_dq_nw<E, D, 4, false>(p, stream);
 }
 

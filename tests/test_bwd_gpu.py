@@ -173,3 +173,26 @@ def test_backward_bitwise_deterministic(be):
         r = _fwd_bwd(be, q, k, v, do, True)
         for x, y in zip(r0[:5], r[:5]):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("alibi", [False, True])
+def test_softcap_backward_vs_oracle(be, d, alibi):
+    """softcap (and softcap+ALiBi) gradients against the fp64 oracle: dS carries (1 - tanh^2)."""
+    from oracle import attention_oracle as orc
+    torch.manual_seed(8)
+    B, Sq, Sk, H, Hk = 2, 150, 231, 4, 2
+    q = torch.randn(B, Sq, H, d, device="cuda", dtype=torch.bfloat16) * 3
+    k = torch.randn(B, Sk, Hk, d, device="cuda", dtype=torch.bfloat16) * 3
+    v = torch.randn(B, Sk, Hk, d, device="cuda", dtype=torch.bfloat16)
+    do = torch.randn(B, Sq, H, d, device="cuda", dtype=torch.bfloat16)
+    slopes = (torch.rand(B, H, device="cuda") * 0.3).float() if alibi else None
+    scale, cap = d ** -0.5, 5.0
+    out, lse, _, _ = be.fwd(q, k, v, None, slopes, 0.0, scale, True, -1, -1, cap, False, None)
+    dq, dk, dv, _ = be.bwd(do, q, k, v, out, lse, None, None, None, slopes, 0.0, scale, True, -1, -1, cap, False, None, None)
+    ref = orc.attention_bwd(do, q, k, v, None, None, scale, True, (-1, -1), cap, None if slopes is None else slopes.cpu())
+    o_ref, _ = orc.attention_fwd(q, k, v, scale, True, (-1, -1), cap, None if slopes is None else slopes.cpu())
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 2e-2
+    for got, r in zip((dq, dk, dv), ref[:3]):
+        r = torch.from_numpy(r)
+        assert max_abs(got.float().cpu(), r) < 3e-2 * max(1.0, float(r.abs().max())), float(r.abs().max())
