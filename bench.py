@@ -146,13 +146,13 @@ def main():
                         "bwd_ms": round(ms_bwd, 4), "frac_of_peak": round(3.5 * flops / (ms + ms_bwd) / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)},
         }
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed
-    # rocprofv3 measurement of the same kernel/config (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) is
-    # reported when present.
-    tpath = os.path.join(ROOT, "profiles", "r01_fwd_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            res["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
-    if world == 1 and not a.no_cpu:
+        # rocprofv3 measurement of the same kernel/config (separate --pmc passes, gfx950 FETCH_SIZE x2 correction)
+        # is reported when present.
+        tpath = os.path.join(ROOT, "profiles", "r01_fwd_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                res["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+        if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(D, S, causal)
         if a.sweep:
             for d_, H_ in ((128, 16), (64, 32)):
