@@ -62,7 +62,7 @@ int check_common(int b, int h, int h_k, int d, int dtype, float softcap) {
   return FA_OK;
 }
 
-int do_fwd(const FaFwdParams* a, void* stream, bool varlen) {
+int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false) {
   if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
   g_err[0] = 0;
   if (int rc = check_common(a->b, a->h, a->h_k, a->d, a->dtype, a->softcap)) return rc;
@@ -72,6 +72,13 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen) {
     return fail(FA_ERR_INVALID_ARGUMENT, varlen ? "fa_varlen_fwd needs cu_seqlens_q and cu_seqlens_k"
                                                 : "fa_fwd takes fixed-length batches (cu_seqlens must be NULL)");
   if (a->seqlen_q < 0 || a->seqlen_k < 0) return fail(FA_ERR_INVALID_ARGUMENT, "negative sequence length");
+  if (!kvcache && (a->cache_batch_idx || a->block_table || a->seqused_k_add))
+    return fail(FA_ERR_INVALID_ARGUMENT, "cache_batch_idx / block_table / seqused_k_add are fa_fwd_kvcache arguments");
+  if (a->block_table) {
+    if (a->cache_batch_idx) return fail(FA_ERR_INVALID_ARGUMENT, "Paged KVcache does not support cache_batch_idx");
+    if (a->page_block_size <= 0 || a->page_block_size % 256 != 0)
+      return fail(FA_ERR_INVALID_ARGUMENT, "Paged KV cache block size must be divisible by 256");
+  }
   if (a->seqlen_q == 0 || a->total_q == 0) return FA_OK;  // nothing to write
 
   fa::FwdK k{};
@@ -81,6 +88,8 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen) {
   k.v_bs = a->v_batch_stride; k.v_rs = a->v_row_stride; k.v_hs = a->v_head_stride;
   k.o_bs = a->o_batch_stride; k.o_rs = a->o_row_stride; k.o_hs = a->o_head_stride;
   k.cu_q = a->cu_seqlens_q; k.cu_k = a->cu_seqlens_k; k.seqused_k = a->seqused_k;
+  k.kv_batch_idx = a->cache_batch_idx; k.block_table = a->block_table; k.block_table_bs = a->block_table_batch_stride;
+  k.page_size = a->page_block_size; k.seqused_add = a->seqused_k_add;
   k.alibi = a->alibi_slopes; k.alibi_bs = a->alibi_batch_stride;
   k.b = a->b; k.h = a->h; k.h_k = a->h_k; k.hk_ratio = a->h / a->h_k;
   k.sq = a->seqlen_q; k.sk = a->seqlen_k; k.total_q = a->total_q;
@@ -190,10 +199,34 @@ extern "C" {
 int fa_abi_version(void) { return FA_ABI_VERSION; }
 int fa_sizeof_fwd_params(void) { return (int)sizeof(FaFwdParams); }
 int fa_sizeof_bwd_params(void) { return (int)sizeof(FaBwdParams); }
+int fa_sizeof_kvappend_params(void) { return (int)sizeof(FaKvAppendParams); }
 const char* fa_last_error(void) { return g_err; }
 
 int fa_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, false); }
 int fa_varlen_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, true); }
+int fa_fwd_kvcache(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, false, true); }
+
+int fa_kvcache_append(const FaKvAppendParams* a, void* stream) {
+  if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+  g_err[0] = 0;
+  if (!a->knew || !a->vnew || !a->kcache || !a->vcache) return fail(FA_ERR_INVALID_ARGUMENT, "knew, vnew, kcache and vcache must be non-NULL");
+  if (a->d <= 0 || a->d % 8 != 0) return fail(FA_ERR_INVALID_ARGUMENT, "head dimension must be a multiple of 8");
+  if (a->dtype != FA_DTYPE_FP16 && a->dtype != FA_DTYPE_BF16) return fail(FA_ERR_INVALID_ARGUMENT, "FlashAttention only supports fp16 and bf16 data type");
+  if (a->block_table && (a->page_block_size <= 0 || a->page_block_size % 256 != 0))
+    return fail(FA_ERR_INVALID_ARGUMENT, "Paged KV cache block size must be divisible by 256");
+  fa::KvAppendK k{};
+  k.knew = a->knew; k.vnew = a->vnew; k.kcache = a->kcache; k.vcache = a->vcache;
+  k.kn_bs = a->knew_batch_stride; k.kn_rs = a->knew_row_stride; k.kn_hs = a->knew_head_stride;
+  k.vn_bs = a->vnew_batch_stride; k.vn_rs = a->vnew_row_stride; k.vn_hs = a->vnew_head_stride;
+  k.kc_bs = a->kcache_batch_stride; k.kc_rs = a->kcache_row_stride; k.kc_hs = a->kcache_head_stride;
+  k.vc_bs = a->vcache_batch_stride; k.vc_rs = a->vcache_row_stride; k.vc_hs = a->vcache_head_stride;
+  k.seqlens_k = a->seqlens_k; k.kv_batch_idx = a->cache_batch_idx; k.block_table = a->block_table;
+  k.block_table_bs = a->block_table_batch_stride; k.page_size = a->page_block_size;
+  k.b = a->b; k.s_new = a->seqlen_new; k.h_k = a->h_k; k.d = a->d;
+  if (fa::launch_kv_append(k, (hipStream_t)stream) != 0)
+    return fail(FA_ERR_LAUNCH, "kv append launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return FA_OK;
+}
 
 int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {
   (void)params;

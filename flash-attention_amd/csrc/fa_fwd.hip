@@ -35,6 +35,7 @@
 //   PP = true   ping-pong (8 waves): the tile is split into a VALU interval SM(j) and a matrix
 //               interval MF(j) = {S_{j+1} = K_{j+1}.Q^T, O += V_j^T.P_j}; waves 4-7 run the same
 //               stream one interval late, so each SIMD always has one wave in each kind of interval.
+#include <algorithm>
 #include <type_traits>
 
 #include "fa_device.h"
@@ -84,7 +85,9 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
 
   int sq = p.sq, sk = p.sk;
   int64_t q_row0 = 0, k_row0 = 0;  // first row of this sequence in the packed tensors
-  int64_t q_boff = (int64_t)b * p.q_bs, k_boff = (int64_t)b * p.k_bs, v_boff = (int64_t)b * p.v_bs, o_boff = (int64_t)b * p.o_bs;
+  const int bkv = p.kv_batch_idx ? p.kv_batch_idx[b] : b;  // KV-cache row of this batch entry
+  int64_t q_boff = (int64_t)b * p.q_bs, k_boff = (int64_t)bkv * p.k_bs, v_boff = (int64_t)bkv * p.v_bs, o_boff = (int64_t)b * p.o_bs;
+  if (p.block_table) { k_boff = 0; v_boff = 0; }  // paged cache: the page index supplies the first-dimension offset
   if (p.cu_q) {  // varlen: rows cu[b] .. cu[b+1]-1  (reference block_info.h:17-36)
     const int c0 = p.cu_q[b];
     sq = p.cu_q[b + 1] - c0;
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
     k_boff = 0;
     v_boff = 0;
   }
-  if (p.seqused_k) sk = p.seqused_k[b];
+  if (p.seqused_k) sk = p.seqused_k[b] + p.seqused_add;
   const int m0 = m_block * BM;
   if (m0 >= sq) return;
 
@@ -161,13 +164,22 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
     st_k[i] = row * ROW_BYTES + ((ch ^ k_swz<D>(row)) << 4);
     st_v[i] = row * ROW_BYTES + (((((ch >> 2) ^ v_swz<D>(row)) << 2) | (ch & 3)) << 4);
   }
+  // first row of key tile n: contiguous cache, or page block_table[b][n*BN / page] of a paged cache
+  // (reference flash_fwd_kernel.h:579-590; pages are multiples of 64 keys, so a tile never straddles two pages)
+  auto tile_row_off = [&](int n, int64_t bs, int64_t rs) __attribute__((always_inline)) -> int64_t {
+    if (!p.block_table) return (int64_t)n * BN * rs;
+    const int key0 = n * BN;
+    const int page = key0 / p.page_size;
+    const int blk = p.block_table[(int64_t)b * p.block_table_bs + page];
+    return (int64_t)blk * bs + (int64_t)(key0 - page * p.page_size) * rs;
+  };
   auto load_k = [&](int n) __attribute__((always_inline)) {
-    const char* base = (const char*)(kp + (int64_t)n * BN * p.k_rs);
+    const char* base = (const char*)(kp + tile_row_off(n, p.k_bs, p.k_rs));
 #pragma unroll
     for (int i = 0; i < LD; ++i) kreg[i] = ld_global_16B(base + kvoff_k[i], n * BN + ld_row[i] < sk);
   };
   auto load_v = [&](int n) __attribute__((always_inline)) {
-    const char* base = (const char*)(vp + (int64_t)n * BN * p.v_rs);
+    const char* base = (const char*)(vp + tile_row_off(n, p.v_bs, p.v_rs));
 #pragma unroll
     for (int i = 0; i < LD; ++i) vreg[i] = ld_global_16B(base + kvoff_v[i], n * BN + ld_row[i] < sk);
   };
@@ -431,6 +443,43 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
       }
     if (hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
   }
+}
+
+// KV-cache append (reference flash_fwd_kernel.h:640-720, the Append_KV branch, without rotary): one thread moves
+// 16 bytes of one new key row and the matching 16 bytes of the value row.
+__global__ void __launch_bounds__(256) fa_kv_append_kernel(const KvAppendK p) {
+  const int cpr = p.d / 8;                       // 16-B chunks per row
+  const int per_b = p.s_new * p.h_k * cpr;
+  const int b = blockIdx.y;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < per_b; i += gridDim.x * 256) {
+    const int c = i % cpr, hk = (i / cpr) % p.h_k, t = i / (cpr * p.h_k);
+    const int row = (p.seqlens_k ? p.seqlens_k[b] : 0) + t;
+    int64_t koff, voff;
+    if (p.block_table) {
+      const int page = row / p.page_size;
+      const int blk = p.block_table[(int64_t)b * p.block_table_bs + page];
+      koff = (int64_t)blk * p.kc_bs + (int64_t)(row - page * p.page_size) * p.kc_rs;
+      voff = (int64_t)blk * p.vc_bs + (int64_t)(row - page * p.page_size) * p.vc_rs;
+    } else {
+      const int bkv = p.kv_batch_idx ? p.kv_batch_idx[b] : b;
+      koff = (int64_t)bkv * p.kc_bs + (int64_t)row * p.kc_rs;
+      voff = (int64_t)bkv * p.vc_bs + (int64_t)row * p.vc_rs;
+    }
+    const unsigned short* ks = (const unsigned short*)p.knew + (int64_t)b * p.kn_bs + (int64_t)t * p.kn_rs + (int64_t)hk * p.kn_hs + c * 8;
+    const unsigned short* vs = (const unsigned short*)p.vnew + (int64_t)b * p.vn_bs + (int64_t)t * p.vn_rs + (int64_t)hk * p.vn_hs + c * 8;
+    unsigned short* kd = (unsigned short*)p.kcache + koff + (int64_t)hk * p.kc_hs + c * 8;
+    unsigned short* vd = (unsigned short*)p.vcache + voff + (int64_t)hk * p.vc_hs + c * 8;
+    *reinterpret_cast<u32x4*>(kd) = *reinterpret_cast<const u32x4*>(ks);
+    *reinterpret_cast<u32x4*>(vd) = *reinterpret_cast<const u32x4*>(vs);
+  }
+}
+
+int launch_kv_append(const KvAppendK& p, hipStream_t stream) {
+  if (p.b <= 0 || p.s_new <= 0) return 0;
+  const int per_b = p.s_new * p.h_k * (p.d / 8);
+  dim3 grid((unsigned)std::min(256, (per_b + 255) / 256), (unsigned)p.b);
+  hipLaunchKernelGGL(fa_kv_append_kernel, grid, dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template <typename E, int D, int NW, bool XFORM, bool PP>

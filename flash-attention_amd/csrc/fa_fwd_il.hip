@@ -72,10 +72,12 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 
   int sq = p.sq, sk = p.sk;
   int64_t q_row0 = 0, k_row0 = 0;
-  int64_t q_boff = (int64_t)b * p.q_bs, k_boff = (int64_t)b * p.k_bs, v_boff = (int64_t)b * p.v_bs, o_boff = (int64_t)b * p.o_bs;
+  const int bkv = p.kv_batch_idx ? p.kv_batch_idx[b] : b;  // KV-cache row of this batch entry
+  int64_t q_boff = (int64_t)b * p.q_bs, k_boff = (int64_t)bkv * p.k_bs, v_boff = (int64_t)bkv * p.v_bs, o_boff = (int64_t)b * p.o_bs;
+  if (p.block_table) { k_boff = 0; v_boff = 0; }  // paged cache: the page index supplies the first-dimension offset
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; o_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
-  if (p.seqused_k) sk = p.seqused_k[b];
+  if (p.seqused_k) sk = p.seqused_k[b] + p.seqused_add;
   const int m0 = m_block * BM;
   if (m0 >= sq) return;
 
@@ -142,7 +144,14 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     constexpr bool ISV = decltype(isvc)::value != 0;
     const int n = n_min + t;
     const int64_t rs = ISV ? p.v_rs : p.k_rs;
-    const char* base = (const char*)((ISV ? vp : kp) + (int64_t)n * BN * rs);
+    int64_t row_off = (int64_t)n * BN * rs;
+    if (p.block_table) {  // paged KV cache: page block_table[b][n*BN / page]; a 64-key tile never straddles two pages
+      const int key0 = n * BN;
+      const int page = key0 / p.page_size;
+      const int blk = p.block_table[(int64_t)b * p.block_table_bs + page];
+      row_off = (int64_t)blk * (ISV ? p.v_bs : p.k_bs) + (int64_t)(key0 - page * p.page_size) * rs;
+    }
+    const char* base = (const char*)((ISV ? vp : kp) + row_off);
     char FA_LDS* dst = lds + (ISV ? 2 + buf : buf) * TILE_BYTES + wave * DPW * 1024;
     if (n * BN + BN <= sk) {
 #pragma unroll

@@ -17,7 +17,12 @@ struct FwdK {
   int64_t o_bs, o_rs, o_hs;
   const int32_t* cu_q;       // nullptr => fixed length
   const int32_t* cu_k;
-  const int32_t* seqused_k;  // optional
+  const int32_t* seqused_k;  // optional: keys in use per batch entry (KV cache: cache_seqlens)
+  const int32_t* kv_batch_idx;   // optional: batch entry -> row of the KV cache (cache_batch_idx)
+  const int32_t* block_table;    // optional: paged KV cache, (b, max_blocks) page indices
+  int64_t block_table_bs;
+  int32_t page_size;             // keys per page (multiple of 64)
+  int32_t seqused_add;           // added to seqused_k (freshly appended keys)
   const float* alibi;        // optional
   int64_t alibi_bs;
   int32_t b, h, h_k, hk_ratio;

@@ -24,6 +24,15 @@ inline long long units_grid(int n_units, int unit_size) { return (long long)((n_
 // failure) or -2 (no kernel built for this dtype/head-dim/nw).
 int launch_fwd(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream);
 int fwd_block_m(int nw);
+
+// KV-cache append: 16-byte copies of the new rows into the (contiguous, batch-indexed or paged) cache.
+struct KvAppendK {
+  const void* knew; const void* vnew; void* kcache; void* vcache;
+  int64_t kn_bs, kn_rs, kn_hs, vn_bs, vn_rs, vn_hs, kc_bs, kc_rs, kc_hs, vc_bs, vc_rs, vc_hs;
+  const int32_t* seqlens_k; const int32_t* kv_batch_idx; const int32_t* block_table; int64_t block_table_bs;
+  int32_t page_size, b, s_new, h_k, d;
+};
+int launch_kv_append(const KvAppendK& p, hipStream_t stream);
 // Software-pipelined forward (fa_fwd_il.hip); nw = 4 or 8 waves per workgroup.  No softcap / ALiBi variant.
 int launch_fwd_il(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream);
 

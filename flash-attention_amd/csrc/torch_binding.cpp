@@ -330,9 +330,118 @@ std::vector<Tensor> mha_varlen_bwd(const Tensor& dout, const Tensor& q, const Te
   return {dq, dk, dv, delta};
 }
 
-std::vector<Tensor> mha_fwd_kvcache(pybind11::args, pybind11::kwargs) {
-  TORCH_CHECK(false, "libfa_gfx950: fwd_kvcache (split-KV decode / paged KV) is not built yet");
-  return {};
+// mha_fwd_kvcache (flash_api.cpp:1243-1532): inference forward against a (contiguous, batch-indexed or paged) KV
+// cache, optionally appending new keys/values first.  Rotary embedding and leftpad_k are not built.
+std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tensor& vcache, OptTensor& k_, OptTensor& v_,
+                                    OptTensor& seqlens_k_, OptTensor& rotary_cos_, OptTensor& rotary_sin_,
+                                    OptTensor& cache_batch_idx_, OptTensor& leftpad_k_, OptTensor& block_table_,
+                                    OptTensor& alibi_slopes_, OptTensor& out_, const double softmax_scale, bool is_causal,
+                                    int64_t window_size_left, int64_t window_size_right, const double softcap,
+                                    bool is_rotary_interleaved, int64_t num_splits) {
+  (void)is_rotary_interleaved; (void)num_splits;
+  TORCH_CHECK(q.dtype() == at::kHalf || q.dtype() == at::kBFloat16, "FlashAttention only support fp16 and bf16 data type");
+  TORCH_CHECK(kcache.dtype() == q.dtype(), "query and key must have the same dtype");
+  TORCH_CHECK(vcache.dtype() == q.dtype(), "query and value must have the same dtype");
+  CHECK_DEVICE(q); CHECK_DEVICE(kcache); CHECK_DEVICE(vcache);
+  TORCH_CHECK(q.stride(-1) == 1 && kcache.stride(-1) == 1 && vcache.stride(-1) == 1, "Input tensor must have contiguous last dimension");
+  TORCH_CHECK(!rotary_cos_.has_value() && !rotary_sin_.has_value(), "libfa_gfx950: rotary embedding in fwd_kvcache is not built");
+  TORCH_CHECK(!leftpad_k_.has_value(), "libfa_gfx950: leftpad_k is not built");
+  const bool paged = block_table_.has_value();
+  if (paged) {
+    TORCH_CHECK(!cache_batch_idx_.has_value(), "Paged KVcache does not support cache_batch_idx");
+    CHECK_DEVICE(*block_table_);
+    TORCH_CHECK(block_table_->dtype() == at::kInt, "block_table must have dtype torch.int32");
+    TORCH_CHECK(block_table_->stride(-1) == 1, "block_table must have contiguous last dimension");
+  }
+  const int64_t B = q.size(0), Sq = q.size(1), H = q.size(2), D = q.size(3);
+  const int64_t Hk = kcache.size(2);
+  const int64_t page = paged ? kcache.size(1) : 0;
+  const int64_t Sk = paged ? block_table_->size(1) * page : kcache.size(1);
+  TORCH_CHECK(B > 0, "batch size must be positive");
+  TORCH_CHECK(D == 64 || D == 128, "libfa_gfx950: fwd_kvcache is built for head dimensions 64 and 128");
+  TORCH_CHECK(H % Hk == 0, "Number of heads in key/value must divide number of heads in query");
+  TORCH_CHECK(kcache.size(3) == D && vcache.sizes() == kcache.sizes(), "kcache / vcache shape mismatch");
+  if (paged) {
+    TORCH_CHECK(page % 256 == 0, "Paged KV cache block size must be divisible by 256");
+  } else if (!cache_batch_idx_.has_value()) {
+    TORCH_CHECK(kcache.size(0) == B, "kcache batch size must match q (or pass cache_batch_idx)");
+  }
+  if (seqlens_k_.has_value()) {
+    TORCH_CHECK(seqlens_k_->dtype() == at::kInt, "seqlens_k must have dtype int32");
+    CHECK_DEVICE(*seqlens_k_); TORCH_CHECK(seqlens_k_->is_contiguous(), "seqlens_k must be contiguous"); CHECK_SHAPE(*seqlens_k_, B);
+  }
+  if (cache_batch_idx_.has_value()) {
+    TORCH_CHECK(cache_batch_idx_->dtype() == at::kInt, "cache_batch_idx must have dtype int32");
+    CHECK_DEVICE(*cache_batch_idx_); TORCH_CHECK(cache_batch_idx_->is_contiguous(), "cache_batch_idx must be contiguous"); CHECK_SHAPE(*cache_batch_idx_, B);
+  }
+  c10::DeviceGuard guard(q.device());
+  if (Sq == 1 && !alibi_slopes_.has_value()) is_causal = false;  // flash_api.cpp:1340
+  if (is_causal) window_size_right = 0;
+
+  int64_t s_new = 0;
+  if (k_.has_value()) {  // append first (flash_fwd_kernel.h Append_KV branch)
+    TORCH_CHECK(v_.has_value(), "If key is supplied, value must also be passed in");
+    TORCH_CHECK(seqlens_k_.has_value(), "If key is supplied, seqlens_k must also be passed in");
+    const Tensor &kn = *k_, &vn = *v_;
+    TORCH_CHECK(kn.dtype() == q.dtype() && vn.dtype() == q.dtype(), "Key and value must have the same dtype as query");
+    CHECK_DEVICE(kn); CHECK_DEVICE(vn); CHECK_LAST_CONTIG(kn); CHECK_LAST_CONTIG(vn);
+    s_new = kn.size(1);
+    CHECK_SHAPE(kn, B, s_new, Hk, D); CHECK_SHAPE(vn, B, s_new, Hk, D);
+    FaKvAppendParams ap{};
+    ap.knew = kn.data_ptr(); ap.vnew = vn.data_ptr(); ap.kcache = kcache.data_ptr(); ap.vcache = vcache.data_ptr();
+    ap.knew_batch_stride = kn.stride(0); ap.knew_row_stride = kn.stride(1); ap.knew_head_stride = kn.stride(2);
+    ap.vnew_batch_stride = vn.stride(0); ap.vnew_row_stride = vn.stride(1); ap.vnew_head_stride = vn.stride(2);
+    ap.kcache_batch_stride = kcache.stride(0); ap.kcache_row_stride = kcache.stride(1); ap.kcache_head_stride = kcache.stride(2);
+    ap.vcache_batch_stride = vcache.stride(0); ap.vcache_row_stride = vcache.stride(1); ap.vcache_head_stride = vcache.stride(2);
+    ap.seqlens_k = seqlens_k_->data_ptr<int>();
+    ap.cache_batch_idx = cache_batch_idx_.has_value() ? cache_batch_idx_->data_ptr<int>() : nullptr;
+    ap.block_table = paged ? block_table_->data_ptr<int>() : nullptr;
+    ap.block_table_batch_stride = paged ? block_table_->stride(0) : 0;
+    ap.page_block_size = (int)page;
+    ap.b = B; ap.seqlen_new = (int)s_new; ap.h_k = Hk; ap.d = D; ap.dtype = dtype_code(q);
+    fa_check(fa_kvcache_append(&ap, cur_stream(q)));
+  }
+
+  // Decode trick of the reference (flash_api.cpp:1346-1353): with one query row the query heads of a KV group
+  // become the rows of the score matrix, so K/V are streamed once per KV head.
+  const bool swap = Sq == 1 && H > Hk && window_size_left < 0 && !alibi_slopes_.has_value();
+  const int64_t ratio = H / Hk;
+  Tensor qk = swap ? q.reshape({B, Hk, ratio, D}).transpose(1, 2) : q;  // (B, rows, heads, D)
+  const int64_t rows = swap ? ratio : Sq, heads = swap ? Hk : H;
+  Tensor out;
+  if (out_.has_value() && !swap) {
+    TORCH_CHECK(out_->dtype() == q.dtype(), "Output must have the same dtype as inputs");
+    CHECK_DEVICE(*out_); CHECK_LAST_CONTIG(*out_); CHECK_SHAPE(*out_, B, Sq, H, D);
+    out = *out_;
+  } else {
+    out = at::empty({B, rows, heads, D}, q.options());
+  }
+  Tensor lse = at::empty({B, heads, rows}, q.options().dtype(at::kFloat));
+  FaFwdParams a{};
+  a.q = qk.data_ptr(); a.k = kcache.data_ptr(); a.v = vcache.data_ptr(); a.o = out.data_ptr(); a.softmax_lse = lse.data_ptr<float>();
+  a.q_batch_stride = qk.stride(0); a.q_row_stride = qk.stride(1); a.q_head_stride = qk.stride(2);
+  a.k_batch_stride = kcache.stride(0); a.k_row_stride = kcache.stride(1); a.k_head_stride = kcache.stride(2);
+  a.v_batch_stride = vcache.stride(0); a.v_row_stride = vcache.stride(1); a.v_head_stride = vcache.stride(2);
+  a.o_batch_stride = out.stride(0); a.o_row_stride = out.stride(1); a.o_head_stride = out.stride(2);
+  a.seqused_k = seqlens_k_.has_value() ? seqlens_k_->data_ptr<int>() : nullptr;
+  a.seqused_k_add = (int)s_new;
+  a.cache_batch_idx = cache_batch_idx_.has_value() ? cache_batch_idx_->data_ptr<int>() : nullptr;
+  a.block_table = paged ? block_table_->data_ptr<int>() : nullptr;
+  a.block_table_batch_stride = paged ? block_table_->stride(0) : 0;
+  a.page_block_size = (int)page;
+  set_alibi(alibi_slopes_, B, H, a.alibi_slopes, a.alibi_batch_stride);
+  a.b = B; a.h = heads; a.h_k = Hk; a.d = D; a.seqlen_q = (int)rows; a.seqlen_k = (int)Sk; a.total_q = B * rows;
+  a.dtype = dtype_code(q);
+  a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
+  a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap;
+  fa_check(fa_fwd_kvcache(&a, cur_stream(q)));
+  if (swap) {
+    Tensor o2 = out.transpose(1, 2).reshape({B, 1, H, D});
+    if (out_.has_value()) { out_->copy_(o2); o2 = *out_; }
+    out = o2;
+    lse = lse.reshape({B, H, 1});
+  }
+  return {out, lse};
 }
 
 }  // namespace

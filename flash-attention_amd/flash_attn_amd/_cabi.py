@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-FA_ABI_VERSION = 1
+FA_ABI_VERSION = 2
 FA_DTYPE_FP16, FA_DTYPE_BF16 = 0, 1
 FA_OK, FA_ERR_INVALID_ARGUMENT, FA_ERR_UNSUPPORTED, FA_ERR_LAUNCH, FA_ERR_WORKSPACE = 0, -1, -2, -3, -4
 
@@ -29,8 +29,22 @@ class FaFwdParams(C.Structure):
         ("b", _i32), ("h", _i32), ("h_k", _i32), ("d", _i32),
         ("seqlen_q", _i32), ("seqlen_k", _i32), ("total_q", _i32), ("dtype", _i32),
         ("is_causal", _i32), ("window_left", _i32), ("window_right", _i32),
-        ("softmax_scale", _f32), ("softcap", _f32),
-        ("reserved", _i32 * 4),
+        ("softmax_scale", _f32), ("softcap", _f32), ("seqused_k_add", _i32),
+        ("cache_batch_idx", _vp), ("block_table", _vp), ("block_table_batch_stride", _i64),
+        ("page_block_size", _i32), ("reserved", _i32 * 3),
+    ]
+
+
+class FaKvAppendParams(C.Structure):
+    _fields_ = [
+        ("knew", _vp), ("vnew", _vp), ("kcache", _vp), ("vcache", _vp),
+        ("knew_batch_stride", _i64), ("knew_row_stride", _i64), ("knew_head_stride", _i64),
+        ("vnew_batch_stride", _i64), ("vnew_row_stride", _i64), ("vnew_head_stride", _i64),
+        ("kcache_batch_stride", _i64), ("kcache_row_stride", _i64), ("kcache_head_stride", _i64),
+        ("vcache_batch_stride", _i64), ("vcache_row_stride", _i64), ("vcache_head_stride", _i64),
+        ("seqlens_k", _vp), ("cache_batch_idx", _vp), ("block_table", _vp), ("block_table_batch_stride", _i64),
+        ("page_block_size", _i32), ("b", _i32), ("seqlen_new", _i32), ("h_k", _i32), ("d", _i32),
+        ("dtype", _i32), ("reserved", _i32 * 2),
     ]
 
 
@@ -58,8 +72,8 @@ class FaBwdParams(C.Structure):
 
 
 EXPORTS = (
-    "fa_abi_version", "fa_sizeof_fwd_params", "fa_sizeof_bwd_params", "fa_last_error",
-    "fa_fwd", "fa_varlen_fwd", "fa_bwd_workspace_bytes", "fa_bwd", "fa_varlen_bwd",
+    "fa_abi_version", "fa_sizeof_fwd_params", "fa_sizeof_bwd_params", "fa_sizeof_kvappend_params", "fa_last_error",
+    "fa_fwd", "fa_varlen_fwd", "fa_fwd_kvcache", "fa_kvcache_append", "fa_bwd_workspace_bytes", "fa_bwd", "fa_varlen_bwd",
 )
 
 _LIB = None
@@ -90,7 +104,10 @@ def load():
     lib.fa_sizeof_fwd_params.restype = C.c_int
     lib.fa_sizeof_bwd_params.restype = C.c_int
     lib.fa_last_error.restype = C.c_char_p
-    for fn in (lib.fa_fwd, lib.fa_varlen_fwd):
+    lib.fa_sizeof_kvappend_params.restype = C.c_int
+    lib.fa_kvcache_append.argtypes = [C.POINTER(FaKvAppendParams), C.c_void_p]
+    lib.fa_kvcache_append.restype = C.c_int
+    for fn in (lib.fa_fwd, lib.fa_varlen_fwd, lib.fa_fwd_kvcache):
         fn.argtypes = [C.POINTER(FaFwdParams), C.c_void_p]
         fn.restype = C.c_int
     for fn in (lib.fa_bwd, lib.fa_varlen_bwd):
@@ -100,7 +117,8 @@ def load():
     lib.fa_bwd_workspace_bytes.restype = C.c_int64
     if lib.fa_abi_version() != FA_ABI_VERSION:
         raise ImportError(f"{path}: ABI version {lib.fa_abi_version()} != binder {FA_ABI_VERSION}")
-    if lib.fa_sizeof_fwd_params() != C.sizeof(FaFwdParams) or lib.fa_sizeof_bwd_params() != C.sizeof(FaBwdParams):
+    if (lib.fa_sizeof_fwd_params() != C.sizeof(FaFwdParams) or lib.fa_sizeof_bwd_params() != C.sizeof(FaBwdParams)
+            or lib.fa_sizeof_kvappend_params() != C.sizeof(FaKvAppendParams)):
         raise ImportError(f"{path}: parameter-block size mismatch with the ctypes mirror")
     _LIB = lib
     return lib

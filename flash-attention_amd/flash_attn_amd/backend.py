@@ -325,6 +325,75 @@ def varlen_bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, cu_seqlens_q, cu_
     return [dq, dk, dv, delta]
 
 
-def fwd_kvcache(*args, **kwargs):
-    """mha_fwd_kvcache (flash_api.cpp:1243-1532): decode path, next row of the scope table."""
-    raise RuntimeError("libfa_gfx950: fwd_kvcache (split-KV decode / paged KV) is not built yet")
+def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_, cache_batch_idx_, leftpad_k_, block_table_,
+                alibi_slopes_, out_, softmax_scale, is_causal, window_size_left, window_size_right, softcap,
+                is_rotary_interleaved, num_splits) -> List[torch.Tensor]:
+    """mha_fwd_kvcache (flash_api.cpp:1243-1532) -> [out, softmax_lse].  Rotary and leftpad_k are not built."""
+    _check_dev(q, kcache, vcache, k_, v_, seqlens_k_, cache_batch_idx_, block_table_)
+    if not (q.dtype == kcache.dtype == vcache.dtype):
+        raise RuntimeError("query and key must have the same dtype")
+    if rotary_cos_ is not None or rotary_sin_ is not None:
+        raise RuntimeError("libfa_gfx950: rotary embedding in fwd_kvcache is not built")
+    if leftpad_k_ is not None:
+        raise RuntimeError("libfa_gfx950: leftpad_k is not built")
+    paged = block_table_ is not None
+    if paged and cache_batch_idx_ is not None:
+        raise RuntimeError("Paged KVcache does not support cache_batch_idx")
+    B, Sq, H, D = q.shape
+    Hk = kcache.shape[2]
+    page = kcache.shape[1] if paged else 0
+    Sk = block_table_.shape[1] * page if paged else kcache.shape[1]
+    if D not in _NATIVE_HEAD_DIMS:
+        raise RuntimeError("libfa_gfx950: fwd_kvcache is built for head dimensions 64 and 128")
+    if H % Hk != 0:
+        raise RuntimeError("Number of heads in key/value must divide number of heads in query")
+    if paged and page % 256 != 0:
+        raise RuntimeError("Paged KV cache block size must be divisible by 256")
+    if Sq == 1 and alibi_slopes_ is None:
+        is_causal = False
+    lib = _cabi.load()
+    s_new = 0
+    with torch.cuda.device(q.device):
+        if k_ is not None:
+            if v_ is None or seqlens_k_ is None:
+                raise RuntimeError("If key is supplied, value and seqlens_k must also be passed in")
+            s_new = k_.shape[1]
+            ap = _cabi.FaKvAppendParams()
+            ap.knew, ap.vnew, ap.kcache, ap.vcache = _ptr(k_), _ptr(v_), _ptr(kcache), _ptr(vcache)
+            for nm, t in (("knew", k_), ("vnew", v_), ("kcache", kcache), ("vcache", vcache)):
+                setattr(ap, nm + "_batch_stride", t.stride(0)); setattr(ap, nm + "_row_stride", t.stride(1)); setattr(ap, nm + "_head_stride", t.stride(2))
+            ap.seqlens_k, ap.cache_batch_idx = _ptr(seqlens_k_), _ptr(cache_batch_idx_)
+            ap.block_table, ap.block_table_batch_stride = _ptr(block_table_), (block_table_.stride(0) if paged else 0)
+            ap.page_block_size = page
+            ap.b, ap.seqlen_new, ap.h_k, ap.d, ap.dtype = B, s_new, Hk, D, _dtype_code(q)
+            _cabi.check(lib.fa_kvcache_append(C.byref(ap), C.c_void_p(_stream_ptr(q.device))))
+        swap = Sq == 1 and H > Hk and window_size_left < 0 and alibi_slopes_ is None
+        ratio = H // Hk
+        qk = q.reshape(B, Hk, ratio, D).transpose(1, 2) if swap else q
+        rows, heads = (ratio, Hk) if swap else (Sq, H)
+        out = out_ if (out_ is not None and not swap) else torch.empty((B, rows, heads, D), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, heads, rows), dtype=torch.float32, device=q.device)
+        alibi, alibi_bs = _alibi_args(alibi_slopes_, B, H)
+        a = _cabi.FaFwdParams()
+        a.q, a.k, a.v, a.o, a.softmax_lse = _ptr(qk), _ptr(kcache), _ptr(vcache), _ptr(out), _ptr(lse)
+        a.q_batch_stride, a.q_row_stride, a.q_head_stride = qk.stride(0), qk.stride(1), qk.stride(2)
+        a.k_batch_stride, a.k_row_stride, a.k_head_stride = kcache.stride(0), kcache.stride(1), kcache.stride(2)
+        a.v_batch_stride, a.v_row_stride, a.v_head_stride = vcache.stride(0), vcache.stride(1), vcache.stride(2)
+        a.o_batch_stride, a.o_row_stride, a.o_head_stride = out.stride(0), out.stride(1), out.stride(2)
+        a.seqused_k, a.seqused_k_add = _ptr(seqlens_k_), s_new
+        a.cache_batch_idx, a.block_table = _ptr(cache_batch_idx_), _ptr(block_table_)
+        a.block_table_batch_stride, a.page_block_size = (block_table_.stride(0) if paged else 0), page
+        a.alibi_slopes, a.alibi_batch_stride = _ptr(alibi), alibi_bs
+        a.b, a.h, a.h_k, a.d = B, heads, Hk, D
+        a.seqlen_q, a.seqlen_k, a.total_q = rows, Sk, B * rows
+        a.dtype = _dtype_code(q)
+        a.is_causal, a.window_left, a.window_right = int(bool(is_causal)), int(window_size_left), int(window_size_right)
+        a.softmax_scale, a.softcap = float(softmax_scale), float(softcap)
+        _cabi.check(lib.fa_fwd_kvcache(C.byref(a), C.c_void_p(_stream_ptr(q.device))))
+    if swap:
+        o2 = out.transpose(1, 2).reshape(B, 1, H, D)
+        if out_ is not None:
+            out_.copy_(o2)
+            o2 = out_
+        out, lse = o2, lse.reshape(B, H, 1)
+    return [out, lse]

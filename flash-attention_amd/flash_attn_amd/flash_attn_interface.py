@@ -197,6 +197,22 @@ def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
                                   return_attn_probs)
 
 
-def flash_attn_with_kvcache(*args, **kwargs):
-    """Decode path (reference :1485-1627): next row of the scope table, not built yet."""
-    return flash_attn_gpu.fwd_kvcache(*args, **kwargs)
+def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None, rotary_sin=None, cache_seqlens=None,
+                            cache_batch_idx=None, cache_leftpad=None, block_table=None, softmax_scale=None, causal=False,
+                            window_size=(-1, -1), softcap=0.0, rotary_interleaved=True, alibi_slopes=None, num_splits=0,
+                            return_softmax_lse=False):
+    """Inference attention against a KV cache (reference :1485-1627).  If k / v are given they are written into the
+    cache in place at rows ``cache_seqlens[b] ..`` before attending; ``cache_seqlens`` may be an int or an int32
+    tensor (batch,); ``cache_batch_idx`` selects cache rows; ``block_table`` selects pages of a paged cache
+    (num_blocks, page, Hk, D).  Rotary embedding and ``cache_leftpad`` are not built yet (RuntimeError).  No backward."""
+    q, k, v = (_unit_stride_last(t) for t in (q, k, v))
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** (-0.5)
+    if cache_seqlens is not None and isinstance(cache_seqlens, int):
+        cache_seqlens = torch.full((q.shape[0],), cache_seqlens, dtype=torch.int32, device=k_cache.device)
+    out, lse = flash_attn_gpu.fwd_kvcache(
+        q, k_cache, v_cache, k, v, cache_seqlens, rotary_cos, rotary_sin,
+        None if cache_batch_idx is None else cache_batch_idx.contiguous(), cache_leftpad,
+        None if block_table is None else _unit_stride_last(block_table), alibi_slopes, None, softmax_scale, causal,
+        window_size[0], window_size[1], softcap, rotary_interleaved, num_splits)
+    return (out, lse) if return_softmax_lse else out

@@ -9,6 +9,7 @@
  *   fa_varlen_fwd  <->  mha_varlen_fwd  csrc/flash_attn/flash_api.cpp:538-788   (pybind "varlen_fwd", :1538)
  *   fa_bwd         <->  mha_bwd         csrc/flash_attn/flash_api.cpp:800-1008  (pybind "bwd",        :1539)
  *   fa_varlen_bwd  <->  mha_varlen_bwd  csrc/flash_attn/flash_api.cpp:1010-1241 (pybind "varlen_bwd", :1540)
+ *   fa_kvcache_append + fa_fwd_kvcache  <->  mha_fwd_kvcache  csrc/flash_attn/flash_api.cpp:1243-1532 (pybind "fwd_kvcache", :1541)
  *
  * The two parameter blocks below are this library's counterpart of the reference's kernel POD
  * `Flash_fwd_params` / `Flash_bwd_params` (csrc/flash_attn/src/flash.h:47-189).  The caller owns
@@ -38,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 1
+#define FA_ABI_VERSION 2
 
 enum { FA_DTYPE_FP16 = 0, FA_DTYPE_BF16 = 1 };
 
@@ -73,8 +74,35 @@ typedef struct FaFwdParams {
   int32_t window_left, window_right;
   float softmax_scale;
   float softcap;                /* 0 = off                              */
-  int32_t reserved[4];
+  int32_t seqused_k_add;        /* added to seqused_k[b] (keys appended in the same call)            */
+  /* KV-cache extensions (fa_fwd_kvcache only; NULL / 0 otherwise) */
+  const int32_t* cache_batch_idx;   /* optional (B): batch entry -> row of the cache                 */
+  const int32_t* block_table;       /* optional (B, max_blocks) int32: paged cache, k/v are (num_blocks, page, Hk, D) */
+  int64_t block_table_batch_stride;
+  int32_t page_block_size;          /* keys per page, multiple of 256 (reference flash_api.cpp:1318)  */
+  int32_t reserved[3];
 } FaFwdParams;
+
+/* Append step of the KV-cache path: copy knew/vnew (B, S_new, Hk, D) into the cache at rows
+ * seqlens_k[b] .. seqlens_k[b]+S_new-1 of cache row cache_batch_idx[b] (or page-table addressed). */
+typedef struct FaKvAppendParams {
+  const void* knew;
+  const void* vnew;
+  void* kcache;
+  void* vcache;
+  int64_t knew_batch_stride, knew_row_stride, knew_head_stride;
+  int64_t vnew_batch_stride, vnew_row_stride, vnew_head_stride;
+  int64_t kcache_batch_stride, kcache_row_stride, kcache_head_stride;
+  int64_t vcache_batch_stride, vcache_row_stride, vcache_head_stride;
+  const int32_t* seqlens_k;         /* (B) current lengths; NULL => append at row 0                  */
+  const int32_t* cache_batch_idx;   /* optional                                                       */
+  const int32_t* block_table;       /* optional (paged cache)                                         */
+  int64_t block_table_batch_stride;
+  int32_t page_block_size;
+  int32_t b, seqlen_new, h_k, d;
+  int32_t dtype;
+  int32_t reserved[2];
+} FaKvAppendParams;
 
 typedef struct FaBwdParams {
   const void* dout;
@@ -118,6 +146,7 @@ int fa_abi_version(void);
 /* sizeof() of the two parameter blocks as the library sees them (binder self-check). */
 int fa_sizeof_fwd_params(void);
 int fa_sizeof_bwd_params(void);
+int fa_sizeof_kvappend_params(void);
 /* Last error message of the calling thread ("" if none). */
 const char* fa_last_error(void);
 
@@ -125,6 +154,11 @@ const char* fa_last_error(void);
 int fa_fwd(const FaFwdParams* params, void* stream);
 /* Forward, packed variable-length batch.  cu_seqlens_q/k must be non-NULL device int32 (b+1). */
 int fa_varlen_fwd(const FaFwdParams* params, void* stream);
+/* Inference forward against a KV cache: fa_fwd plus seqused_k (cache_seqlens), cache_batch_idx and/or a
+ * paged cache (block_table).  k/v point at the cache.  No backward. */
+int fa_fwd_kvcache(const FaFwdParams* params, void* stream);
+/* Writes the new keys/values into the cache (call before fa_fwd_kvcache with seqused_k_add = seqlen_new). */
+int fa_kvcache_append(const FaKvAppendParams* params, void* stream);
 /* Bytes of scratch the backward needs for this problem (0 is possible). */
 int64_t fa_bwd_workspace_bytes(const FaBwdParams* params);
 /* Backward, fixed-length batch: writes dq, dk, dv (caller-allocated) and softmax_d. */

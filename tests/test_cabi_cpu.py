@@ -40,7 +40,8 @@ def test_library_exports_every_declared_symbol(built):
 def test_ctypes_mirror_matches_c_structs(built):
     from flash_attn_amd import _cabi
     lib = _cabi.load()
-    assert lib.fa_abi_version() == _cabi.FA_ABI_VERSION == 1
+    assert lib.fa_abi_version() == _cabi.FA_ABI_VERSION == 2
+    assert lib.fa_sizeof_kvappend_params() == ctypes.sizeof(_cabi.FaKvAppendParams)
     assert lib.fa_sizeof_fwd_params() == ctypes.sizeof(_cabi.FaFwdParams)
     assert lib.fa_sizeof_bwd_params() == ctypes.sizeof(_cabi.FaBwdParams)
 
@@ -71,8 +72,8 @@ def test_torch_extension_is_the_reference_backend_module(built):
         m.fwd(q, q, q, None, None, 0.0, 0.125, False, -1, -1, 0.0, False, None)
     with pytest.raises(RuntimeError, match="generator"):
         m.fwd(q, q, q, None, None, 0.0, 0.125, False, -1, -1, 0.0, False, torch.Generator())
-    with pytest.raises(RuntimeError, match="kvcache"):
-        m.fwd_kvcache()
+    with pytest.raises(RuntimeError, match="CUDA"):
+        m.fwd_kvcache(q, q, q, None, None, None, None, None, None, None, None, None, None, 0.125, False, -1, -1, 0.0, True, 0)
     assert os.path.dirname(m.__file__) == PKG  # in-tree build, not site-packages
 
 

@@ -1,0 +1,98 @@
+"""GPU parity tests of the KV-cache inference path (fwd_kvcache): contiguous / batch-indexed / paged caches,
+in-place append, decode (one query row, GQA head packing) and chunked prefill, against the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests._util import max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["ext", "ctypes"])
+def kv(request):
+    if request.param == "ext":
+        import flash_attn_2_cuda as m
+    else:
+        from flash_attn_amd import backend as m
+    return m
+
+
+def _oracle(q, kc, vc, lens, causal, window=(-1, -1)):
+    from oracle import attention_oracle as orc
+    outs, lses = [], []
+    for b in range(q.shape[0]):
+        L = int(lens[b])
+        o, l = orc.attention_fwd(q[b:b + 1], kc[b:b + 1, :L], vc[b:b + 1, :L], None, causal, window)
+        outs.append(o); lses.append(l)
+    return np.concatenate(outs), np.concatenate(lses)
+
+
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("sq,causal", [(1, False), (1, True), (5, True), (77, True), (300, False)])
+@pytest.mark.parametrize("hk", [1, 2, 8])
+def test_kvcache_contiguous_with_append_and_batch_idx(kv, d, sq, causal, hk):
+    torch.manual_seed(0)
+    B, H, Scache, Bc, snew = 3, 8, 700, 5, sq
+    q = torch.randn(B, sq, H, d, device="cuda", dtype=torch.bfloat16)
+    kc = torch.randn(Bc, Scache, hk, d, device="cuda", dtype=torch.bfloat16)
+    vc = torch.randn(Bc, Scache, hk, d, device="cuda", dtype=torch.bfloat16)
+    kn = torch.randn(B, snew, hk, d, device="cuda", dtype=torch.bfloat16)
+    vn = torch.randn(B, snew, hk, d, device="cuda", dtype=torch.bfloat16)
+    lens = torch.tensor([0, 333, 700 - snew], dtype=torch.int32, device="cuda")
+    idx = torch.tensor([4, 0, 2], dtype=torch.int32, device="cuda")
+    kc0, vc0 = kc.clone(), vc.clone()
+    out, lse = kv.fwd_kvcache(q, kc, vc, kn, vn, lens, None, None, idx, None, None, None, None, d ** -0.5, causal, -1, -1, 0.0, True, 0)
+    # the cache was updated in place at the right rows, and nowhere else
+    for b in range(B):
+        r, L = int(idx[b]), int(lens[b])
+        assert torch.equal(kc[r, L:L + snew], kn[b]) and torch.equal(vc[r, L:L + snew], vn[b])
+        assert torch.equal(kc[r, :L], kc0[r, :L]) and torch.equal(kc[r, L + snew:], kc0[r, L + snew:])
+    for r in (1, 3):
+        assert torch.equal(kc[r], kc0[r]) and torch.equal(vc[r], vc0[r])
+    o_ref, l_ref = _oracle(q, kc[idx.long()], vc[idx.long()], (lens + snew).cpu().numpy(), causal)
+    assert out.shape == q.shape and lse.shape == (B, H, sq)
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 2e-2
+    assert max_abs(lse.cpu(), torch.from_numpy(l_ref).float()) < 2e-3
+
+
+@pytest.mark.parametrize("sq,causal", [(1, False), (64, True)])
+def test_kvcache_paged(kv, sq, causal):
+    torch.manual_seed(1)
+    B, H, hk, d, page, nblk_per = 4, 8, 2, 128, 256, 3
+    num_blocks = B * nblk_per + 2
+    kp = torch.randn(num_blocks, page, hk, d, device="cuda", dtype=torch.bfloat16)
+    vp = torch.randn(num_blocks, page, hk, d, device="cuda", dtype=torch.bfloat16)
+    perm = torch.randperm(num_blocks, device="cuda")[: B * nblk_per].reshape(B, nblk_per).to(torch.int32)
+    lens = torch.tensor([1, 256, 300, 768 - sq], dtype=torch.int32, device="cuda")
+    q = torch.randn(B, sq, H, d, device="cuda", dtype=torch.bfloat16)
+    kn = torch.randn(B, sq, hk, d, device="cuda", dtype=torch.bfloat16)
+    vn = torch.randn(B, sq, hk, d, device="cuda", dtype=torch.bfloat16)
+    out, lse = kv.fwd_kvcache(q, kp, vp, kn, vn, lens, None, None, None, None, perm, None, None, d ** -0.5, causal, -1, -1, 0.0, True, 0)
+    # gather the logical caches back from the pages
+    kc = kp[perm.long()].reshape(B, nblk_per * page, hk, d)
+    vc = vp[perm.long()].reshape(B, nblk_per * page, hk, d)
+    for b in range(B):
+        L = int(lens[b])
+        assert torch.equal(kc[b, L:L + sq], kn[b]) and torch.equal(vc[b, L:L + sq], vn[b])
+    o_ref, l_ref = _oracle(q, kc, vc, (lens + sq).cpu().numpy(), causal)
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 2e-2
+    assert max_abs(lse.cpu(), torch.from_numpy(l_ref).float()) < 2e-3
+
+
+def test_kvcache_interface_and_errors():
+    from flash_attn_amd import flash_attn_interface as fi
+    torch.manual_seed(2)
+    q = torch.randn(2, 1, 8, 128, device="cuda", dtype=torch.float16)
+    kc = torch.randn(2, 512, 2, 128, device="cuda", dtype=torch.float16)
+    vc = torch.randn_like(kc)
+    out, lse = fi.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=300, return_softmax_lse=True)
+    o_ref, l_ref = _oracle(q, kc, vc, [300, 300], False)
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 5e-3 and max_abs(lse.cpu(), torch.from_numpy(l_ref).float()) < 2e-3
+    out_w = fi.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=300, window_size=(100, 0))
+    ow_ref, _ = _oracle(q, kc, vc, [300, 300], False, (100, 0))
+    assert max_abs(out_w.float().cpu(), torch.from_numpy(ow_ref)) < 5e-3
+    with pytest.raises(RuntimeError, match="rotary"):
+        fi.flash_attn_with_kvcache(q, kc, vc, rotary_cos=torch.zeros(8, 16, device="cuda"), rotary_sin=torch.zeros(8, 16, device="cuda"))
+    with pytest.raises(RuntimeError, match="divisible by 256"):
+        fi.flash_attn_with_kvcache(q, kc[:, :128].contiguous(), vc[:, :128].contiguous(), block_table=torch.zeros(2, 1, dtype=torch.int32, device="cuda"))
