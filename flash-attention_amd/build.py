@@ -58,7 +58,7 @@ def build_lib(force=False):
         src = os.path.join(CSRC, u)
         obj = os.path.join(CSRC, os.path.splitext(u)[0] + ".o")
         if force or not _newer(obj, [src] + hdrs):
-            cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("FA_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
             if u.endswith(".cpp"):
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")

@@ -11,8 +11,8 @@
 //    ~65 VALU     P_i = exp2(S_i*c - m*c), row sums, row max of S_{i+1}, bf16 packing of P_i
 // i.e. ~4 VALU per MFMA with no dependence between the three strands inside a step.
 // Online-softmax bookkeeping is arranged so the only data-dependent branch (rescale when a row maximum grew
-// by more than `rescale_thr`) sits at the step boundary and rescales everything still at the old scale
-// exactly once: O (all of P_{<i}), l (including P_i's row sum) and P_i itself while it is still fp32.
+// by more than `rescale_thr`) sits at the step boundary, moves m and rescales l there, and rescales O one
+// step later (after P_i.V, computed at the old scale, has been added), so it never touches the packed P_i.
 //
 // One iteration of the tile loop = two steps = one 64-key K tile and the previous V tile, double-buffered
 // in LDS exactly as in the lock-step kernel (64 KB), one barrier per iteration.
@@ -39,6 +39,7 @@ template <int N> using ICi = std::integral_constant<int, N>;
 
 template <typename E, int D, int NW, int SCHED>
 __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
+  // SCHED = operand-read lead (MFMA slots) of the hand-placed steady-state step; 0 = compiler-ordered step
   constexpr int sched_mode = SCHED;
   constexpr bool QLDS = (NW == 8);  // 8 waves: Q block in LDS (1 workgroup/CU); 4 waves: Q fragments in registers (2 workgroups/CU)
   using T = ElemTraits<E>;
@@ -201,6 +202,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  float o_lag = 1.f;   // factor O still has to be multiplied by (applied one step after the decision)
   f32x16 sA, sB;       // scores of the current / next step (roles swap every step)
   V8 pfA[2], pfB[2];   // packed P of the previous / current step
 #pragma unroll
@@ -264,8 +266,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
       s[r] = ((off <= rel_hi) && (off >= rel_lo)) ? s[r] : -INFINITY;
     }
   };
-  // Row max of the NEXT step's scores and the rescale decision.  Everything still at the old scale is
-  // rescaled here exactly once: O, l and (if do_pend) the pending fp32 probabilities of this step.
+  // Row max of the NEXT step's scores and the rescale decision.
   auto row_max_grow = [&](const f32x16& s_nxt, float& m_new) __attribute__((always_inline)) {
     float tmax = fmaxf(fmaxf(s_nxt[0], s_nxt[1]), s_nxt[2]);
 #pragma unroll
@@ -275,7 +276,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     m_new = fmaxf(m_run, tmax);
     return (m_new - m_run) * cs > thr;
   };
-  auto rescale = [&](bool grow, float m_new, f32x16& pend, bool do_pend) __attribute__((always_inline)) {
+  // The decision taken at the end of step i (max of S_{i+1} grew by more than thr) moves m and rescales l
+  // at once; P_i was already computed (and packed) at the old scale, so O is multiplied one step later, after
+  // the product P_i.V has been accumulated at the old scale.  The branch therefore never touches P.
+  auto rescale = [&](bool grow, float m_new) __attribute__((always_inline)) {
     const float m_upd = grow ? m_new : m_run;
     const float m_safe = (m_upd == -INFINITY) ? 0.f : m_upd;
     const float alpha = grow ? fast_exp2((m_run - m_safe) * cs) : 1.f;
@@ -284,12 +288,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
-    if (do_pend) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pend[r] *= alpha;
-    }
+      for (int r = 0; r < 16; ++r) o_acc[db][r] *= o_lag;
+    o_lag = alpha;
   };
+  auto need_rescale = [&](bool grow) __attribute__((always_inline)) { return grow || o_lag != 1.f; };
 
   int qa[KS];  // loop-invariant Q fragment addresses
 #pragma unroll
@@ -351,6 +353,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 #if FA_ABL == 1
         const float p0 = s_cur[r] * cs, p1 = s_cur[r + 1] * cs;
 #else
+        // (v_pk_fma_f32 for the scale/subtract pair measured 5 % slower than two v_fma_f32)
         const float p0 = fast_exp2(__builtin_fmaf(s_cur[r], cs, neg_mc));
         const float p1 = fast_exp2(__builtin_fmaf(s_cur[r + 1], cs, neg_mc));
 #endif
@@ -386,6 +389,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
           }
         }
       }
+      if (g < 2) {  // P_i is final once its exponentials are done: pack it under the first PV slots
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) pf_cur[g][jj] = (E)s_cur[8 * g + jj];
+      }
       if (FA_ABL != 6 && g >= (MASK ? 3 : 2)) {  // row-max tree, spread over the remaining slots (2 values per max3)
         constexpr int G0 = MASK ? 3 : 2;
         constexpr int SLOTS = NOP - G0;
@@ -401,11 +408,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     tmax = half_max(tmax);
     const float m_new = fmaxf(m_run, tmax);
     const bool grow = (m_new - m_run) * cs > thr;
-    if (__any(grow)) rescale(grow, m_new, s_cur, true);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) pf_cur[t][jj] = (E)s_cur[8 * t + jj];
+    if (__any(need_rescale(grow))) rescale(grow, m_new);
   };
 
   // One pipeline step.  s_cur: scores of step i (masked, decision already taken) -> becomes P_i in place;
@@ -433,11 +436,14 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
       l_run += ps0 + ps1;
     }
     if (do_pv) pv_half(pf_prev, vb_lane, halfc);
-    if (do_qk) {
-      if (!FAST && step_needs_mask(i + 1)) apply_mask(s_nxt, i + 1);
-      float m_new;
-      const bool grow = row_max_grow(s_nxt, m_new);
-      if (__any(grow)) rescale(grow, m_new, s_cur, do_sm);
+    {
+      float m_new = m_run;
+      bool grow = false;
+      if (do_qk) {
+        if (!FAST && step_needs_mask(i + 1)) apply_mask(s_nxt, i + 1);
+        grow = row_max_grow(s_nxt, m_new);
+      }
+      if (__any(need_rescale(grow))) rescale(grow, m_new);
     }
     if (do_sm) {
 #pragma unroll
@@ -478,8 +484,14 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     if (u < n_tiles) dma_tile(ICi<1>{}, par, u);
   };
   auto iter_tail = [&]() __attribute__((always_inline)) {
+#if FA_ABL == 7
+    lds_dma_wait_all();
+#elif FA_ABL == 8
+    __syncthreads();
+#elif FA_ABL != 9
     lds_dma_wait_all();  // this wave's DMA pieces have landed ...
     __syncthreads();     // ... and everybody's are visible before the next iteration reads them
+#endif
   };
   if (n_tiles > 0) {
     int u = 0;
@@ -536,6 +548,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   }
 
   if (!wave_valid) return;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)  // a factor decided but not yet applied (1 unless the last scored step moved the maximum)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[db][r] *= o_lag;
   const float l_tot = half_sum(l_run);
   const bool dead = (l_tot == 0.f) || (l_tot != l_tot);
   const float inv = dead ? 1.f : 1.f / l_tot;
@@ -567,19 +583,28 @@ static int launch_fwd_il_t(const FwdK& p, hipStream_t stream) {
   }
   const long long total = units_grid(p.n_units, p.unit_size);
   if (total <= 0) return 0;
+#ifdef FA_IL_EXPERIMENTS  // occupancy experiments: extra (unused) dynamic LDS
+  if (const char* e = getenv("FA_IL_LDS_PAD")) {
+    const int padded = smem + atoi(e);
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), padded, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // nw = 4 or 8 waves per workgroup (query block = 32*nw rows)
 int launch_fwd_il(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream) {
-  // FA_IL_SCHED=0: compiler-ordered steady-state step; default: hand-placed slots, operand reads 4 slots ahead
-  static const int sched = [] { const char* e = getenv("FA_IL_SCHED"); return e ? atoi(e) : 4; }();
+  // FA_IL_SCHED=0: compiler-ordered steady-state step; default: hand-placed slots, operand reads 3 slots ahead
+  const char* sched_env = getenv("FA_IL_SCHED");
+  const int sched = sched_env ? atoi(sched_env) : 3;
   if ((uint64_t)64 * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 31)) return -2;
   if (p.softcap > 0.f || p.alibi != nullptr) return -2;
 #define FA_IL_CASE(E_, D_, NW_)                                                                       \
   if (d == D_ && nw == NW_)                                                                           \
-    return sched == 0 ? launch_fwd_il_t<E_, D_, NW_, 0>(p, stream) : launch_fwd_il_t<E_, D_, NW_, 4>(p, stream);
+    return sched == 0 ? launch_fwd_il_t<E_, D_, NW_, 0>(p, stream) : launch_fwd_il_t<E_, D_, NW_, 3>(p, stream);
   if (dtype_bf16) {
     FA_IL_CASE(__bf16, 128, 8) FA_IL_CASE(__bf16, 128, 4) FA_IL_CASE(__bf16, 64, 8) FA_IL_CASE(__bf16, 64, 4)
   } else {

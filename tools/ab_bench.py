@@ -27,9 +27,17 @@ def main():
         res = {x: [] for x in variants}
         f = lambda: be.fwd(q, k, v, None, None, 0.0, D ** -0.5, causal, -1, -1, 0.0, False, None)
         def setv(x):
-            nw, _, thr = x.partition(":")
-            os.environ["FA_FWD_NW"] = nw
-            os.environ["FA_RESCALE_THR"] = thr or "0"
+            parts = x.split(":") + ["", "", ""]
+            if parts[3]:
+                os.environ["FA_IL_LDS_PAD"] = parts[3]
+            else:
+                os.environ.pop("FA_IL_LDS_PAD", None)
+            os.environ["FA_FWD_NW"] = parts[0]
+            os.environ["FA_RESCALE_THR"] = parts[1] or "0"
+            if parts[2]:
+                os.environ["FA_IL_SCHED"] = parts[2]
+            else:
+                os.environ.pop("FA_IL_SCHED", None)
         for x in variants:
             setv(x); f()
         for _ in range(5):
