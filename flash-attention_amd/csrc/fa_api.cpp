@@ -48,6 +48,21 @@ void normalize_window(int seqlen_q, int seqlen_k, bool has_alibi, int& is_causal
   if (wr < 0) wr = -1;
 }
 
+// dropout fields shared by the forward and backward parameter blocks
+int check_dropout(float p_dropout, const void* rng_state) {
+  if (!(p_dropout >= 0.f) || p_dropout >= 1.f) return fail(FA_ERR_INVALID_ARGUMENT, "p_dropout must be in [0, 1)");
+  if (p_dropout > 0.f && !rng_state) return fail(FA_ERR_INVALID_ARGUMENT, "p_dropout > 0 needs a device rng_state {seed, offset}");
+  return FA_OK;
+}
+template <typename K> void fill_dropout(K& k, float p_dropout, const uint64_t* rng_state, int seqlen_k) {
+  if (p_dropout > 0.f) {
+    k.rng = rng_state;
+    k.drop_thr8 = (uint32_t)std::floor(255.0 * (1.0 - (double)p_dropout));  // csrc/flash_attn_ck convention (uint8 threshold)
+    k.drop_groups = (seqlen_k + 3) / 4;
+    k.rp_keep = 1.f / (1.f - p_dropout);
+  }
+}
+
 int check_common(int b, int h, int h_k, int d, int dtype, float softcap) {
   if (b <= 0) return fail(FA_ERR_INVALID_ARGUMENT, "batch size must be positive");
   if (h <= 0 || h_k <= 0 || h % h_k != 0)
@@ -79,6 +94,10 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     if (a->page_block_size <= 0 || a->page_block_size % 256 != 0)
       return fail(FA_ERR_INVALID_ARGUMENT, "Paged KV cache block size must be divisible by 256");
   }
+  if (int rc = check_dropout(a->p_dropout, a->rng_state)) return rc;
+  if (kvcache && a->p_dropout > 0.f) return fail(FA_ERR_INVALID_ARGUMENT, "fa_fwd_kvcache is an inference path: p_dropout must be 0");
+  if (a->randval && !(a->p_dropout > 0.f)) return fail(FA_ERR_INVALID_ARGUMENT, "return_softmax is only supported when p_dropout > 0.0");
+  if (a->num_splits > 1) return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: num_splits > 1 is not built yet");
   if (a->seqlen_q == 0 || a->total_q == 0) return FA_OK;  // nothing to write
 
   fa::FwdK k{};
@@ -99,6 +118,8 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   k.scale = a->softmax_scale;
   k.scale_log2 = a->softmax_scale * 1.4426950408889634f;
   k.softcap = a->softcap;
+  fill_dropout(k, a->p_dropout, a->rng_state, a->seqlen_k);
+  if (a->p_dropout > 0.f) { k.randval = a->randval; k.rv_bs = a->randval_batch_stride; k.rv_hs = a->randval_head_stride; k.rv_rs = a->randval_row_stride; }
   // Deferred O rescale: the running max only moves when a row's max grew by more than this many log2
   // units (P stays <= 2^thr; fp32 accumulators and the relative precision of bf16/fp16 P are unaffected).
   // 0 reproduces the reference's rescale-on-any-growth rule exactly.  Default 8 (measured +4..10 %,
@@ -126,7 +147,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     else nw = (a->seqlen_q > 128) ? 34 : 4;
   }
   // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
-  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes;
+  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f);
   const bool il = (nw == 34 || nw == 38) && plain;
   if ((nw == 34 || nw == 38) && !il) nw -= 30;
   const int bm = il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
@@ -169,6 +190,8 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   k.scale = a->softmax_scale;
   k.scale_log2 = a->softmax_scale * 1.4426950408889634f;
   k.softcap = a->softcap;
+  if (int rc = check_dropout(a->p_dropout, a->rng_state)) return rc;
+  fill_dropout(k, a->p_dropout, a->rng_state, a->seqlen_k);
   k.nmb = (a->seqlen_q + fa::bwd_block_m() - 1) / fa::bwd_block_m();
   k.nnb = (a->seqlen_k + fa::bwd_block_n() - 1) / fa::bwd_block_n();
   fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb, k.q_units, k.q_unit_size, k.q_unit_hpx);
@@ -226,6 +249,19 @@ int fa_kvcache_append(const FaKvAppendParams* a, void* stream) {
   if (fa::launch_kv_append(k, (hipStream_t)stream) != 0)
     return fail(FA_ERR_LAUNCH, "kv append launch failed: %s", hipGetErrorString(hipGetLastError()));
   return FA_OK;
+}
+
+int fa_set_rng_state(uint64_t seed, uint64_t offset, uint64_t* rng_state, void* stream) {
+  g_err[0] = 0;
+  if (!rng_state) return fail(FA_ERR_INVALID_ARGUMENT, "rng_state is NULL");
+  if (fa::launch_set_rng(seed, offset, rng_state, (hipStream_t)stream) != 0)
+    return fail(FA_ERR_LAUNCH, "rng_state launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return FA_OK;
+}
+
+int64_t fa_fwd_workspace_bytes(const FaFwdParams* params) {
+  (void)params;
+  return 0;  // no split-KV schedule is built yet (num_splits <= 1)
 }
 
 int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {

@@ -233,6 +233,9 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
     if (has_next) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
     const int m0 = item_m0(it);
     const float slope = (XFORM && p.alibi) ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
+    const bool drop = XFORM && (p.rng != nullptr);
+    // stream key of this (batch, query head) plus this lane's key group; rows are added per 4-query group below
+    const uint32_t drop_col = drop ? (drop_bh_key(p.rng, b * p.h + item_head(it)) + (uint32_t)(my_key >> 2)) : 0u;
     const char FA_LDS* qbuf = lds + OFF_Q + cur * QT_BYTES;
     const char FA_LDS* dobuf = lds + OFF_DO + cur * QT_BYTES;
 
@@ -298,13 +301,28 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
         const int qoff = (cur * 2 * BMQ + qb * 32 + 8 * g + 4 * hi) * 4;
         const f32x4 l4 = *(const f32x4 FA_LDS*)(lds + OFF_AUX + qoff);
         const f32x4 d4 = *(const f32x4 FA_LDS*)(lds + OFF_AUX + BMQ * 4 + qoff);
+        // Dropout: the 4 lanes of a quad hold the 4 keys of one key group; lane a hashes query row a of this 4-row
+        // group (4 bytes = those 4 keys) and the quad exchanges words, so each lane reads its key's byte of every row.
+        uint32_t hq = 0u;
+        if constexpr (XFORM) {
+          if (drop) hq = hash32(drop_col + (uint32_t)(q0 + 8 * g + 4 * hi + (ki & 3)) * (uint32_t)p.drop_groups);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           const float pv = fast_exp2(__builtin_fmaf(s[r], cs, -l4[j]));
-          float dsv = pv * (dp[r] - d4[j]);
+          float pkeep = pv, dpe = dp[r];
+          if constexpr (XFORM) {
+            if (drop) {  // Z = keep / (1 - p): dV uses P*Z (the 1/(1-p) is applied to dV at the end), dS = P*(dP*Z - delta)
+              const uint32_t hj = quad_bcast(hq, j);
+              const bool keep = ((hj >> (8 * (ki & 3))) & 0xffu) <= p.drop_thr8;
+              pkeep = keep ? pv : 0.f;
+              dpe = keep ? dp[r] * p.rp_keep : 0.f;
+            }
+          }
+          float dsv = pv * (dpe - d4[j]);
           if constexpr (XFORM) dsv *= dcap[r];
-          pfrag[r >> 3][r & 7] = (E)pv;
+          pfrag[r >> 3][r & 7] = (E)pkeep;
           dsfrag[r >> 3][r & 7] = (E)dsv;
         }
       }
@@ -332,6 +350,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
 
   // ---- epilogue: dK = scale * acc, dV = acc; every key row of the block is written (zeros included) --
   if (!key_valid) return;
+  const float dv_scale = (XFORM && p.rng) ? p.rp_keep : 1.f;
   E* dkrow = (E*)p.dk + dk_boff + (k_row0 + my_key) * p.dk_rs + (int64_t)hk * p.dk_hs;
   E* dvrow = (E*)p.dv + dv_boff + (k_row0 + my_key) * p.dv_rs + (int64_t)hk * p.dv_hs;
 #pragma unroll
@@ -342,7 +361,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         a[j] = (E)(dk_acc[db][4 * g + j] * p.scale);
-        c[j] = (E)(dv_acc[db][4 * g + j]);
+        c[j] = (E)(dv_acc[db][4 * g + j] * dv_scale);
       }
       *reinterpret_cast<V4*>(dkrow + 32 * db + 8 * g + 4 * hi) = a;
       *reinterpret_cast<V4*>(dvrow + 32 * db + 8 * g + 4 * hi) = c;
@@ -410,6 +429,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_bwd_dq_kernel(const BwdK p) {
 
   const float cs = XFORM ? kLog2e : p.scale_log2;
   const float slope = (XFORM && p.alibi) ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
+  const bool drop = XFORM && (p.rng != nullptr);
+  const uint32_t drop_row = drop ? (drop_bh_key(p.rng, b * p.h + h) + (uint32_t)my_row * (uint32_t)p.drop_groups) : 0u;
 
   // Q and dO fragments (B operands), LSE and delta (lane-local scalars)
   V8 qf[KS], dof[KS];
@@ -525,7 +546,15 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_bwd_dq_kernel(const BwdK p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pv = fast_exp2(__builtin_fmaf(s[r], cs, -lse_l));
-          float dsv = pv * (dp[r] - delta_l);
+          float dpe = dp[r];
+          if constexpr (XFORM) {
+            if (drop) {  // acc rows 4g..4g+3 are keys key0..key0+3: one hash per group, byte r&3
+              const int key0 = kv0 + 32 * kb + 8 * (r >> 2) + 4 * hi;
+              const uint32_t bytes = hash32(drop_row + (uint32_t)(key0 >> 2));
+              dpe = (((bytes >> (8 * (r & 3))) & 0xffu) <= p.drop_thr8) ? dp[r] * p.rp_keep : 0.f;
+            }
+          }
+          float dsv = pv * (dpe - delta_l);
           if constexpr (XFORM) dsv *= dcap[r];
           dsfrag[r >> 3][r & 7] = (E)dsv;
         }
@@ -592,7 +621,7 @@ static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
 
 template <typename E, int D>
 static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
-  return (p.alibi || p.softcap > 0.f) ? launch_dkdv_a<E, D, true>(p, stream) : launch_dkdv_a<E, D, false>(p, stream);
+  return (p.alibi || p.softcap > 0.f || p.rng) ? launch_dkdv_a<E, D, true>(p, stream) : launch_dkdv_a<E, D, false>(p, stream);
 }
 
 template <typename E, int D, int NW, bool XFORM>
@@ -610,7 +639,7 @@ static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
 }
 template <typename E, int D>
 static int launch_dq_t(const BwdK& p, hipStream_t stream) {
-  if (p.alibi || p.softcap > 0.f) return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, true>(p, stream) : launch_dq_nw<E, D, 4, true>(p, stream);
+  if (p.alibi || p.softcap > 0.f || p.rng) return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, true>(p, stream) : launch_dq_nw<E, D, 4, true>(p, stream);
   return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, false>(p, stream) : launch_dq_nw<E, D, 4, false>(p, stream);
 }
 

@@ -122,4 +122,31 @@ FA_DEVINL int xcd_interleave(int bid, int n_units, int unit_size, int hpx) {
   return unit < n_units ? unit * unit_size + item : -1;
 }
 
+// ---- dropout random stream --------------------------------------------------------------------------
+// Counter-based: the random byte of element (batch b, query head h, query i, key j) is a pure function of
+// (seed, offset, b, h, i, j), so the forward and both backward kernels regenerate the same mask in their own
+// tilings (the reference does the same with Philox keyed on its tile coordinates, dropout.h:31-90).  One
+// 32-bit integer hash (two multiply/xorshift rounds) yields the 4 bytes of keys 4g .. 4g+3 of one query row.
+FA_DEVINL uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+FA_DEVINL uint32_t drop_bh_key(const uint64_t* rng, int bh) {
+  const uint64_t seed = rng[0], off = rng[1];
+  uint32_t k = hash32((uint32_t)seed ^ 0x9E3779B9u);
+  k = hash32(k ^ (uint32_t)(seed >> 32));
+  k = hash32(k ^ (uint32_t)off);
+  k = hash32(k ^ (uint32_t)(off >> 32));
+  return hash32(k ^ ((uint32_t)bh * 0x9E3779B1u));
+}
+// value held by lane j of the caller's quad (4 adjacent lanes); j must fold to a constant
+template <int J> FA_DEVINL uint32_t quad_bcast_c(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, J * 0x55, 0xf, 0xf, true); }
+FA_DEVINL uint32_t quad_bcast(uint32_t x, int j) {
+  return j == 0 ? quad_bcast_c<0>(x) : j == 1 ? quad_bcast_c<1>(x) : j == 2 ? quad_bcast_c<2>(x) : quad_bcast_c<3>(x);
+}
+// bytes of keys 4g..4g+3 (byte c <-> key 4g+c) of query row i; groups = key groups per row in the stream index
+FA_DEVINL uint32_t drop_bytes(uint32_t bh_key, int i, int groups, int g) {
+  return hash32(bh_key + (uint32_t)i * (uint32_t)groups + (uint32_t)g);
+}
+
 }  // namespace fa

@@ -139,6 +139,10 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   // XFORM (softcap / ALiBi) is a compile-time variant so the common kernel carries none of it
   const float cs = XFORM ? kLog2e : p.scale_log2;  // multiplier taking S to the log2 domain
   const float slope = (XFORM && p.alibi) ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
+  // dropout lives in the XFORM variant too (runtime switch): per-(batch, head) stream key and this lane's row base
+  const bool drop = XFORM && (p.rng != nullptr);
+  const uint32_t drop_row = drop ? (drop_bh_key(p.rng, b * p.h + h) + (uint32_t)my_row * (uint32_t)p.drop_groups) : 0u;
+  uint8_t* rv_row = (drop && p.randval) ? (p.randval + (int64_t)b * p.rv_bs + (int64_t)h * p.rv_hs + (q_row0 + my_row) * p.rv_rs) : nullptr;
   const float thr = p.rescale_thr;
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane = query row, 8 consecutive d per k-step -----
@@ -317,6 +321,23 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
         psum1 += p1;
       }
     l_run += psum0 + psum1;
+    if constexpr (XFORM) {
+      if (drop) {  // the row sum above is that of the un-dropped probabilities (flash_fwd_kernel.h:357-368)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int key0 = kv0 + 32 * kb + 8 * g4 + 4 * hi;  // acc rows 4*g4 .. 4*g4+3 are keys key0 .. key0+3
+            const uint32_t bytes = hash32(drop_row + (uint32_t)(key0 >> 2));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const uint32_t byte = (bytes >> (8 * c)) & 0xffu;
+              if (byte > p.drop_thr8) s[kb][4 * g4 + c] = 0.f;
+              if (rv_row && row_valid && key0 + c < sk) rv_row[key0 + c] = (uint8_t)byte;
+            }
+          }
+      }
+    }
     // P^T as B operand: k-step (kb,t) <-> accumulator registers 8t..8t+7 of s[kb]
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -429,7 +450,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   if (!wave_valid) return;
   const float l_tot = half_sum(l_run);
   const bool dead = (l_tot == 0.f) || (l_tot != l_tot);  // no visible key (softmax.h:179-180)
-  const float inv = dead ? 1.f : 1.f / l_tot;
+  const float inv = (dead ? 1.f : 1.f / l_tot) * (drop ? p.rp_keep : 1.f);
   if (row_valid) {
     E* orow = op + (int64_t)my_row * p.o_rs;
 #pragma unroll
@@ -443,6 +464,15 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
       }
     if (hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
   }
+}
+
+__global__ void fa_set_rng_kernel(uint64_t seed, uint64_t offset, uint64_t* dst) {
+  dst[0] = seed;
+  dst[1] = offset;
+}
+int launch_set_rng(uint64_t seed, uint64_t offset, uint64_t* dst, hipStream_t stream) {
+  hipLaunchKernelGGL(fa_set_rng_kernel, dim3(1), dim3(1), 0, stream, seed, offset, dst);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // KV-cache append (reference flash_fwd_kernel.h:640-720, the Append_KV branch, without rotary): one thread moves
@@ -501,7 +531,7 @@ int fwd_block_m(int nw) { return nw == 16 ? 256 : 32 * nw; }
 
 template <typename E, int D>
 static int launch_fwd_ed(const FwdK& p, int nw, hipStream_t stream) {
-  const bool xf = (p.softcap > 0.f) || (p.alibi != nullptr);
+  const bool xf = (p.softcap > 0.f) || (p.alibi != nullptr) || (p.rng != nullptr);
   if (nw == 16) return xf ? launch_fwd_t<E, D, 8, true, true>(p, stream) : launch_fwd_t<E, D, 8, false, true>(p, stream);
   if (nw == 8) return xf ? launch_fwd_t<E, D, 8, true, false>(p, stream) : launch_fwd_t<E, D, 8, false, false>(p, stream);
   if (nw == 4) return xf ? launch_fwd_t<E, D, 4, true, false>(p, stream) : launch_fwd_t<E, D, 4, false, false>(p, stream);

@@ -35,6 +35,13 @@ struct FwdK {
   float scale_log2;          // softmax_scale * log2(e)
   float softcap;             // 0 = off
   float rescale_thr;         // O rescale deferred until a row max grows by more than this (log2 units)
+  // dropout (rng == nullptr => off): element (b, h, i, j) is kept iff its random byte <= drop_thr8 (fa_device.h drop_bytes)
+  const uint64_t* rng;       // device {seed, offset}
+  uint8_t* randval;          // optional: random bytes out
+  int64_t rv_bs, rv_hs, rv_rs;
+  uint32_t drop_thr8;        // floor(255 * (1 - p_dropout))
+  int32_t drop_groups;       // key groups (of 4) per query row in the stream index
+  float rp_keep;             // 1 / (1 - p_dropout)
 };
 
 struct BwdK {
@@ -70,6 +77,10 @@ struct BwdK {
   float scale;
   float scale_log2;
   float softcap;
+  const uint64_t* rng;       // dropout, as in FwdK
+  uint32_t drop_thr8;
+  int32_t drop_groups;
+  float rp_keep;
 };
 
 }  // namespace fa

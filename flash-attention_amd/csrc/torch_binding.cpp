@@ -7,11 +7,13 @@
 // tests match on them), output allocation from the caching allocator, current-stream lookup, and one
 // call into the C ABI of libfa_gfx950.so (include/fa_gfx950.h).  No kernels, no math.
 #include <ATen/ATen.h>
+#include <ATen/Context.h>
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/csrc/utils/pybind.h>
 #include <torch/extension.h>
 
+#include <mutex>
 #include <optional>
 #include <vector>
 
@@ -50,7 +52,7 @@ Tensor pad_d(const Tensor& x, int64_t d_to) {
 void common_checks(const Tensor& q, const Tensor& k, const Tensor& v, double p_dropout, const OptTensor& alibi,
                    const std::optional<at::Generator>& gen) {
   TORCH_CHECK(!gen.has_value(), "Passing a `generator` argument is no longer supported; seed the default generator instead");
-  TORCH_CHECK(p_dropout == 0.0, "libfa_gfx950: dropout > 0 is not built (feature-gated like FLASHATTENTION_DISABLE_DROPOUT)");
+  TORCH_CHECK(p_dropout >= 0.0 && p_dropout < 1.0, "p_dropout must be in [0, 1)");
   CHECK_DEVICE(q); CHECK_DEVICE(k); CHECK_DEVICE(v);
   TORCH_CHECK(k.dtype() == q.dtype() && v.dtype() == q.dtype(), "query, key and value must have the same dtype");
   TORCH_CHECK(q.stride(-1) == 1 && k.stride(-1) == 1 && v.stride(-1) == 1, "Input tensor must have contiguous last dimension");
@@ -59,6 +61,31 @@ void common_checks(const Tensor& q, const Tensor& k, const Tensor& v, double p_d
     CHECK_DEVICE(*alibi);
     TORCH_CHECK(alibi->stride(-1) == 1, "ALiBi slopes tensor must have contiguous last dimension");
   }
+}
+
+// rng_state = {seed, offset} of the device's default generator (flash_api.cpp:496-515); the Philox offset advances as
+// in csrc/flash_attn_ck/mha_fwd.cpp:283-295 so that consecutive calls draw different masks.
+Tensor make_rng_state(const Tensor& q, double p_dropout, int64_t B, int64_t H) {
+  Tensor rng_state = at::empty({2}, q.options().dtype(at::kLong));
+  if (p_dropout > 0.0) {
+    at::Generator gen = at::globalContext().defaultGenerator(q.device());
+    uint64_t seed, off;
+    {
+      std::lock_guard<std::mutex> lock(gen.mutex());
+      seed = gen.current_seed();
+      off = gen.get_offset();
+      gen.set_offset(off + (uint64_t)((B * H * 64 + 3) / 4) * 4);
+    }
+    fa_check(fa_set_rng_state(seed, off, reinterpret_cast<uint64_t*>(rng_state.data_ptr<int64_t>()), cur_stream(q)));
+  }
+  return rng_state;
+}
+
+const uint64_t* bwd_rng(double p_dropout, const OptTensor& rng_state) {
+  if (!(p_dropout > 0.0)) return nullptr;
+  TORCH_CHECK(rng_state.has_value(), "p_dropout > 0 in the backward needs the forward's rng_state");
+  TORCH_CHECK(rng_state->is_cuda() && rng_state->dtype() == at::kLong && rng_state->numel() == 2, "rng_state must be a CUDA int64 tensor of shape (2,)");
+  return reinterpret_cast<const uint64_t*>(rng_state->data_ptr<int64_t>());
 }
 
 void set_alibi(const OptTensor& alibi, int64_t B, int64_t H, const float*& ptr, int64_t& bs) {
@@ -76,7 +103,7 @@ std::vector<Tensor> mha_fwd(Tensor& q, const Tensor& k, const Tensor& v, OptTens
                             int64_t window_size_right, const double softcap, const bool return_softmax,
                             std::optional<at::Generator> gen_) {
   common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
-  TORCH_CHECK(!return_softmax, "return_softmax is only supported when p_dropout > 0.0");
+  TORCH_CHECK(!return_softmax || p_dropout > 0.0, "return_softmax is only supported when p_dropout > 0.0");
   TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.dim() == 4, "q, k, v must be 4-D (batch, seqlen, nheads, headdim)");
   const int64_t B = q.size(0), Sq = q.size(1), H = q.size(2), D = q.size(3), Sk = k.size(1), Hk = k.size(2);
   TORCH_CHECK(B > 0, "batch size must be positive");
@@ -95,8 +122,9 @@ std::vector<Tensor> mha_fwd(Tensor& q, const Tensor& k, const Tensor& v, OptTens
   }
   out = (out_.has_value() && Dn == D) ? *out_ : at::empty({B, Sq, H, Dn}, q.options());
   Tensor lse = at::empty({B, H, Sq}, q.options().dtype(at::kFloat));
-  Tensor rng_state = at::empty({2}, q.options().dtype(at::kLong));
-  Tensor p = at::empty({0}, q.options());
+  Tensor rng_state = make_rng_state(q, p_dropout, B, H);
+  // return_softmax: the random byte of every (query, key) pair, the ROCm backend's payload (csrc/flash_attn_ck/mha_fwd.cpp:275-279)
+  Tensor p = return_softmax ? at::zeros({B, H, Sq, Sk}, q.options().dtype(at::kByte)) : at::empty({0}, q.options());
   if (Sk == 0) {  // flash_api.cpp:524-528
     out.zero_();
     lse.fill_(std::numeric_limits<float>::infinity());
@@ -112,6 +140,14 @@ std::vector<Tensor> mha_fwd(Tensor& q, const Tensor& k, const Tensor& v, OptTens
     a.dtype = dtype_code(q);
     a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
     a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap;
+    if (p_dropout > 0.0) {
+      a.p_dropout = (float)p_dropout;
+      a.rng_state = reinterpret_cast<const uint64_t*>(rng_state.data_ptr<int64_t>());
+      if (return_softmax) {
+        a.randval = p.data_ptr<uint8_t>();
+        a.randval_batch_stride = p.stride(0); a.randval_head_stride = p.stride(1); a.randval_row_stride = p.stride(2);
+      }
+    }
     fa_check(fa_fwd(&a, cur_stream(q)));
   }
   if (Dn != D) {
@@ -130,7 +166,7 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
                                    const double softcap, const bool return_softmax, std::optional<at::Generator> gen_,
                                    const int64_t num_splits) {
   common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
-  TORCH_CHECK(!return_softmax, "return_softmax is only supported when p_dropout > 0.0");
+  TORCH_CHECK(!return_softmax || p_dropout > 0.0, "return_softmax is only supported when p_dropout > 0.0");
   TORCH_CHECK(!block_table_.has_value(), "libfa_gfx950: paged KV (block_table) is not built");
   TORCH_CHECK(!leftpad_k_.has_value(), "libfa_gfx950: leftpad_k is not built");
   TORCH_CHECK(num_splits <= 1, "num_splits > 1 is not supported");
@@ -163,8 +199,9 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
   }
   Tensor out = (out_.has_value() && Dn == D) ? *out_ : at::empty({total_q, H, Dn}, q.options());
   Tensor lse = at::empty({H, total_q}, q.options().dtype(at::kFloat));
-  Tensor rng_state = at::empty({2}, q.options().dtype(at::kLong));
-  Tensor p = at::empty({0}, q.options());
+  Tensor rng_state = make_rng_state(q, p_dropout, B, H);
+  // varlen payload layout of the ROCm backend: (nheads, total_q, max_seqlen_k)
+  Tensor p = return_softmax ? at::zeros({H, total_q, max_seqlen_k}, q.options().dtype(at::kByte)) : at::empty({0}, q.options());
   if (zero_tensors) {  // flash_api.cpp:693-697
     out.zero_();
     lse.fill_(-std::numeric_limits<float>::infinity());
@@ -186,6 +223,14 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
     a.dtype = dtype_code(q);
     a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
     a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap;
+    if (p_dropout > 0.0) {
+      a.p_dropout = (float)p_dropout;
+      a.rng_state = reinterpret_cast<const uint64_t*>(rng_state.data_ptr<int64_t>());
+      if (return_softmax) {
+        a.randval = p.data_ptr<uint8_t>();
+        a.randval_batch_stride = 0; a.randval_head_stride = p.stride(0); a.randval_row_stride = p.stride(1);
+      }
+    }
     fa_check(fa_varlen_fwd(&a, cur_stream(q)));
   }
   if (Dn != D) {
@@ -269,6 +314,7 @@ std::vector<Tensor> mha_bwd(const Tensor& dout, const Tensor& q, const Tensor& k
   a.dtype = dtype_code(q);
   a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
   a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap; a.deterministic = deterministic;
+  a.p_dropout = (float)p_dropout; a.rng_state = bwd_rng(p_dropout, rng_state);
   run_bwd(a, q, false);
   if (Dn != D) {
     dq.copy_(t.dq.slice(-1, 0, D)); dk.copy_(t.dk.slice(-1, 0, D)); dv.copy_(t.dv.slice(-1, 0, D));
@@ -323,6 +369,7 @@ std::vector<Tensor> mha_varlen_bwd(const Tensor& dout, const Tensor& q, const Te
   a.dtype = dtype_code(q);
   a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
   a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap; a.deterministic = deterministic;
+  a.p_dropout = (float)p_dropout; a.rng_state = bwd_rng(p_dropout, rng_state);
   run_bwd(a, q, true);
   if (Dn != D) {
     dq.copy_(t.dq.slice(-1, 0, D)); dk.copy_(t.dk.slice(-1, 0, D)); dv.copy_(t.dv.slice(-1, 0, D));

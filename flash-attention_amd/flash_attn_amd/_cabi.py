@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-FA_ABI_VERSION = 2
+FA_ABI_VERSION = 3
 FA_DTYPE_FP16, FA_DTYPE_BF16 = 0, 1
 FA_OK, FA_ERR_INVALID_ARGUMENT, FA_ERR_UNSUPPORTED, FA_ERR_LAUNCH, FA_ERR_WORKSPACE = 0, -1, -2, -3, -4
 
@@ -31,7 +31,10 @@ class FaFwdParams(C.Structure):
         ("is_causal", _i32), ("window_left", _i32), ("window_right", _i32),
         ("softmax_scale", _f32), ("softcap", _f32), ("seqused_k_add", _i32),
         ("cache_batch_idx", _vp), ("block_table", _vp), ("block_table_batch_stride", _i64),
-        ("page_block_size", _i32), ("reserved", _i32 * 3),
+        ("page_block_size", _i32), ("num_splits", _i32), ("p_dropout", _f32), ("reserved0", _i32),
+        ("rng_state", _vp), ("randval", _vp),
+        ("randval_batch_stride", _i64), ("randval_head_stride", _i64), ("randval_row_stride", _i64),
+        ("workspace", _vp), ("workspace_bytes", _i64),
     ]
 
 
@@ -67,13 +70,14 @@ class FaBwdParams(C.Structure):
         ("seqlen_q", _i32), ("seqlen_k", _i32), ("total_q", _i32), ("total_k", _i32),
         ("dtype", _i32), ("is_causal", _i32), ("window_left", _i32), ("window_right", _i32),
         ("softmax_scale", _f32), ("softcap", _f32), ("deterministic", _i32),
-        ("reserved", _i32 * 4),
+        ("p_dropout", _f32), ("reserved", _i32 * 3), ("rng_state", _vp),
     ]
 
 
 EXPORTS = (
     "fa_abi_version", "fa_sizeof_fwd_params", "fa_sizeof_bwd_params", "fa_sizeof_kvappend_params", "fa_last_error",
-    "fa_fwd", "fa_varlen_fwd", "fa_fwd_kvcache", "fa_kvcache_append", "fa_bwd_workspace_bytes", "fa_bwd", "fa_varlen_bwd",
+    "fa_fwd", "fa_varlen_fwd", "fa_fwd_kvcache", "fa_kvcache_append", "fa_set_rng_state", "fa_fwd_workspace_bytes",
+    "fa_bwd_workspace_bytes", "fa_bwd", "fa_varlen_bwd",
 )
 
 _LIB = None
@@ -113,6 +117,10 @@ def load():
     for fn in (lib.fa_bwd, lib.fa_varlen_bwd):
         fn.argtypes = [C.POINTER(FaBwdParams), C.c_void_p]
         fn.restype = C.c_int
+    lib.fa_set_rng_state.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.fa_set_rng_state.restype = C.c_int
+    lib.fa_fwd_workspace_bytes.argtypes = [C.POINTER(FaFwdParams)]
+    lib.fa_fwd_workspace_bytes.restype = C.c_int64
     lib.fa_bwd_workspace_bytes.argtypes = [C.POINTER(FaBwdParams)]
     lib.fa_bwd_workspace_bytes.restype = C.c_int64
     if lib.fa_abi_version() != FA_ABI_VERSION:

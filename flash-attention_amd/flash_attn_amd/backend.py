@@ -58,8 +58,8 @@ def _ptr(t: Optional[torch.Tensor]):
 def _common_checks(q, k, v, p_dropout, alibi_slopes, gen_):
     if gen_ is not None:
         raise RuntimeError("Passing a `generator` argument is no longer supported; seed the default generator instead")
-    if p_dropout != 0.0:
-        raise RuntimeError("libfa_gfx950: dropout > 0 is not built (feature-gated like FLASHATTENTION_DISABLE_DROPOUT)")
+    if not (0.0 <= p_dropout < 1.0):
+        raise RuntimeError("p_dropout must be in [0, 1)")
     _check_dev(q, k, v)
     if not (q.dtype == k.dtype == v.dtype):
         raise RuntimeError("query, key and value must have the same dtype")
@@ -71,6 +71,20 @@ def _common_checks(q, k, v, p_dropout, alibi_slopes, gen_):
             raise RuntimeError("ALiBi slopes must have dtype fp32")
         if alibi_slopes.stride(-1) != 1:
             raise RuntimeError("ALiBi slopes tensor must have contiguous last dimension")
+
+
+def _new_rng_state(device, p_dropout, batch, nheads):
+    """(seed, offset) of the default generator of ``device`` as the device int64[2] the reference returns
+    (flash_api.cpp:496-515); the generator's Philox offset advances as in csrc/flash_attn_ck/mha_fwd.cpp:283-295."""
+    rng_state = torch.empty((2,), dtype=torch.int64, device=device)
+    if p_dropout > 0.0:
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        seed, off = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(off + ((batch * nheads * 64 + 3) // 4) * 4)
+        with torch.cuda.device(device):
+            _cabi.check(_cabi.load().fa_set_rng_state(C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(off), _ptr(rng_state),
+                                                      C.c_void_p(_stream_ptr(device))))
+    return rng_state
 
 
 def _alibi_args(alibi_slopes, batch, nheads):
@@ -85,7 +99,7 @@ def fwd(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, windo
         window_size_right, softcap, return_softmax, gen_) -> List[torch.Tensor]:
     """mha_fwd (flash_api.cpp:368-536): q (B,Sq,H,D), k/v (B,Sk,Hk,D) -> [out, softmax_lse, p, rng_state]."""
     _common_checks(q, k, v, p_dropout, alibi_slopes_, gen_)
-    if return_softmax:
+    if return_softmax and not p_dropout > 0.0:
         raise RuntimeError("return_softmax is only supported when p_dropout > 0.0")
     B, Sq, H, D = q.shape
     Sk, Hk = k.shape[1], k.shape[2]
@@ -106,8 +120,10 @@ def fwd(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, windo
             raise RuntimeError("out_ must have the same dtype/shape as q and a contiguous last dimension")
     out = out_ if (out_ is not None and Dn == D) else torch.empty((B, Sq, H, Dn), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
-    rng_state = torch.empty((2,), dtype=torch.int64, device=q.device)
-    p_out = torch.empty((0,), dtype=q.dtype, device=q.device)
+    rng_state = _new_rng_state(q.device, p_dropout, B, H)
+    # return_softmax: the random byte of every (query, key) pair, the ROCm backend's payload (mha_fwd.cpp:275-279)
+    p_out = (torch.zeros((B, H, Sq, Sk), dtype=torch.uint8, device=q.device) if return_softmax
+             else torch.empty((0,), dtype=q.dtype, device=q.device))
     if Sk == 0:  # flash_api.cpp:524-528
         out.zero_()
         lse.fill_(float("inf"))
@@ -125,6 +141,11 @@ def fwd(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, windo
         a.dtype = _dtype_code(q)
         a.is_causal, a.window_left, a.window_right = int(bool(is_causal)), int(window_size_left), int(window_size_right)
         a.softmax_scale, a.softcap = float(softmax_scale), float(softcap)
+        if p_dropout > 0.0:
+            a.p_dropout, a.rng_state = float(p_dropout), _ptr(rng_state)
+            if return_softmax:
+                a.randval = _ptr(p_out)
+                a.randval_batch_stride, a.randval_head_stride, a.randval_row_stride = p_out.stride(0), p_out.stride(1), p_out.stride(2)
         with torch.cuda.device(q.device):
             _cabi.check(_cabi.load().fa_fwd(C.byref(a), C.c_void_p(_stream_ptr(q.device))))
     if Dn != D:
@@ -142,7 +163,7 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
                num_splits: int = 0) -> List[torch.Tensor]:
     """mha_varlen_fwd (flash_api.cpp:538-788): packed q (total_q,H,D), k/v (total_k,Hk,D), int32 cu_seqlens (B+1)."""
     _common_checks(q, k, v, p_dropout, alibi_slopes_, gen_)
-    if return_softmax:
+    if return_softmax and not p_dropout > 0.0:
         raise RuntimeError("return_softmax is only supported when p_dropout > 0.0")
     if block_table_ is not None:
         raise RuntimeError("libfa_gfx950: paged KV (block_table) is not built")
@@ -173,8 +194,10 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
     qp, kp, vp = _pad_d(q, Dn), _pad_d(k, Dn), _pad_d(v, Dn)
     out = out_ if (out_ is not None and Dn == D) else torch.empty((total_q, H, Dn), dtype=q.dtype, device=q.device)
     lse = torch.empty((H, total_q), dtype=torch.float32, device=q.device)
-    rng_state = torch.empty((2,), dtype=torch.int64, device=q.device)
-    p_out = torch.empty((0,), dtype=q.dtype, device=q.device)
+    rng_state = _new_rng_state(q.device, p_dropout, B, H)
+    # varlen payload layout of the ROCm backend: (nheads, total_q, max_seqlen_k) (mha_varlen_fwd.cpp)
+    p_out = (torch.zeros((H, total_q, int(max_seqlen_k)), dtype=torch.uint8, device=q.device) if return_softmax
+             else torch.empty((0,), dtype=q.dtype, device=q.device))
     if zero_tensors:  # flash_api.cpp:693-697
         out.zero_()
         lse.fill_(float("-inf"))
@@ -196,6 +219,11 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
         a.dtype = _dtype_code(q)
         a.is_causal, a.window_left, a.window_right = int(bool(is_causal)), int(window_size_left), int(window_size_right)
         a.softmax_scale, a.softcap = float(softmax_scale), float(softcap)
+        if p_dropout > 0.0:
+            a.p_dropout, a.rng_state = float(p_dropout), _ptr(rng_state)
+            if return_softmax:
+                a.randval = _ptr(p_out)
+                a.randval_batch_stride, a.randval_head_stride, a.randval_row_stride = 0, p_out.stride(0), p_out.stride(1)
         with torch.cuda.device(q.device):
             _cabi.check(_cabi.load().fa_varlen_fwd(C.byref(a), C.c_void_p(_stream_ptr(q.device))))
     if Dn != D:
@@ -213,6 +241,16 @@ def _bwd_out(buf, like, name):
     if buf.dtype != like.dtype or tuple(buf.shape) != tuple(like.shape) or buf.stride(-1) != 1:
         raise RuntimeError(f"{name} must have the same dtype/shape as its input and a contiguous last dimension")
     return buf
+
+
+def _bwd_rng(p_dropout, rng_state, device):
+    if not p_dropout > 0.0:
+        return None
+    if rng_state is None:
+        raise RuntimeError("p_dropout > 0 in the backward needs the forward's rng_state")
+    if rng_state.dtype != torch.int64 or rng_state.numel() != 2 or not rng_state.is_cuda:
+        raise RuntimeError("rng_state must be a CUDA int64 tensor of shape (2,)")
+    return rng_state
 
 
 def _fill_bwd_common(a, dout, q, k, v, out, lse, dq, dk, dv, delta, alibi, alibi_bs, softmax_scale,
@@ -275,6 +313,9 @@ def bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, alibi_slopes_, p_dropout
         setattr(a, nm + "_head_stride", t.stride(2))
     a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
     a.seqlen_q, a.seqlen_k, a.total_q, a.total_k = Sq, Sk, B * Sq, B * Sk
+    rng = _bwd_rng(p_dropout, rng_state, q.device)
+    if rng is not None:
+        a.p_dropout, a.rng_state = float(p_dropout), _ptr(rng)
     _run_bwd(a, q.device, False)
     if Dn != D:
         dq.copy_(dqp[..., :D]); dk.copy_(dkp[..., :D]); dv.copy_(dvp[..., :D])
@@ -319,6 +360,9 @@ def varlen_bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, cu_seqlens_q, cu_
     a.cu_seqlens_q, a.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
     a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
     a.seqlen_q, a.seqlen_k, a.total_q, a.total_k = int(max_seqlen_q), int(max_seqlen_k), total_q, total_k
+    rng = _bwd_rng(p_dropout, rng_state, q.device)
+    if rng is not None:
+        a.p_dropout, a.rng_state = float(p_dropout), _ptr(rng)
     _run_bwd(a, q.device, True)
     if Dn != D:
         dq.copy_(dqp[..., :D]); dk.copy_(dkp[..., :D]); dv.copy_(dvp[..., :D])

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 2
+#define FA_ABI_VERSION 3
 
 enum { FA_DTYPE_FP16 = 0, FA_DTYPE_BF16 = 1 };
 
@@ -80,7 +80,18 @@ typedef struct FaFwdParams {
   const int32_t* block_table;       /* optional (B, max_blocks) int32: paged cache, k/v are (num_blocks, page, Hk, D) */
   int64_t block_table_batch_stride;
   int32_t page_block_size;          /* keys per page, multiple of 256 (reference flash_api.cpp:1318)  */
-  int32_t reserved[3];
+  int32_t num_splits;               /* fa_fwd_kvcache: 0 = heuristic, 1 = no split, >1 = split the keys this many ways */
+  float p_dropout;                  /* probability to DROP, in [0, 1); 0 = off                         */
+  int32_t reserved0;
+  /* dropout (p_dropout > 0): */
+  const uint64_t* rng_state;        /* device, 2 x u64 {seed, offset} (reference rng_state, flash_api.cpp:496-515) */
+  uint8_t* randval;                 /* optional out: the random byte of every (query, key) pair; a pair is KEPT iff
+                                       byte <= floor(255*(1-p_dropout)) (the ROCm backend's return_softmax payload,
+                                       csrc/flash_attn_ck/mha_fwd.cpp:275-279); (B,H,Sq,Sk) or varlen (H,total_q,max_seqlen_k) */
+  int64_t randval_batch_stride, randval_head_stride, randval_row_stride;
+  /* split-KV scratch (fa_fwd_kvcache): fa_fwd_workspace_bytes() bytes, 256-B aligned; may be NULL if that is 0 */
+  void* workspace;
+  int64_t workspace_bytes;
 } FaFwdParams;
 
 /* Append step of the KV-cache path: copy knew/vnew (B, S_new, Hk, D) into the cache at rows
@@ -138,7 +149,9 @@ typedef struct FaBwdParams {
   float softmax_scale;
   float softcap;
   int32_t deterministic;        /* accepted; this implementation is always deterministic */
-  int32_t reserved[4];
+  float p_dropout;              /* as in the forward call                                  */
+  int32_t reserved[3];
+  const uint64_t* rng_state;    /* device {seed, offset} the forward used (p_dropout > 0) */
 } FaBwdParams;
 
 /* ABI version of the loaded library (== FA_ABI_VERSION of the header it was built from). */
@@ -159,6 +172,10 @@ int fa_varlen_fwd(const FaFwdParams* params, void* stream);
 int fa_fwd_kvcache(const FaFwdParams* params, void* stream);
 /* Writes the new keys/values into the cache (call before fa_fwd_kvcache with seqused_k_add = seqlen_new). */
 int fa_kvcache_append(const FaKvAppendParams* params, void* stream);
+/* Writes {seed, offset} to a device rng_state (2 x u64) in stream order (binder helper for p_dropout > 0). */
+int fa_set_rng_state(uint64_t seed, uint64_t offset, uint64_t* rng_state, void* stream);
+/* Bytes of split-KV scratch fa_fwd_kvcache needs for this problem with params->num_splits (0 is possible). */
+int64_t fa_fwd_workspace_bytes(const FaFwdParams* params);
 /* Bytes of scratch the backward needs for this problem (0 is possible). */
 int64_t fa_bwd_workspace_bytes(const FaBwdParams* params);
 /* Backward, fixed-length batch: writes dq, dk, dv (caller-allocated) and softmax_d. */

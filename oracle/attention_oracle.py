@@ -131,8 +131,12 @@ def _scores(qh, kh, scale, softcap, vis, alibi_slope, shift):
 
 def attention_fwd(q, k, v, softmax_scale: Optional[float] = None, causal: bool = False,
                   window: Tuple[int, int] = (-1, -1), softcap: float = 0.0,
-                  alibi_slopes=None):
+                  alibi_slopes=None, dropout_p: float = 0.0, dropout_mask=None):
     """Forward oracle.
+
+    Dropout (tests/test_util.py:262-269, flash_fwd_kernel.h:357-368): the normalised probabilities are
+    multiplied by ``dropout_mask`` (B,H,Sq,Sk, True = keep) and by 1/(1-dropout_p) before the product
+    with V; the softmax statistics (lse) are those of the un-dropped scores.
 
     q (B,Sq,H,D); k,v (B,Sk,Hk,D).  Returns out (B,Sq,H,D) f64 and
     lse (B,H,Sq) f64 with lse = log(sum_j exp(score_ij)) over visible j;
@@ -164,6 +168,8 @@ def attention_fwd(q, k, v, softmax_scale: Optional[float] = None, causal: bool =
             p = np.exp(s - m_safe[:, None])
             l = p.sum(axis=1)
             l_safe = np.where(live, l, 1.0)
+            if dropout_mask is not None:
+                p = p * np.asarray(dropout_mask[b, h], dtype=np.float64) / (1.0 - dropout_p)
             o = (p @ v[b, :, h // g]) / l_safe[:, None]
             out[b, :, h] = np.where(live[:, None], o, 0.0)
             lse[b, h] = np.where(live, m_safe + np.log(l_safe), np.inf)
@@ -172,8 +178,11 @@ def attention_fwd(q, k, v, softmax_scale: Optional[float] = None, causal: bool =
 
 def attention_bwd(dout, q, k, v, out=None, lse=None, softmax_scale: Optional[float] = None,
                   causal: bool = False, window: Tuple[int, int] = (-1, -1), softcap: float = 0.0,
-                  alibi_slopes=None):
+                  alibi_slopes=None, dropout_p: float = 0.0, dropout_mask=None):
     """Backward oracle: returns dq (B,Sq,H,D), dk, dv (B,Sk,Hk,D), delta (B,H,Sq), all f64.
+
+    With dropout (flash_bwd_kernel.h:560-600): Z = mask/(1-p); dV = (P*Z)^T dO, dP = (dO V^T)*Z,
+    delta = rowsum(dO*O) with the dropped O.
 
     Restates flash_bwd_kernel.h:536-733: P_ij = exp(score_ij - LSE_i) (0 when LSE_i = +inf),
     dV = P^T dO, dP = dO V^T, delta_i = sum_d dO_id O_id, dS = P * (dP - delta),
@@ -186,7 +195,7 @@ def attention_bwd(dout, q, k, v, out=None, lse=None, softmax_scale: Optional[flo
     Sk, Hk = k.shape[1], k.shape[2]
     scale = D ** -0.5 if softmax_scale is None else float(softmax_scale)
     if out is None or lse is None:
-        out, lse = attention_fwd(q, k, v, scale, causal, window, softcap, alibi_slopes)
+        out, lse = attention_fwd(q, k, v, scale, causal, window, softcap, alibi_slopes, dropout_p, dropout_mask)
     out, lse = _f64(out), _f64(lse)
     _, wl, wr = normalize_window(Sq, Sk, causal, window[0], window[1], alibi_slopes is not None)
     vis = visible_mask(Sq, Sk, wl, wr)
@@ -210,8 +219,9 @@ def attention_bwd(dout, q, k, v, out=None, lse=None, softmax_scale: Optional[flo
             live = np.isfinite(row_lse)
             p = np.where(live[:, None], np.exp(s - np.where(live, row_lse, 0.0)[:, None]), 0.0)
             do = dout[b, :, h]
-            dv[b, :, hk] += p.T @ do
-            dp = do @ v[b, :, hk].T
+            z = 1.0 if dropout_mask is None else np.asarray(dropout_mask[b, h], dtype=np.float64) / (1.0 - dropout_p)
+            dv[b, :, hk] += (p * z).T @ do
+            dp = (do @ v[b, :, hk].T) * z
             ds = p * (dp - delta[b, h][:, None])
             if softcap > 0.0:
                 raw = (q[b, :, h] @ k[b, :, hk].T) * scale

@@ -20,3 +20,16 @@ def golden_cases():
     z = np.load(os.path.join(ROOT, "tests", "golden", "attention_ref_cases.npz"))
     names = sorted({k.split("/")[0] for k in z.files})
     return {n: {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(n + "/")} for n in names}
+
+
+@pytest.fixture(scope="session")
+def dropout_cases():
+    """Reference oracle outputs with an explicit keep-mask (tests/golden/make_golden.py)."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "dropout_ref_cases.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    cases = {n: {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(n + "/")} for n in names}
+    for c in cases.values():
+        B, Sq, Sk, H = [int(x) for x in c["meta"][:4]]
+        c["keep"] = np.unpackbits(c["keep"])[: B * H * Sq * Sk].reshape(B, H, Sq, Sk).astype(bool)
+    return cases

@@ -97,6 +97,32 @@ def main():
         print(name, "out", tuple(o.shape), "max|out|", float(o.detach().abs().max()))
     np.savez_compressed(os.path.join(HERE, "attention_ref_cases.npz"), **out)
 
+    # dropout: the reference oracle with an explicit keep-mask (tests/test_util.py:262-269), seeded mask
+    dro = {}
+    for (name, B, Sq, Sk, H, Hk, D, causal, window, pdrop) in [
+            ("drop_full_d64", 1, 72, 96, 2, 2, 64, False, (-1, -1), 0.17),
+            ("drop_causal_gqa_d128", 2, 65, 100, 4, 2, 128, True, (-1, -1), 0.3),
+            ("drop_local_d64", 1, 96, 96, 2, 1, 64, False, (30, 10), 0.1)]:
+        g = torch.Generator().manual_seed(sum(map(ord, name)))
+        q = torch.randn(B, Sq, H, D, generator=g).bfloat16().float().requires_grad_()
+        k = torch.randn(B, Sk, Hk, D, generator=g).bfloat16().float().requires_grad_()
+        v = torch.randn(B, Sk, Hk, D, generator=g).bfloat16().float().requires_grad_()
+        do = torch.randn(B, Sq, H, D, generator=g).bfloat16().float()
+        keep = torch.rand(B, H, Sq, Sk, generator=g) >= pdrop
+        o, _ = tu.attention_ref(q, k, v, None, None, None, pdrop, keep, causal=causal, window_size=window)
+        dq, dk, dv = torch.autograd.grad(o, (q, k, v), do)
+        pre = name + "/"
+        for nm, t in (("q", q), ("k", k), ("v", v), ("do", do)):
+            bits = t.detach().numpy().astype(np.float32).view(np.uint32)
+            dro[pre + nm + "_bf16bits"] = (bits >> 16).astype(np.uint16)
+        dro[pre + "keep"] = np.packbits(keep.numpy())
+        for nm, t in (("out", o), ("dq", dq), ("dk", dk), ("dv", dv)):
+            dro[pre + nm] = t.detach().numpy().astype(np.float32)
+        dro[pre + "meta"] = np.array([B, Sq, Sk, H, Hk, D, int(causal), window[0], window[1]], dtype=np.int64)
+        dro[pre + "p"] = np.array([pdrop], dtype=np.float64)
+        print(name, "out", tuple(o.shape))
+    np.savez_compressed(os.path.join(HERE, "dropout_ref_cases.npz"), **dro)
+
     # documented causal mask pictures, flash_attn_interface.py:1176-1185 (1 = keep)
     pics = {
         "mask_2x5": np.array([[1, 1, 1, 1, 0], [1, 1, 1, 1, 1]], dtype=np.int8),

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_ctypes_mirror_matches_c_structs(built):
     from flash_attn_amd import _cabi
     lib = _cabi.load()
-    assert lib.fa_abi_version() == _cabi.FA_ABI_VERSION == 2
+    assert lib.fa_abi_version() == _cabi.FA_ABI_VERSION == 3
     assert lib.fa_sizeof_kvappend_params() == ctypes.sizeof(_cabi.FaKvAppendParams)
     assert lib.fa_sizeof_fwd_params() == ctypes.sizeof(_cabi.FaFwdParams)
     assert lib.fa_sizeof_bwd_params() == ctypes.sizeof(_cabi.FaBwdParams)
@@ -84,7 +84,9 @@ def test_ctypes_backend_validation_matches():
         be.fwd(q, q, q, None, None, 0.0, 0.125, False, -1, -1, 0.0, False, None)
     with pytest.raises(RuntimeError, match="generator"):
         be.fwd(q, q, q, None, None, 0.0, 0.125, False, -1, -1, 0.0, False, torch.Generator())
-    with pytest.raises(RuntimeError, match="dropout"):
+    with pytest.raises(RuntimeError, match="p_dropout"):
+        be.fwd(q, q, q, None, None, 1.0, 0.125, False, -1, -1, 0.0, False, None)
+    with pytest.raises(RuntimeError, match="CUDA"):  # dropout is built: the device check comes first
         be.fwd(q, q, q, None, None, 0.1, 0.125, False, -1, -1, 0.0, False, None)
 
 

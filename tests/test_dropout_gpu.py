@@ -1,0 +1,144 @@
+"""GPU parity tests of dropout (forward + backward + return_softmax payload) against the fp64 oracle.
+
+The kernels regenerate the keep-mask from (rng_state, batch, head, query, key); ``return_softmax`` hands the
+random byte of every pair back (the ROCm backend's payload, reference csrc/flash_attn_ck/mha_fwd.cpp:275-279,
+tests/test_flash_attn_ck.py:49-53: kept iff byte <= floor(255 * (1 - p))).  The tests take the mask from that
+payload, feed it to the oracle (pinned to the reference's attention_ref on CPU, tests/test_oracle_cpu.py) and
+compare outputs and all three gradients -- so a backward kernel that regenerated a different mask would fail.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=["ext", "ctypes"])
+def be(request):
+    if request.param == "ext":
+        import flash_attn_2_cuda as m
+    else:
+        from flash_attn_amd import backend as m
+    return m
+
+
+def _keep(randval, p):
+    return randval.to(torch.int32) <= math.floor(255.0 * (1.0 - p))
+
+
+def _visible(sq, sk, causal, window):
+    from oracle import attention_oracle as orc
+    _, wl, wr = orc.normalize_window(sq, sk, causal, window[0], window[1])
+    return orc.visible_mask(sq, sk, wl, wr)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("p", [0.17, 0.5])
+@pytest.mark.parametrize("sq,sk,h,hk,causal,window", [
+    (128, 128, 4, 4, False, (-1, -1)), (113, 203, 4, 2, True, (-1, -1)), (256, 130, 2, 1, True, (-1, -1)),
+    (200, 333, 4, 4, False, (50, 20)), (97, 400, 6, 2, False, (-1, -1)), (300, 300, 2, 2, True, (64, 0))])
+def test_dropout_fwd_bwd_vs_oracle(be, sq, sk, h, hk, causal, window, p, d, dtype):
+    from oracle import attention_oracle as orc
+    torch.manual_seed(sq * 3 + sk)
+    B = 2
+    q = torch.randn(B, sq, h, d, device="cuda", dtype=dtype)
+    k = torch.randn(B, sk, hk, d, device="cuda", dtype=dtype)
+    v = torch.randn(B, sk, hk, d, device="cuda", dtype=dtype)
+    do = torch.randn(B, sq, h, d, device="cuda", dtype=dtype)
+    scale = d ** -0.5
+    out, lse, rv, rng = be.fwd(q, k, v, None, None, p, scale, causal, window[0], window[1], 0.0, True, None)
+    assert rv.dtype == torch.uint8 and tuple(rv.shape) == (B, h, sq, sk) and tuple(rng.shape) == (2,)
+    keep = _keep(rv, p).cpu().numpy()
+    vis = _visible(sq, sk, causal, window)
+    if vis.sum() * B * h > 20000:  # kept fraction of the visible pairs (reference get_dropout_fraction check)
+        frac = keep[:, :, vis].mean()
+        assert abs(frac - (math.floor(255 * (1 - p)) + 1) / 256) < 0.01
+    o_ref, l_ref = orc.attention_fwd(q, k, v, scale, causal, window, 0.0, None, p, keep)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < tol / (1 - p)
+    live = np.isfinite(l_ref)
+    assert max_abs(lse.cpu()[torch.from_numpy(live)], torch.from_numpy(l_ref[live]).float()) < 2e-3
+    dq, dk, dv, _ = be.bwd(do, q, k, v, out, lse, None, None, None, None, p, scale, causal, window[0], window[1], 0.0, False, None, rng)
+    rq, rk, rvv, _ = orc.attention_bwd(do, q, k, v, out, lse, scale, causal, window, 0.0, None, p, keep)
+    for nm, got, ref in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rvv)):
+        gtol = (4e-2 if dtype == torch.bfloat16 else 8e-3) * max(1.0, float(np.abs(ref).max())) / (1 - p)
+        assert max_abs(got.float().cpu(), torch.from_numpy(ref)) < gtol, (nm, max_abs(got.float().cpu(), torch.from_numpy(ref)), gtol)
+    # same rng_state => bitwise the same backward; the forward replays from a seeded generator
+    dq2, dk2, dv2, _ = be.bwd(do, q, k, v, out, lse, None, None, None, None, p, scale, causal, window[0], window[1], 0.0, False, None, rng)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+
+
+def test_dropout_varlen_and_generator_semantics(be):
+    from oracle import attention_oracle as orc
+    torch.manual_seed(5)
+    lens_q, lens_k = [70, 1, 200, 129], [70, 33, 260, 129]
+    H, Hk, d, p = 4, 2, 128, 0.25
+    cu_q = torch.tensor([0] + list(np.cumsum(lens_q)), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0] + list(np.cumsum(lens_k)), dtype=torch.int32, device="cuda")
+    tq, tk = sum(lens_q), sum(lens_k)
+    q = torch.randn(tq, H, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(tk, Hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(tk, Hk, d, device="cuda", dtype=torch.bfloat16)
+    do = torch.randn(tq, H, d, device="cuda", dtype=torch.bfloat16)
+    scale = d ** -0.5
+    args = (q, k, v, None, cu_q, cu_k, None, None, None, None, max(lens_q), max(lens_k), p, scale, False, True, -1, -1, 0.0, True, None)
+    torch.manual_seed(123)
+    out, lse, rv, rng = be.varlen_fwd(*args)
+    assert tuple(rv.shape) == (H, tq, max(lens_k)) and rv.dtype == torch.uint8
+    torch.manual_seed(123)
+    out_b, _, rv_b, rng_b = be.varlen_fwd(*args)       # re-seeded generator => same mask, same output
+    assert torch.equal(rng, rng_b) and torch.equal(rv, rv_b) and torch.equal(out, out_b)
+    _, _, rv_c, rng_c = be.varlen_fwd(*args)           # the generator's offset advanced => another mask
+    assert not torch.equal(rng, rng_c) and not torch.equal(rv, rv_c)
+    dq, dk, dv, _ = be.varlen_bwd(do, q, k, v, out, lse, None, None, None, cu_q, cu_k, None, max(lens_q), max(lens_k), p, scale,
+                                  False, True, -1, -1, 0.0, False, None, rng)
+    for b in range(len(lens_q)):
+        qs, ks = slice(int(cu_q[b]), int(cu_q[b + 1])), slice(int(cu_k[b]), int(cu_k[b + 1]))
+        keep = _keep(rv[:, qs, : lens_k[b]], p).cpu().numpy()[None]
+        o_ref, _ = orc.attention_fwd(q[qs][None], k[ks][None], v[ks][None], scale, True, (-1, -1), 0.0, None, p, keep)
+        assert max_abs(out[qs].float().cpu(), torch.from_numpy(o_ref[0])) < 3e-2
+        rq, rk, rvv, _ = orc.attention_bwd(do[qs][None], q[qs][None], k[ks][None], v[ks][None], None, None, scale, True, (-1, -1),
+                                           0.0, None, p, keep)
+        for got, ref in ((dq[qs], rq[0]), (dk[ks], rk[0]), (dv[ks], rvv[0])):
+            assert max_abs(got.float().cpu(), torch.from_numpy(ref)) < 6e-2 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_dropout_random_bytes_are_uniform_and_uncorrelated(be):
+    torch.manual_seed(9)
+    B, S, H, d = 2, 512, 4, 64
+    q = torch.randn(B, S, H, d, device="cuda", dtype=torch.bfloat16)
+    _, _, rv, _ = be.fwd(q, q, q, None, None, 0.1, d ** -0.5, False, -1, -1, 0.0, True, None)
+    x = rv.cpu().numpy().astype(np.int64)
+    n = x.size
+    hist = np.bincount(x.ravel(), minlength=256)
+    assert np.abs(hist / n - 1 / 256).max() < 5 * math.sqrt((1 / 256) / n)       # every byte value equally likely (5 sigma)
+    xf = (x - 127.5) / 73.9
+    for a, b in ((xf[..., :, :-1], xf[..., :, 1:]), (xf[..., :-1, :], xf[..., 1:, :]), (xf[:, :-1], xf[:, 1:]), (xf[:-1], xf[1:]),
+                 (xf[..., :, :-4], xf[..., :, 4:]), (xf[..., :-4, :], xf[..., 4:, :])):
+        assert abs((a * b).mean()) < 5 / math.sqrt(a.size)                       # neighbours along keys / queries / heads / batch
+
+
+def test_dropout_through_the_public_interface():
+    from flash_attn_amd import flash_attn_interface as fi
+    from oracle import attention_oracle as orc
+    torch.manual_seed(11)
+    B, S, H, d, p = 2, 160, 4, 64, 0.17
+    q = torch.randn(B, S, H, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    k = torch.randn(B, S, 2, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    v = torch.randn(B, S, 2, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    out, lse, rv = fi.flash_attn_func(q, k, v, dropout_p=p, causal=True, return_attn_probs=True)
+    g = torch.randn_like(out)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), g)
+    keep = _keep(rv, p).cpu().numpy()
+    o_ref, _ = orc.attention_fwd(q, k, v, None, True, (-1, -1), 0.0, None, p, keep)
+    rq, rk, rvv, _ = orc.attention_bwd(g, q, k, v, None, None, None, True, (-1, -1), 0.0, None, p, keep)
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 3e-2
+    for got, ref in ((dq, rq), (dk, rk), (dv, rvv)):
+        assert max_abs(got.float().cpu(), torch.from_numpy(ref)) < 6e-2 * max(1.0, float(np.abs(ref).max()))
+    with pytest.raises(RuntimeError, match="return_softmax"):
+        fi._flash_attn_forward(q.detach(), k.detach(), v.detach(), 0.0, d ** -0.5, True, -1, -1, 0.0, None, True)

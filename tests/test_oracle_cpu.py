@@ -100,3 +100,17 @@ def test_flop_model_matches_survey_table():
     assert abs(orc.attention_flops(8, 16, 2048, 2048, 64) / 1e12 - 0.1374) < 1e-4
     assert abs(orc.attention_flops(4, 32, 4096, 4096, 128, causal=True) / 1e12 - 0.5498) < 2e-4
     assert abs(orc.attention_flops(2, 32, 8192, 8192, 128, causal=True, window=(1024, 0)) / 1e12 - 0.2579) < 2e-4
+
+
+@pytest.mark.parametrize("name", ["drop_full_d64", "drop_causal_gqa_d128", "drop_local_d64"])
+def test_oracle_dropout_matches_reference_golden(dropout_cases, name):
+    """dropout branch of the oracle == reference attention_ref(dropout_p, dropout_mask) + autograd."""
+    case = dropout_cases[name]
+    B, Sq, Sk, H, Hk, D, causal, wl, wr = [int(x) for x in case["meta"]]
+    pd = float(case["p"][0])
+    q, k, v, do = _inputs(case)
+    out, _ = orc.attention_fwd(q, k, v, None, bool(causal), (wl, wr), 0.0, None, pd, case["keep"])
+    assert np.abs(out - case["out"]).max() < 2e-5
+    dq, dk, dv, _ = orc.attention_bwd(do, q, k, v, None, None, None, bool(causal), (wl, wr), 0.0, None, pd, case["keep"])
+    for got, ref in ((dq, case["dq"]), (dk, case["dk"]), (dv, case["dv"])):
+        assert np.abs(got - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
