@@ -63,6 +63,29 @@ template <typename K> void fill_dropout(K& k, float p_dropout, const uint64_t* r
   }
 }
 
+// Split-KV schedule of the decode path (reference num_splits_heuristic, flash_api.cpp:275-347, re-derived for 256 CUs
+// with two workgroups each): split only single-block query lengths whose (batch x head) grid leaves most CUs idle,
+// into the fewest key splits that give every CU two workgroups; a split is a whole number of 64-key tiles.
+int choose_splits(const FaFwdParams* a, int& split_tiles) {
+  const int tiles = (a->seqlen_k + 63) / 64;
+  split_tiles = tiles;
+  if (a->seqlen_q > 128 || tiles < 2 || a->num_splits == 1) return 1;
+  int want = a->num_splits;
+  if (want <= 0) {
+    const long units = (long)a->b * a->h;
+    if (units >= 384) return 1;
+    want = (int)((512 + units - 1) / units);
+    want = std::min(want, std::max(1, tiles / 4));  // at least 4 tiles (256 keys) per split
+  }
+  want = std::max(1, std::min(std::min(want, 64), tiles));
+  split_tiles = (tiles + want - 1) / want;
+  return (tiles + split_tiles - 1) / split_tiles;
+}
+int64_t splitkv_bytes(const FaFwdParams* a, int n_splits) {
+  if (n_splits <= 1) return 0;
+  return (int64_t)n_splits * a->b * a->h * a->seqlen_q * (a->d + 1) * (int64_t)sizeof(float);
+}
+
 int check_common(int b, int h, int h_k, int d, int dtype, float softcap) {
   if (b <= 0) return fail(FA_ERR_INVALID_ARGUMENT, "batch size must be positive");
   if (h <= 0 || h_k <= 0 || h % h_k != 0)
@@ -97,10 +120,11 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   if (int rc = check_dropout(a->p_dropout, a->rng_state)) return rc;
   if (kvcache && a->p_dropout > 0.f) return fail(FA_ERR_INVALID_ARGUMENT, "fa_fwd_kvcache is an inference path: p_dropout must be 0");
   if (a->randval && !(a->p_dropout > 0.f)) return fail(FA_ERR_INVALID_ARGUMENT, "return_softmax is only supported when p_dropout > 0.0");
-  if (a->num_splits > 1) return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: num_splits > 1 is not built yet");
+  if (a->num_splits > 1 && !kvcache) return fail(FA_ERR_INVALID_ARGUMENT, "num_splits > 1 is not supported");
   if (a->seqlen_q == 0 || a->total_q == 0) return FA_OK;  // nothing to write
 
   fa::FwdK k{};
+  k.n_splits = 1;
   k.q = a->q; k.k = a->k; k.v = a->v; k.o = a->o; k.lse = a->softmax_lse;
   k.q_bs = a->q_batch_stride; k.q_rs = a->q_row_stride; k.q_hs = a->q_head_stride;
   k.k_bs = a->k_batch_stride; k.k_rs = a->k_row_stride; k.k_hs = a->k_head_stride;
@@ -146,15 +170,32 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     if (a->d == 128) nw = (tiles >= 48 && a->seqlen_q >= 512) ? 38 : (a->seqlen_q > 128 ? 34 : 4);
     else nw = (a->seqlen_q > 128) ? 34 : 4;
   }
+  // decode: split the keys over several workgroups when (batch x heads) cannot fill the chip
+  if (kvcache) {
+    int split_tiles = 0;
+    const int ns = choose_splits(a, split_tiles);
+    if (ns > 1) {
+      const int64_t need = splitkv_bytes(a, ns);
+      if (a->workspace && a->workspace_bytes >= need) {
+        k.n_splits = ns; k.split_tiles = split_tiles;
+        k.o_accum = (float*)a->workspace;
+        k.lse_accum = k.o_accum + (int64_t)ns * a->b * a->h * a->seqlen_q * a->d;
+        nw = 4;
+      } else if (a->num_splits > 1) {
+        return fail(FA_ERR_WORKSPACE, "fa_fwd_kvcache: num_splits = %d needs a workspace of %lld bytes (fa_fwd_workspace_bytes)", a->num_splits, (long long)need);
+      }  // auto schedule without a workspace: run unsplit
+    }
+  }
   // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
-  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f);
+  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && k.n_splits == 1;
   const bool il = (nw == 34 || nw == 38) && plain;
   if ((nw == 34 || nw == 38) && !il) nw -= 30;
   const int bm = il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
   k.nmb = (a->seqlen_q + bm - 1) / bm;
-  fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb, k.n_units, k.unit_size, k.unit_hpx);
-  const int rc = il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, a->d, nw - 30, (hipStream_t)stream)
+  fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb * k.n_splits, k.n_units, k.unit_size, k.unit_hpx);
+  int rc = il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, a->d, nw - 30, (hipStream_t)stream)
                     : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
+  if (rc == 0 && k.n_splits > 1) rc = fa::launch_splitkv_combine(k, a->dtype == FA_DTYPE_BF16, a->d, (hipStream_t)stream);
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
   if (rc != 0) return fail(FA_ERR_LAUNCH, "forward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   return FA_OK;
@@ -260,8 +301,9 @@ int fa_set_rng_state(uint64_t seed, uint64_t offset, uint64_t* rng_state, void* 
 }
 
 int64_t fa_fwd_workspace_bytes(const FaFwdParams* params) {
-  (void)params;
-  return 0;  // no split-KV schedule is built yet (num_splits <= 1)
+  if (!params) return 0;
+  int split_tiles = 0;
+  return splitkv_bytes(params, choose_splits(params, split_tiles));
 }
 
 int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {

@@ -76,8 +76,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   // ---- which (batch, head, query block) -------------------------------------------------------
   const int w = xcd_interleave(blockIdx.x, p.n_units, p.unit_size, p.unit_hpx);
   if (w < 0) return;
-  const int bh = w / p.nmb;
-  const int mbr = w - bh * p.nmb;
+  const int nmbs = p.nmb * p.n_splits;  // n_splits >= 1: key splits of one query block are adjacent work items
+  const int bh = w / nmbs;
+  int mbr = w - bh * nmbs;
+  const int split = mbr % p.n_splits;
+  mbr /= p.n_splits;
   const int m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
   const int b = bh / p.h;
   const int h = bh - b * p.h;
@@ -119,8 +122,12 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   int kmax = sk - 1, kmin = 0;
   if (p.wr >= 0) kmax = min(kmax, blk_last + shift + p.wr);
   if (p.wl >= 0) kmin = max(0, m0 + shift - p.wl);
-  const int n_min = kmin / BN;
-  const int n_max = (kmax >= kmin) ? (kmax / BN + 1) : n_min;
+  int n_min = kmin / BN;
+  int n_max = (kmax >= kmin) ? (kmax / BN + 1) : n_min;
+  if (p.n_splits > 1) {  // this workgroup's share of the key tiles (may be empty)
+    n_min = max(n_min, split * p.split_tiles);
+    n_max = max(n_min, min(n_max, (split + 1) * p.split_tiles));
+  }
   const int n_tiles = n_max - n_min;
 
   const int w_row0 = m0 + wave * 32;
@@ -451,6 +458,23 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   const float l_tot = half_sum(l_run);
   const bool dead = (l_tot == 0.f) || (l_tot != l_tot);  // no visible key (softmax.h:179-180)
   const float inv = (dead ? 1.f : 1.f / l_tot) * (drop ? p.rp_keep : 1.f);
+  if (p.n_splits > 1) {  // partial result of this key split, fp32, merged by fa_splitkv_combine_kernel
+    if (row_valid) {
+      const int64_t prow = (((int64_t)split * p.b + b) * p.h + h) * p.sq + my_row;
+      float* orow = p.o_accum + prow * D;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 ov;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) ov[jj] = o_acc[db][4 * g + jj] * inv;
+          *reinterpret_cast<f32x4*>(orow + 32 * db + 8 * g + 4 * hi) = ov;
+        }
+      if (hi == 0) p.lse_accum[prow] = dead ? -INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
+    }
+    return;
+  }
   if (row_valid) {
     E* orow = op + (int64_t)my_row * p.o_rs;
 #pragma unroll
@@ -464,6 +488,56 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
       }
     if (hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
   }
+}
+
+// Merge of the split-KV partials (reference combine_attn_seqk_parallel, flash_fwd_kernel.h:1117-1299): one wave per
+// (batch, head, query row); lse = log sum_s exp(lse_s), out = sum_s exp(lse_s - lse) * out_s.
+template <typename E, int D>
+__global__ void __launch_bounds__(256) fa_splitkv_combine_kernel(const FwdK p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t rows = (int64_t)p.b * p.h * p.sq;
+  if (r >= rows) return;
+  const int i = (int)(r % p.sq);
+  const int h = (int)((r / p.sq) % p.h);
+  const int b = (int)(r / ((int64_t)p.sq * p.h));
+  const float lse_s = lane < p.n_splits ? p.lse_accum[(int64_t)lane * rows + r] : -INFINITY;
+  float mx = lse_s;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  const bool dead = (mx == -INFINITY);
+  float e = dead ? 0.f : __expf(lse_s - mx);
+  float sum = e;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+  const float wgt = dead ? 0.f : e / sum;  // exp(lse_s - lse)
+  constexpr int EPL = D / 64;              // output elements per lane
+  float acc[EPL];
+#pragma unroll
+  for (int t = 0; t < EPL; ++t) acc[t] = 0.f;
+  for (int s = 0; s < p.n_splits; ++s) {
+    const float ws = __shfl(wgt, s);
+    if (ws != 0.f) {
+      const float* src = p.o_accum + ((int64_t)s * rows + r) * D + lane * EPL;
+#pragma unroll
+      for (int t = 0; t < EPL; ++t) acc[t] += ws * src[t];
+    }
+  }
+  E* dst = (E*)p.o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + (int64_t)h * p.o_hs + lane * EPL;
+#pragma unroll
+  for (int t = 0; t < EPL; ++t) dst[t] = (E)acc[t];
+  if (lane == 0) p.lse[((int64_t)b * p.h + h) * p.sq + i] = dead ? INFINITY : (mx + __logf(sum));
+}
+
+int launch_splitkv_combine(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
+  const int64_t rows = (int64_t)p.b * p.h * p.sq;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype_bf16 && d == 128) hipLaunchKernelGGL((fa_splitkv_combine_kernel<__bf16, 128>), grid, block, 0, stream, p);
+  else if (dtype_bf16 && d == 64) hipLaunchKernelGGL((fa_splitkv_combine_kernel<__bf16, 64>), grid, block, 0, stream, p);
+  else if (d == 128) hipLaunchKernelGGL((fa_splitkv_combine_kernel<_Float16, 128>), grid, block, 0, stream, p);
+  else if (d == 64) hipLaunchKernelGGL((fa_splitkv_combine_kernel<_Float16, 64>), grid, block, 0, stream, p);
+  else return -2;
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 __global__ void fa_set_rng_kernel(uint64_t seed, uint64_t offset, uint64_t* dst) {

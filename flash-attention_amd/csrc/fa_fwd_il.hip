@@ -601,7 +601,7 @@ int launch_fwd_il(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stre
   const char* sched_env = getenv("FA_IL_SCHED");
   const int sched = sched_env ? atoi(sched_env) : 3;
   if ((uint64_t)64 * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 31)) return -2;
-  if (p.softcap > 0.f || p.alibi != nullptr) return -2;
+  if (p.softcap > 0.f || p.alibi != nullptr || p.rng != nullptr || p.n_splits > 1) return -2;
 #define FA_IL_CASE(E_, D_, NW_)                                                                       \
   if (d == D_ && nw == NW_)                                                                           \
     return sched == 0 ? launch_fwd_il_t<E_, D_, NW_, 0>(p, stream) : launch_fwd_il_t<E_, D_, NW_, 3>(p, stream);

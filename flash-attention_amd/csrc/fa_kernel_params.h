@@ -35,6 +35,11 @@ struct FwdK {
   float scale_log2;          // softmax_scale * log2(e)
   float softcap;             // 0 = off
   float rescale_thr;         // O rescale deferred until a row max grows by more than this (log2 units)
+  // split-KV (decode): n_splits > 1 => workgroup (.., split) scans key tiles [split*split_tiles, (split+1)*split_tiles) and
+  // writes a normalised fp32 partial output + its log-sum-exp; fa_splitkv_combine_kernel merges them
+  int32_t n_splits, split_tiles;
+  float* o_accum;            // (n_splits, b, h, sq, d) fp32
+  float* lse_accum;          // (n_splits, b, h, sq) fp32, -inf for an empty partial
   // dropout (rng == nullptr => off): element (b, h, i, j) is kept iff its random byte <= drop_thr8 (fa_device.h drop_bytes)
   const uint64_t* rng;       // device {seed, offset}
   uint8_t* randval;          // optional: random bytes out

@@ -481,6 +481,13 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tenso
   a.dtype = dtype_code(q);
   a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
   a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap;
+  a.num_splits = (int)num_splits;
+  Tensor ws;  // split-KV partials (reference softmax_lse_accum / out_accum, flash_api.cpp:320-345), freed in stream order
+  const int64_t ws_bytes = fa_fwd_workspace_bytes(&a);
+  if (ws_bytes > 0) {
+    ws = at::empty({ws_bytes}, q.options().dtype(at::kByte));
+    a.workspace = ws.data_ptr(); a.workspace_bytes = ws_bytes;
+  }
   fa_check(fa_fwd_kvcache(&a, cur_stream(q)));
   if (swap) {
     Tensor o2 = out.transpose(1, 2).reshape({B, 1, H, D});

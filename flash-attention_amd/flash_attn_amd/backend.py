@@ -433,6 +433,11 @@ def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_,
         a.dtype = _dtype_code(q)
         a.is_causal, a.window_left, a.window_right = int(bool(is_causal)), int(window_size_left), int(window_size_right)
         a.softmax_scale, a.softcap = float(softmax_scale), float(softcap)
+        a.num_splits = int(num_splits)
+        ws_bytes = lib.fa_fwd_workspace_bytes(C.byref(a))  # split-KV partials (0 when the keys are not split)
+        if ws_bytes > 0:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=q.device)
+            a.workspace, a.workspace_bytes = _ptr(ws), ws_bytes
         _cabi.check(lib.fa_fwd_kvcache(C.byref(a), C.c_void_p(_stream_ptr(q.device))))
     if swap:
         o2 = out.transpose(1, 2).reshape(B, 1, H, D)

@@ -96,3 +96,29 @@ def test_kvcache_interface_and_errors():
         fi.flash_attn_with_kvcache(q, kc, vc, rotary_cos=torch.zeros(8, 16, device="cuda"), rotary_sin=torch.zeros(8, 16, device="cuda"))
     with pytest.raises(RuntimeError, match="divisible by 256"):
         fi.flash_attn_with_kvcache(q, kc[:, :128].contiguous(), vc[:, :128].contiguous(), block_table=torch.zeros(2, 1, dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("num_splits", [0, 1, 2, 7, 64])
+@pytest.mark.parametrize("sq,causal,paged", [(1, False, False), (1, False, True), (6, True, False), (33, True, True)])
+def test_kvcache_split_kv(kv, sq, causal, paged, num_splits):
+    """Split-KV decode: every split count (0 = heuristic) gives the unsplit result up to fp32 merge rounding, including
+    splits that hold no key of a short sequence."""
+    torch.manual_seed(3)
+    B, H, hk, d, cap = 2, 16, 4, 128, 4096
+    q = torch.randn(B, sq, H, d, device="cuda", dtype=torch.bfloat16)
+    lens = torch.tensor([cap - 7, 300], dtype=torch.int32, device="cuda")
+    if paged:
+        page, per = 256, cap // 256
+        kc = torch.randn(B * per + 3, page, hk, d, device="cuda", dtype=torch.bfloat16)
+        vc = torch.randn_like(kc)
+        table = torch.randperm(B * per + 3, device="cuda")[: B * per].reshape(B, per).to(torch.int32)
+        k_log, v_log = kc[table.long()].reshape(B, cap, hk, d), vc[table.long()].reshape(B, cap, hk, d)
+    else:
+        kc = torch.randn(B, cap, hk, d, device="cuda", dtype=torch.bfloat16)
+        vc = torch.randn_like(kc)
+        table, k_log, v_log = None, kc, vc
+    out, lse = kv.fwd_kvcache(q, kc, vc, None, None, lens, None, None, None, None, table, None, None, d ** -0.5, causal, -1, -1, 0.0, True,
+                              num_splits)
+    o_ref, l_ref = _oracle(q, k_log, v_log, lens.cpu().numpy(), causal)
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 2e-2
+    assert max_abs(lse.cpu(), torch.from_numpy(l_ref).float()) < 2e-3
