@@ -110,8 +110,11 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     return fail(FA_ERR_INVALID_ARGUMENT, varlen ? "fa_varlen_fwd needs cu_seqlens_q and cu_seqlens_k"
                                                 : "fa_fwd takes fixed-length batches (cu_seqlens must be NULL)");
   if (a->seqlen_q < 0 || a->seqlen_k < 0) return fail(FA_ERR_INVALID_ARGUMENT, "negative sequence length");
-  if (!kvcache && (a->cache_batch_idx || a->block_table || a->seqused_k_add))
-    return fail(FA_ERR_INVALID_ARGUMENT, "cache_batch_idx / block_table / seqused_k_add are fa_fwd_kvcache arguments");
+  if (!kvcache && (a->cache_batch_idx || a->block_table || a->seqused_k_add || a->leftpad_k))
+    return fail(FA_ERR_INVALID_ARGUMENT, "cache_batch_idx / block_table / seqused_k_add / leftpad_k are fa_fwd_kvcache arguments");
+  if (a->leftpad_k && a->block_table)
+    return fail(FA_ERR_INVALID_ARGUMENT, "We don't support Paged KV and leftpad_k running at the same time yet");
+  if (a->leftpad_k && !a->seqused_k) return fail(FA_ERR_INVALID_ARGUMENT, "leftpad_k needs seqused_k (cache_seqlens)");
   if (a->block_table) {
     if (a->cache_batch_idx) return fail(FA_ERR_INVALID_ARGUMENT, "Paged KVcache does not support cache_batch_idx");
     if (a->page_block_size <= 0 || a->page_block_size % 256 != 0)
@@ -132,7 +135,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   k.o_bs = a->o_batch_stride; k.o_rs = a->o_row_stride; k.o_hs = a->o_head_stride;
   k.cu_q = a->cu_seqlens_q; k.cu_k = a->cu_seqlens_k; k.seqused_k = a->seqused_k;
   k.kv_batch_idx = a->cache_batch_idx; k.block_table = a->block_table; k.block_table_bs = a->block_table_batch_stride;
-  k.page_size = a->page_block_size; k.seqused_add = a->seqused_k_add;
+  k.page_size = a->page_block_size; k.seqused_add = a->seqused_k_add; k.leftpad_k = a->leftpad_k;
   k.alibi = a->alibi_slopes; k.alibi_bs = a->alibi_batch_stride;
   k.b = a->b; k.h = a->h; k.h_k = a->h_k; k.hk_ratio = a->h / a->h_k;
   k.sq = a->seqlen_q; k.sk = a->seqlen_k; k.total_q = a->total_q;
@@ -264,6 +267,7 @@ int fa_abi_version(void) { return FA_ABI_VERSION; }
 int fa_sizeof_fwd_params(void) { return (int)sizeof(FaFwdParams); }
 int fa_sizeof_bwd_params(void) { return (int)sizeof(FaBwdParams); }
 int fa_sizeof_kvappend_params(void) { return (int)sizeof(FaKvAppendParams); }
+int fa_sizeof_rotary_params(void) { return (int)sizeof(FaRotaryParams); }
 const char* fa_last_error(void) { return g_err; }
 
 int fa_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, false); }
@@ -289,6 +293,26 @@ int fa_kvcache_append(const FaKvAppendParams* a, void* stream) {
   k.b = a->b; k.s_new = a->seqlen_new; k.h_k = a->h_k; k.d = a->d;
   if (fa::launch_kv_append(k, (hipStream_t)stream) != 0)
     return fail(FA_ERR_LAUNCH, "kv append launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return FA_OK;
+}
+
+int fa_rotary(const FaRotaryParams* a, void* stream) {
+  if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+  g_err[0] = 0;
+  if (!a->x || !a->y || !a->cos || !a->sin) return fail(FA_ERR_INVALID_ARGUMENT, "x, y, cos and sin must be non-NULL");
+  if (a->dtype != FA_DTYPE_FP16 && a->dtype != FA_DTYPE_BF16) return fail(FA_ERR_INVALID_ARGUMENT, "FlashAttention only supports fp16 and bf16 data type");
+  if (a->d <= 0 || a->d % 8 != 0) return fail(FA_ERR_INVALID_ARGUMENT, "head dimension must be a multiple of 8");
+  if (a->rotary_dim <= 0 || a->rotary_dim > a->d) return fail(FA_ERR_INVALID_ARGUMENT, "rotary_dim must be <= headdim");
+  if (a->rotary_dim % 16 != 0) return fail(FA_ERR_INVALID_ARGUMENT, "Only rotary dimensions divisible by 16 are currently supported");
+  if (a->seqlen_ro <= 0) return fail(FA_ERR_INVALID_ARGUMENT, "cos/sin must have at least one row");
+  fa::RotaryK k{};
+  k.x = a->x; k.y = a->y; k.cos = a->cos; k.sin = a->sin; k.offsets = a->seqlen_offsets;
+  k.x_bs = a->x_batch_stride; k.x_rs = a->x_row_stride; k.x_hs = a->x_head_stride;
+  k.y_bs = a->y_batch_stride; k.y_rs = a->y_row_stride; k.y_hs = a->y_head_stride; k.cos_rs = a->cos_row_stride;
+  k.b = a->b; k.s = a->s; k.h = a->h; k.d = a->d; k.rotary_dim = a->rotary_dim; k.seqlen_ro = a->seqlen_ro;
+  k.interleaved = a->interleaved; k.per_token = a->per_token;
+  if (fa::launch_rotary(k, a->dtype == FA_DTYPE_BF16, (hipStream_t)stream) != 0)
+    return fail(FA_ERR_LAUNCH, "rotary launch failed: %s", hipGetErrorString(hipGetLastError()));
   return FA_OK;
 }
 

@@ -105,7 +105,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
     k_boff = 0;
     v_boff = 0;
   }
-  if (p.seqused_k) sk = p.seqused_k[b] + p.seqused_add;
+  if (p.seqused_k) {  // keys in use, never beyond the addressable capacity; a left-padded cache starts at row leftpad_k[b]
+    const int lp = p.leftpad_k ? p.leftpad_k[b] : 0;
+    sk = max(0, min(p.seqused_k[b] + p.seqused_add, p.sk) - lp);
+    k_row0 += lp;
+  }
   const int m0 = m_block * BM;
   if (m0 >= sq) return;
 
@@ -537,6 +541,70 @@ int launch_splitkv_combine(const FwdK& p, int dtype_bf16, int d, hipStream_t str
   else if (d == 128) hipLaunchKernelGGL((fa_splitkv_combine_kernel<_Float16, 128>), grid, block, 0, stream, p);
   else if (d == 64) hipLaunchKernelGGL((fa_splitkv_combine_kernel<_Float16, 64>), grid, block, 0, stream, p);
   else return -2;
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Rotary embedding (reference csrc/flash_attn/src/rotary.h, flash_fwd_kernel.h:640-720): one thread rotates 8 channel
+// pairs of one (batch, row, head) = two 16-B chunks: interleaved pairs (2t, 2t+1) -> two adjacent chunks; non-interleaved
+// pairs (t, t + rotary_dim/2) -> chunk c and chunk c + rotary_dim/16.
+// Arithmetic in fp32, one rounding to the storage type; channels >= rotary_dim are copied.
+template <typename E>
+__global__ void __launch_bounds__(256) fa_rotary_kernel(const RotaryK p) {
+  using V8 = typename ElemTraits<E>::v8;
+  const int cpr = p.d / 8;                 // 16-B chunks per row
+  const int rc = p.rotary_dim / 8;         // chunks in the rotated part (even)
+  const int upr = rc / 2 + (cpr - rc);     // work units per row: chunk pairs + pass-through chunks
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)p.b * p.s * p.h * upr;
+  if (idx >= total) return;
+  const int u = (int)(idx % upr);
+  const int h = (int)((idx / upr) % p.h);
+  const int srow = (int)((idx / ((int64_t)upr * p.h)) % p.s);
+  const int b = (int)(idx / ((int64_t)upr * p.h * p.s));
+  const E* xr = (const E*)p.x + (int64_t)b * p.x_bs + (int64_t)srow * p.x_rs + (int64_t)h * p.x_hs;
+  E* yr = (E*)p.y + (int64_t)b * p.y_bs + (int64_t)srow * p.y_rs + (int64_t)h * p.y_hs;
+  if (u >= rc / 2) {  // channels past rotary_dim
+    const int c = rc + (u - rc / 2);
+    *reinterpret_cast<u32x4*>(yr + 8 * c) = *reinterpret_cast<const u32x4*>(xr + 8 * c);
+    return;
+  }
+  int pos = (p.offsets ? p.offsets[b] : 0) + (p.per_token ? srow : 0);
+  pos = min(pos, p.seqlen_ro - 1);
+  const E* cr = (const E*)p.cos + (int64_t)pos * p.cos_rs;
+  const E* sr = (const E*)p.sin + (int64_t)pos * p.cos_rs;
+  const int c0 = p.interleaved ? 2 * u : u;           // first chunk of the pair
+  const int c1 = p.interleaved ? 2 * u + 1 : u + rc / 2;
+  const V8 a = bitcast_u32x4<V8>(*reinterpret_cast<const u32x4*>(xr + 8 * c0));
+  const V8 bb = bitcast_u32x4<V8>(*reinterpret_cast<const u32x4*>(xr + 8 * c1));
+  const V8 cv = bitcast_u32x4<V8>(*reinterpret_cast<const u32x4*>(cr + 8 * u));  // angles 8u .. 8u+7
+  const V8 sv = bitcast_u32x4<V8>(*reinterpret_cast<const u32x4*>(sr + 8 * u));
+  V8 oa, ob;
+  if (p.interleaved) {  // channel 16u + 2t pairs with 16u + 2t + 1, angle 8u + t
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float x1 = (float)(t < 4 ? a[2 * t] : bb[2 * t - 8]), x2 = (float)(t < 4 ? a[2 * t + 1] : bb[2 * t - 7]);
+      const float c = (float)cv[t], sn = (float)sv[t];
+      const E o1 = (E)(x1 * c - x2 * sn), o2 = (E)(x1 * sn + x2 * c);
+      if (t < 4) { oa[2 * t] = o1; oa[2 * t + 1] = o2; } else { ob[2 * t - 8] = o1; ob[2 * t - 7] = o2; }
+    }
+  } else {  // channel 8u + t pairs with 8u + t + rotary_dim/2, angle 8u + t
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float x1 = (float)a[t], x2 = (float)bb[t], c = (float)cv[t], sn = (float)sv[t];
+      oa[t] = (E)(x1 * c - x2 * sn);
+      ob[t] = (E)(x1 * sn + x2 * c);
+    }
+  }
+  *reinterpret_cast<V8*>(yr + 8 * c0) = oa;
+  *reinterpret_cast<V8*>(yr + 8 * c1) = ob;
+}
+int launch_rotary(const RotaryK& p, int dtype_bf16, hipStream_t stream) {
+  const int cpr = p.d / 8, rc = p.rotary_dim / 8;
+  const int64_t total = (int64_t)p.b * p.s * p.h * (rc / 2 + (cpr - rc));
+  if (total <= 0) return 0;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dtype_bf16) hipLaunchKernelGGL(fa_rotary_kernel<__bf16>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(fa_rotary_kernel<_Float16>, grid, block, 0, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -78,7 +78,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   if (p.block_table) { k_boff = 0; v_boff = 0; }  // paged cache: the page index supplies the first-dimension offset
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; o_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
-  if (p.seqused_k) sk = p.seqused_k[b] + p.seqused_add;
+  if (p.seqused_k) {  // keys in use, never beyond the addressable capacity; a left-padded cache starts at row leftpad_k[b]
+    const int lp = p.leftpad_k ? p.leftpad_k[b] : 0;
+    sk = max(0, min(p.seqused_k[b] + p.seqused_add, p.sk) - lp);
+    k_row0 += lp;
+  }
   const int m0 = m_block * BM;
   if (m0 >= sq) return;
 

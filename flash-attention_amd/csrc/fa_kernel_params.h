@@ -23,6 +23,7 @@ struct FwdK {
   int64_t block_table_bs;
   int32_t page_size;             // keys per page (multiple of 64)
   int32_t seqused_add;           // added to seqused_k (freshly appended keys)
+  const int32_t* leftpad_k;      // optional: first cache row of each batch entry (seqused_k counts from row 0)
   const float* alibi;        // optional
   int64_t alibi_bs;
   int32_t b, h, h_k, hk_ratio;

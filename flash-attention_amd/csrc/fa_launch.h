@@ -34,6 +34,12 @@ struct KvAppendK {
 };
 int launch_kv_append(const KvAppendK& p, hipStream_t stream);
 // Software-pipelined forward (fa_fwd_il.hip); nw = 4 or 8 waves per workgroup.  No softcap / ALiBi variant.
+struct RotaryK {
+  const void* x; void* y; const void* cos; const void* sin; const int32_t* offsets;
+  int64_t x_bs, x_rs, x_hs, y_bs, y_rs, y_hs, cos_rs;
+  int32_t b, s, h, d, rotary_dim, seqlen_ro, interleaved, per_token;
+};
+int launch_rotary(const RotaryK& p, int dtype_bf16, hipStream_t stream);
 int launch_splitkv_combine(const FwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_set_rng(uint64_t seed, uint64_t offset, uint64_t* dst, hipStream_t stream);
 int launch_fwd_il(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream);

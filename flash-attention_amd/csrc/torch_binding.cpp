@@ -385,15 +385,30 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tenso
                                     OptTensor& alibi_slopes_, OptTensor& out_, const double softmax_scale, bool is_causal,
                                     int64_t window_size_left, int64_t window_size_right, const double softcap,
                                     bool is_rotary_interleaved, int64_t num_splits) {
-  (void)is_rotary_interleaved; (void)num_splits;
   TORCH_CHECK(q.dtype() == at::kHalf || q.dtype() == at::kBFloat16, "FlashAttention only support fp16 and bf16 data type");
   TORCH_CHECK(kcache.dtype() == q.dtype(), "query and key must have the same dtype");
   TORCH_CHECK(vcache.dtype() == q.dtype(), "query and value must have the same dtype");
   CHECK_DEVICE(q); CHECK_DEVICE(kcache); CHECK_DEVICE(vcache);
   TORCH_CHECK(q.stride(-1) == 1 && kcache.stride(-1) == 1 && vcache.stride(-1) == 1, "Input tensor must have contiguous last dimension");
-  TORCH_CHECK(!rotary_cos_.has_value() && !rotary_sin_.has_value(), "libfa_gfx950: rotary embedding in fwd_kvcache is not built");
-  TORCH_CHECK(!leftpad_k_.has_value(), "libfa_gfx950: leftpad_k is not built");
   const bool paged = block_table_.has_value();
+  if (leftpad_k_.has_value()) {  // flash_api.cpp:1377-1386
+    TORCH_CHECK(!paged, "We don't support Paged KV and leftpad_k running at the same time yet");
+    TORCH_CHECK(leftpad_k_->dtype() == at::kInt, "leftpad_k must have dtype int32");
+    CHECK_DEVICE(*leftpad_k_); TORCH_CHECK(leftpad_k_->is_contiguous(), "leftpad_k must be contiguous");
+    CHECK_SHAPE(*leftpad_k_, q.size(0));
+    TORCH_CHECK(seqlens_k_.has_value(), "leftpad_k needs seqlens_k (cache_seqlens)");
+  }
+  if (rotary_cos_.has_value()) {  // flash_api.cpp:1455-1477
+    TORCH_CHECK(k_.has_value(), "If rotary cos/sin are provided, new key / value to be appended to KV cache must also be provided");
+    TORCH_CHECK(rotary_sin_.has_value(), "If rotary cos is provided, rotary sin must also be provided");
+    const Tensor &rc = *rotary_cos_, &rs = *rotary_sin_;
+    CHECK_DEVICE(rc); CHECK_DEVICE(rs);
+    TORCH_CHECK(rc.dim() == 2 && rs.sizes() == rc.sizes(), "rotary_cos and rotary_sin must both be (seqlen_ro, rotary_dim / 2)");
+    TORCH_CHECK(2 * rc.size(1) <= q.size(3), "rotary_dim must be <= headdim");
+    TORCH_CHECK((2 * rc.size(1)) % 16 == 0, "Only rotary dimensions divisible by 16 are currently supported");
+    TORCH_CHECK(rc.dtype() == q.dtype() && rs.dtype() == q.dtype(), "rotary_cos/sin must have the same dtype as query");
+    TORCH_CHECK(rc.stride(-1) == 1 && rs.stride(-1) == 1 && rc.stride(0) == rs.stride(0), "rotary_cos/sin must have contiguous last dimension and equal row strides");
+  }
   if (paged) {
     TORCH_CHECK(!cache_batch_idx_.has_value(), "Paged KVcache does not support cache_batch_idx");
     CHECK_DEVICE(*block_table_);
@@ -425,11 +440,39 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tenso
   if (Sq == 1 && !alibi_slopes_.has_value()) is_causal = false;  // flash_api.cpp:1340
   if (is_causal) window_size_right = 0;
 
-  int64_t s_new = 0;
+  int64_t s_new = k_.has_value() ? k_->size(1) : 0;
+  if (paged && seqlens_k_.has_value()) {  // the reference's guard (flash_api.cpp:1433-1447); costs a device->host sync
+    const int64_t need = seqlens_k_->max().item<int>() + s_new;
+    TORCH_CHECK(need <= Sk, "Paged KV cache: max(seqlens_k)", s_new > 0 ? " + seqlen_knew" : "", " (= ", need,
+                ") exceeds the capacity addressable by block_table (max_num_blocks_per_seq * page_block_size = ", Sk, ")");
+  }
+  // rotary: new keys at positions cache_seqlens + i; queries too if causal / local, else all at cache_seqlens
+  // (flash_attn_interface.py:1530-1541)
+  Tensor q_in = q, k_rot;
+  auto rotate = [&](const Tensor& x, bool per_token) {
+    Tensor y = at::empty_like(x);
+    FaRotaryParams r{};
+    r.x = x.data_ptr(); r.y = y.data_ptr(); r.cos = rotary_cos_->data_ptr(); r.sin = rotary_sin_->data_ptr();
+    r.seqlen_offsets = seqlens_k_.has_value() ? seqlens_k_->data_ptr<int>() : nullptr;
+    r.x_batch_stride = x.stride(0); r.x_row_stride = x.stride(1); r.x_head_stride = x.stride(2);
+    r.y_batch_stride = y.stride(0); r.y_row_stride = y.stride(1); r.y_head_stride = y.stride(2);
+    r.cos_row_stride = rotary_cos_->stride(0);
+    r.b = (int)x.size(0); r.s = (int)x.size(1); r.h = (int)x.size(2); r.d = (int)x.size(3);
+    r.rotary_dim = (int)(2 * rotary_cos_->size(1)); r.seqlen_ro = (int)rotary_cos_->size(0);
+    r.interleaved = is_rotary_interleaved; r.per_token = per_token; r.dtype = dtype_code(q);
+    fa_check(fa_rotary(&r, cur_stream(q)));
+    return y;
+  };
+  if (rotary_cos_.has_value()) {
+    TORCH_CHECK(k_->dim() == 4 && k_->stride(-1) == 1, "key must be 4-D with contiguous last dimension");
+    k_rot = rotate(*k_, true);
+    q_in = rotate(q, is_causal || window_size_left >= 0 || window_size_right >= 0);
+  }
+  if (Sq == 1) window_size_right = -1;  // a right bound cannot hide a key from the single, bottom-right aligned query row
   if (k_.has_value()) {  // append first (flash_fwd_kernel.h Append_KV branch)
     TORCH_CHECK(v_.has_value(), "If key is supplied, value must also be passed in");
     TORCH_CHECK(seqlens_k_.has_value(), "If key is supplied, seqlens_k must also be passed in");
-    const Tensor &kn = *k_, &vn = *v_;
+    const Tensor &kn = rotary_cos_.has_value() ? k_rot : *k_, &vn = *v_;
     TORCH_CHECK(kn.dtype() == q.dtype() && vn.dtype() == q.dtype(), "Key and value must have the same dtype as query");
     CHECK_DEVICE(kn); CHECK_DEVICE(vn); CHECK_LAST_CONTIG(kn); CHECK_LAST_CONTIG(vn);
     s_new = kn.size(1);
@@ -453,7 +496,7 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tenso
   // become the rows of the score matrix, so K/V are streamed once per KV head.
   const bool swap = Sq == 1 && H > Hk && window_size_left < 0 && !alibi_slopes_.has_value();
   const int64_t ratio = H / Hk;
-  Tensor qk = swap ? q.reshape({B, Hk, ratio, D}).transpose(1, 2) : q;  // (B, rows, heads, D)
+  Tensor qk = swap ? q_in.reshape({B, Hk, ratio, D}).transpose(1, 2) : q_in;  // (B, rows, heads, D)
   const int64_t rows = swap ? ratio : Sq, heads = swap ? Hk : H;
   Tensor out;
   if (out_.has_value() && !swap) {
@@ -476,6 +519,7 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tenso
   a.block_table = paged ? block_table_->data_ptr<int>() : nullptr;
   a.block_table_batch_stride = paged ? block_table_->stride(0) : 0;
   a.page_block_size = (int)page;
+  a.leftpad_k = leftpad_k_.has_value() ? leftpad_k_->data_ptr<int>() : nullptr;
   set_alibi(alibi_slopes_, B, H, a.alibi_slopes, a.alibi_batch_stride);
   a.b = B; a.h = heads; a.h_k = Hk; a.d = D; a.seqlen_q = (int)rows; a.seqlen_k = (int)Sk; a.total_q = B * rows;
   a.dtype = dtype_code(q);

@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-FA_ABI_VERSION = 3
+FA_ABI_VERSION = 4
 FA_DTYPE_FP16, FA_DTYPE_BF16 = 0, 1
 FA_OK, FA_ERR_INVALID_ARGUMENT, FA_ERR_UNSUPPORTED, FA_ERR_LAUNCH, FA_ERR_WORKSPACE = 0, -1, -2, -3, -4
 
@@ -34,7 +34,7 @@ class FaFwdParams(C.Structure):
         ("page_block_size", _i32), ("num_splits", _i32), ("p_dropout", _f32), ("reserved0", _i32),
         ("rng_state", _vp), ("randval", _vp),
         ("randval_batch_stride", _i64), ("randval_head_stride", _i64), ("randval_row_stride", _i64),
-        ("workspace", _vp), ("workspace_bytes", _i64),
+        ("workspace", _vp), ("workspace_bytes", _i64), ("leftpad_k", _vp),
     ]
 
 
@@ -48,6 +48,16 @@ class FaKvAppendParams(C.Structure):
         ("seqlens_k", _vp), ("cache_batch_idx", _vp), ("block_table", _vp), ("block_table_batch_stride", _i64),
         ("page_block_size", _i32), ("b", _i32), ("seqlen_new", _i32), ("h_k", _i32), ("d", _i32),
         ("dtype", _i32), ("reserved", _i32 * 2),
+    ]
+
+
+class FaRotaryParams(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("y", _vp), ("cos", _vp), ("sin", _vp), ("seqlen_offsets", _vp),
+        ("x_batch_stride", _i64), ("x_row_stride", _i64), ("x_head_stride", _i64),
+        ("y_batch_stride", _i64), ("y_row_stride", _i64), ("y_head_stride", _i64), ("cos_row_stride", _i64),
+        ("b", _i32), ("s", _i32), ("h", _i32), ("d", _i32), ("rotary_dim", _i32), ("seqlen_ro", _i32),
+        ("interleaved", _i32), ("per_token", _i32), ("dtype", _i32), ("reserved", _i32 * 3),
     ]
 
 
@@ -75,7 +85,8 @@ class FaBwdParams(C.Structure):
 
 
 EXPORTS = (
-    "fa_abi_version", "fa_sizeof_fwd_params", "fa_sizeof_bwd_params", "fa_sizeof_kvappend_params", "fa_last_error",
+    "fa_abi_version", "fa_sizeof_fwd_params", "fa_sizeof_bwd_params", "fa_sizeof_kvappend_params", "fa_sizeof_rotary_params",
+    "fa_last_error", "fa_rotary",
     "fa_fwd", "fa_varlen_fwd", "fa_fwd_kvcache", "fa_kvcache_append", "fa_set_rng_state", "fa_fwd_workspace_bytes",
     "fa_bwd_workspace_bytes", "fa_bwd", "fa_varlen_bwd",
 )
@@ -117,6 +128,9 @@ def load():
     for fn in (lib.fa_bwd, lib.fa_varlen_bwd):
         fn.argtypes = [C.POINTER(FaBwdParams), C.c_void_p]
         fn.restype = C.c_int
+    lib.fa_sizeof_rotary_params.restype = C.c_int
+    lib.fa_rotary.argtypes = [C.POINTER(FaRotaryParams), C.c_void_p]
+    lib.fa_rotary.restype = C.c_int
     lib.fa_set_rng_state.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.fa_set_rng_state.restype = C.c_int
     lib.fa_fwd_workspace_bytes.argtypes = [C.POINTER(FaFwdParams)]
@@ -126,7 +140,8 @@ def load():
     if lib.fa_abi_version() != FA_ABI_VERSION:
         raise ImportError(f"{path}: ABI version {lib.fa_abi_version()} != binder {FA_ABI_VERSION}")
     if (lib.fa_sizeof_fwd_params() != C.sizeof(FaFwdParams) or lib.fa_sizeof_bwd_params() != C.sizeof(FaBwdParams)
-            or lib.fa_sizeof_kvappend_params() != C.sizeof(FaKvAppendParams)):
+            or lib.fa_sizeof_kvappend_params() != C.sizeof(FaKvAppendParams)
+            or lib.fa_sizeof_rotary_params() != C.sizeof(FaRotaryParams)):
         raise ImportError(f"{path}: parameter-block size mismatch with the ctypes mirror")
     _LIB = lib
     return lib

@@ -369,20 +369,51 @@ def varlen_bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, cu_seqlens_q, cu_
     return [dq, dk, dv, delta]
 
 
+def _rotary(lib, x, cos, sin, offsets, interleaved, per_token):
+    """x (B,S,H,D) -> rotated copy (fa_rotary; reference layers/rotary.py apply_rotary_emb semantics)."""
+    y = torch.empty_like(x)
+    r = _cabi.FaRotaryParams()
+    r.x, r.y, r.cos, r.sin, r.seqlen_offsets = _ptr(x), _ptr(y), _ptr(cos), _ptr(sin), _ptr(offsets)
+    r.x_batch_stride, r.x_row_stride, r.x_head_stride = x.stride(0), x.stride(1), x.stride(2)
+    r.y_batch_stride, r.y_row_stride, r.y_head_stride = y.stride(0), y.stride(1), y.stride(2)
+    r.cos_row_stride = cos.stride(0)
+    r.b, r.s, r.h, r.d = x.shape
+    r.rotary_dim, r.seqlen_ro = 2 * cos.shape[1], cos.shape[0]
+    r.interleaved, r.per_token, r.dtype = int(bool(interleaved)), int(bool(per_token)), _dtype_code(x)
+    _cabi.check(lib.fa_rotary(C.byref(r), C.c_void_p(_stream_ptr(x.device))))
+    return y
+
+
 def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_, cache_batch_idx_, leftpad_k_, block_table_,
                 alibi_slopes_, out_, softmax_scale, is_causal, window_size_left, window_size_right, softcap,
                 is_rotary_interleaved, num_splits) -> List[torch.Tensor]:
-    """mha_fwd_kvcache (flash_api.cpp:1243-1532) -> [out, softmax_lse].  Rotary and leftpad_k are not built."""
-    _check_dev(q, kcache, vcache, k_, v_, seqlens_k_, cache_batch_idx_, block_table_)
+    """mha_fwd_kvcache (flash_api.cpp:1243-1532) -> [out, softmax_lse]."""
+    _check_dev(q, kcache, vcache, k_, v_, seqlens_k_, cache_batch_idx_, block_table_, rotary_cos_, rotary_sin_, leftpad_k_)
     if not (q.dtype == kcache.dtype == vcache.dtype):
         raise RuntimeError("query and key must have the same dtype")
-    if rotary_cos_ is not None or rotary_sin_ is not None:
-        raise RuntimeError("libfa_gfx950: rotary embedding in fwd_kvcache is not built")
-    if leftpad_k_ is not None:
-        raise RuntimeError("libfa_gfx950: leftpad_k is not built")
     paged = block_table_ is not None
     if paged and cache_batch_idx_ is not None:
         raise RuntimeError("Paged KVcache does not support cache_batch_idx")
+    if leftpad_k_ is not None:
+        if paged:
+            raise RuntimeError("We don't support Paged KV and leftpad_k running at the same time yet")
+        if leftpad_k_.dtype != torch.int32 or not leftpad_k_.is_contiguous() or leftpad_k_.numel() != q.shape[0]:
+            raise RuntimeError("leftpad_k must be a contiguous int32 tensor of shape (batch_size)")
+        if seqlens_k_ is None:
+            raise RuntimeError("leftpad_k needs seqlens_k (cache_seqlens)")
+    if rotary_cos_ is not None:
+        if k_ is None:
+            raise RuntimeError("If rotary cos/sin are provided, new key / value to be appended to KV cache must also be provided")
+        if rotary_sin_ is None or rotary_cos_.shape != rotary_sin_.shape or rotary_cos_.dim() != 2:
+            raise RuntimeError("rotary_cos and rotary_sin must both be (seqlen_ro, rotary_dim / 2)")
+        if 2 * rotary_cos_.shape[1] > q.shape[-1]:
+            raise RuntimeError("rotary_dim must be <= headdim")
+        if (2 * rotary_cos_.shape[1]) % 16 != 0:
+            raise RuntimeError("Only rotary dimensions divisible by 16 are currently supported")
+        if rotary_cos_.dtype != q.dtype or rotary_sin_.dtype != q.dtype:
+            raise RuntimeError("rotary_cos/sin must have the same dtype as query")
+        if rotary_cos_.stride(-1) != 1 or rotary_sin_.stride(-1) != 1 or rotary_cos_.stride(0) != rotary_sin_.stride(0):
+            raise RuntimeError("rotary_cos/sin must have contiguous last dimension and equal row strides")
     B, Sq, H, D = q.shape
     Hk = kcache.shape[2]
     page = kcache.shape[1] if paged else 0
@@ -396,8 +427,17 @@ def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_,
     if Sq == 1 and alibi_slopes_ is None:
         is_causal = False
     lib = _cabi.load()
-    s_new = 0
+    s_new = 0 if k_ is None else k_.shape[1]
+    if paged and seqlens_k_ is not None:  # the reference's guard (flash_api.cpp:1433-1447); costs a device->host sync
+        need = int(seqlens_k_.max().item()) + s_new
+        if need > Sk:
+            raise RuntimeError(f"Paged KV cache: max(seqlens_k){' + seqlen_knew' if s_new else ''} (= {need}) exceeds the capacity "
+                               f"addressable by block_table (max_num_blocks_per_seq * page_block_size = {Sk})")
     with torch.cuda.device(q.device):
+        if rotary_cos_ is not None:  # keys at positions cache_seqlens + i; queries too if causal/local, else all at cache_seqlens
+            local = is_causal or window_size_left >= 0 or window_size_right >= 0
+            k_ = _rotary(lib, k_, rotary_cos_, rotary_sin_, seqlens_k_, is_rotary_interleaved, True)
+            q = _rotary(lib, q, rotary_cos_, rotary_sin_, seqlens_k_, is_rotary_interleaved, local)
         if k_ is not None:
             if v_ is None or seqlens_k_ is None:
                 raise RuntimeError("If key is supplied, value and seqlens_k must also be passed in")
@@ -411,6 +451,8 @@ def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_,
             ap.page_block_size = page
             ap.b, ap.seqlen_new, ap.h_k, ap.d, ap.dtype = B, s_new, Hk, D, _dtype_code(q)
             _cabi.check(lib.fa_kvcache_append(C.byref(ap), C.c_void_p(_stream_ptr(q.device))))
+        if Sq == 1:
+            window_size_right = -1  # a right bound cannot hide a key from the single, bottom-right aligned query row
         swap = Sq == 1 and H > Hk and window_size_left < 0 and alibi_slopes_ is None
         ratio = H // Hk
         qk = q.reshape(B, Hk, ratio, D).transpose(1, 2) if swap else q
@@ -425,7 +467,7 @@ def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_,
         a.v_batch_stride, a.v_row_stride, a.v_head_stride = vcache.stride(0), vcache.stride(1), vcache.stride(2)
         a.o_batch_stride, a.o_row_stride, a.o_head_stride = out.stride(0), out.stride(1), out.stride(2)
         a.seqused_k, a.seqused_k_add = _ptr(seqlens_k_), s_new
-        a.cache_batch_idx, a.block_table = _ptr(cache_batch_idx_), _ptr(block_table_)
+        a.cache_batch_idx, a.block_table, a.leftpad_k = _ptr(cache_batch_idx_), _ptr(block_table_), _ptr(leftpad_k_)
         a.block_table_batch_stride, a.page_block_size = (block_table_.stride(0) if paged else 0), page
         a.alibi_slopes, a.alibi_batch_stride = _ptr(alibi), alibi_bs
         a.b, a.h, a.h_k, a.d = B, heads, Hk, D

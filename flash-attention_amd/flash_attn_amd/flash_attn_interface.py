@@ -204,14 +204,16 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None
     """Inference attention against a KV cache (reference :1485-1627).  If k / v are given they are written into the
     cache in place at rows ``cache_seqlens[b] ..`` before attending; ``cache_seqlens`` may be an int or an int32
     tensor (batch,); ``cache_batch_idx`` selects cache rows; ``block_table`` selects pages of a paged cache
-    (num_blocks, page, Hk, D).  Rotary embedding and ``cache_leftpad`` are not built yet (RuntimeError).  No backward."""
+    (num_blocks, page, Hk, D); ``rotary_cos/sin`` (seqlen_ro, rotary_dim/2) rotate the new keys at positions
+    cache_seqlens + i and the queries likewise (all at cache_seqlens unless causal / local); ``cache_leftpad`` gives the
+    first valid cache row of each entry.  No backward."""
     q, k, v = (_unit_stride_last(t) for t in (q, k, v))
     if softmax_scale is None:
         softmax_scale = q.shape[-1] ** (-0.5)
     if cache_seqlens is not None and isinstance(cache_seqlens, int):
         cache_seqlens = torch.full((q.shape[0],), cache_seqlens, dtype=torch.int32, device=k_cache.device)
     out, lse = flash_attn_gpu.fwd_kvcache(
-        q, k_cache, v_cache, k, v, cache_seqlens, rotary_cos, rotary_sin,
+        q, k_cache, v_cache, k, v, cache_seqlens, _unit_stride_last(rotary_cos), _unit_stride_last(rotary_sin),
         None if cache_batch_idx is None else cache_batch_idx.contiguous(), cache_leftpad,
         None if block_table is None else _unit_stride_last(block_table), alibi_slopes, None, softmax_scale, causal,
         window_size[0], window_size[1], softcap, rotary_interleaved, num_splits)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 3
+#define FA_ABI_VERSION 4
 
 enum { FA_DTYPE_FP16 = 0, FA_DTYPE_BF16 = 1 };
 
@@ -92,6 +92,8 @@ typedef struct FaFwdParams {
   /* split-KV scratch (fa_fwd_kvcache): fa_fwd_workspace_bytes() bytes, 256-B aligned; may be NULL if that is 0 */
   void* workspace;
   int64_t workspace_bytes;
+  const int32_t* leftpad_k;         /* fa_fwd_kvcache, optional (B): the cache of entry b starts at row leftpad_k[b]; seqused_k
+                                       counts from row 0 (reference block_info.h:17-36); not with block_table */
 } FaFwdParams;
 
 /* Append step of the KV-cache path: copy knew/vnew (B, S_new, Hk, D) into the cache at rows
@@ -114,6 +116,28 @@ typedef struct FaKvAppendParams {
   int32_t dtype;
   int32_t reserved[2];
 } FaKvAppendParams;
+
+/* Rotary position embedding of x (B, S, H, D) into y (same shape, may alias x): the first rotary_dim channels of
+ * every row are rotated by the angle row of position seqlen_offsets[b] + (per_token ? s : 0)
+ * (reference flash_fwd_kernel.h:640-720 Append_KV rotary, csrc/flash_attn/src/rotary.h; Python
+ * flash_attn/layers/rotary.py apply_rotary_emb).  cos/sin: (seqlen_ro, rotary_dim/2), same dtype as x. */
+typedef struct FaRotaryParams {
+  const void* x;
+  void* y;
+  const void* cos;
+  const void* sin;
+  const int32_t* seqlen_offsets;   /* (B) or NULL (= 0) */
+  int64_t x_batch_stride, x_row_stride, x_head_stride;
+  int64_t y_batch_stride, y_row_stride, y_head_stride;
+  int64_t cos_row_stride;          /* elements between consecutive positions of cos / sin */
+  int32_t b, s, h, d;
+  int32_t rotary_dim;              /* multiple of 16, <= d */
+  int32_t seqlen_ro;               /* rows of cos / sin */
+  int32_t interleaved;             /* 1: pairs (2t, 2t+1) (GPT-J); 0: pairs (t, t + rotary_dim/2) (GPT-NeoX) */
+  int32_t per_token;               /* 1: row s sits at position offset + s; 0: every row at position offset */
+  int32_t dtype;
+  int32_t reserved[3];
+} FaRotaryParams;
 
 typedef struct FaBwdParams {
   const void* dout;
@@ -160,6 +184,7 @@ int fa_abi_version(void);
 int fa_sizeof_fwd_params(void);
 int fa_sizeof_bwd_params(void);
 int fa_sizeof_kvappend_params(void);
+int fa_sizeof_rotary_params(void);
 /* Last error message of the calling thread ("" if none). */
 const char* fa_last_error(void);
 
@@ -176,6 +201,8 @@ int fa_kvcache_append(const FaKvAppendParams* params, void* stream);
 int fa_set_rng_state(uint64_t seed, uint64_t offset, uint64_t* rng_state, void* stream);
 /* Bytes of split-KV scratch fa_fwd_kvcache needs for this problem with params->num_splits (0 is possible). */
 int64_t fa_fwd_workspace_bytes(const FaFwdParams* params);
+/* Rotary embedding of q / new keys ahead of fa_kvcache_append + fa_fwd_kvcache (y may alias x). */
+int fa_rotary(const FaRotaryParams* params, void* stream);
 /* Bytes of scratch the backward needs for this problem (0 is possible). */
 int64_t fa_bwd_workspace_bytes(const FaBwdParams* params);
 /* Backward, fixed-length batch: writes dq, dk, dv (caller-allocated) and softmax_d. */

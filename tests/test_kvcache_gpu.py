@@ -92,8 +92,9 @@ def test_kvcache_interface_and_errors():
     out_w = fi.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=300, window_size=(100, 0))
     ow_ref, _ = _oracle(q, kc, vc, [300, 300], False, (100, 0))
     assert max_abs(out_w.float().cpu(), torch.from_numpy(ow_ref)) < 5e-3
-    with pytest.raises(RuntimeError, match="rotary"):
-        fi.flash_attn_with_kvcache(q, kc, vc, rotary_cos=torch.zeros(8, 16, device="cuda"), rotary_sin=torch.zeros(8, 16, device="cuda"))
+    with pytest.raises(RuntimeError, match="rotary"):   # rotary needs new keys to append (flash_api.cpp:1455)
+        fi.flash_attn_with_kvcache(q, kc, vc, rotary_cos=torch.zeros(8, 16, device="cuda", dtype=torch.float16),
+                                   rotary_sin=torch.zeros(8, 16, device="cuda", dtype=torch.float16))
     with pytest.raises(RuntimeError, match="divisible by 256"):
         fi.flash_attn_with_kvcache(q, kc[:, :128].contiguous(), vc[:, :128].contiguous(), block_table=torch.zeros(2, 1, dtype=torch.int32, device="cuda"))
 
@@ -122,3 +123,101 @@ def test_kvcache_split_kv(kv, sq, causal, paged, num_splits):
     o_ref, l_ref = _oracle(q, k_log, v_log, lens.cpu().numpy(), causal)
     assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 2e-2
     assert max_abs(lse.cpu(), torch.from_numpy(l_ref).float()) < 2e-3
+
+
+def _rotary_ref(x, cos, sin, offsets, interleaved, per_token):
+    """apply_rotary_emb semantics (reference flash_attn/layers/rotary.py:25-60 + seqlen_offsets), fp32 math."""
+    B, S, H, D = x.shape
+    rd = 2 * cos.shape[1]
+    xf = x.float().cpu()
+    out = xf.clone()
+    for b in range(B):
+        pos = int(offsets[b]) + (torch.arange(S) if per_token else torch.zeros(S, dtype=torch.long))
+        c = cos.float().cpu()[pos][:, None, :]
+        s = sin.float().cpu()[pos][:, None, :]
+        xr = xf[b, :, :, :rd]
+        if interleaved:
+            x1, x2 = xr[..., 0::2], xr[..., 1::2]
+            out[b, :, :, 0:rd:2] = x1 * c - x2 * s
+            out[b, :, :, 1:rd:2] = x1 * s + x2 * c
+        else:
+            x1, x2 = xr[..., : rd // 2], xr[..., rd // 2:]
+            out[b, :, :, : rd // 2] = x1 * c - x2 * s
+            out[b, :, :, rd // 2: rd] = x1 * s + x2 * c
+    return out.to(x.dtype)
+
+
+@pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("rotary_frac", [0.25, 1.0])
+@pytest.mark.parametrize("sq,causal", [(1, False), (9, True), (9, False)])
+@pytest.mark.parametrize("d", [64, 128])
+def test_kvcache_rotary(kv, d, sq, causal, rotary_frac, interleaved):
+    torch.manual_seed(4)
+    B, H, hk, cap = 3, 8, 2, 512
+    rd = int(rotary_frac * d) // 16 * 16
+    q = torch.randn(B, sq, H, d, device="cuda", dtype=torch.bfloat16)
+    kc = torch.randn(B, cap, hk, d, device="cuda", dtype=torch.bfloat16)
+    vc = torch.randn_like(kc)
+    kn = torch.randn(B, sq, hk, d, device="cuda", dtype=torch.bfloat16)
+    vn = torch.randn_like(kn)
+    lens = torch.tensor([0, 100, cap - sq], dtype=torch.int32, device="cuda")
+    ang = torch.rand(cap, rd // 2, device="cuda") * 2 * np.pi
+    cos, sin = torch.cos(ang).bfloat16(), torch.sin(ang).bfloat16()
+    kc_ref = kc.clone()
+    out, lse = kv.fwd_kvcache(q, kc, vc, kn, vn, lens, cos, sin, None, None, None, None, None, d ** -0.5, causal, -1, -1, 0.0, interleaved, 0)
+    k_ro = _rotary_ref(kn, cos, sin, lens.cpu(), interleaved, True)
+    q_ro = _rotary_ref(q, cos, sin, lens.cpu(), interleaved, causal)
+    for b in range(B):
+        L = int(lens[b])
+        assert max_abs(kc[b, L:L + sq].float().cpu(), k_ro[b].float()) < 4e-2   # one bf16 ulp of |x| <= 4 (fma vs mul+sub)
+        assert torch.equal(vc[b, L:L + sq], vn[b])
+        kc_ref[b, L:L + sq] = kc[b, L:L + sq]                                    # attend over exactly what the cache holds
+    assert (kc[:, :, :, rd:] == kc_ref[:, :, :, rd:]).all()
+    o_ref, l_ref = _oracle(q_ro, kc_ref, vc, (lens + sq).cpu().numpy(), causal)
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 3e-2
+    assert max_abs(lse.cpu(), torch.from_numpy(l_ref).float()) < 3e-2
+
+
+@pytest.mark.parametrize("sq,causal", [(1, False), (5, True), (40, False)])
+def test_kvcache_leftpad(kv, sq, causal):
+    torch.manual_seed(6)
+    B, H, hk, d, cap = 3, 8, 4, 128, 640
+    q = torch.randn(B, sq, H, d, device="cuda", dtype=torch.bfloat16)
+    kc = torch.randn(B, cap, hk, d, device="cuda", dtype=torch.bfloat16)
+    vc = torch.randn_like(kc)
+    kn = torch.randn(B, sq, hk, d, device="cuda", dtype=torch.bfloat16)
+    vn = torch.randn_like(kn)
+    lens = torch.tensor([70, 333, cap - sq], dtype=torch.int32, device="cuda")      # counted from row 0 (includes the pad)
+    pad = torch.tensor([0, 200, 65], dtype=torch.int32, device="cuda")
+    out, lse = kv.fwd_kvcache(q, kc, vc, kn, vn, lens, None, None, None, pad, None, None, None, d ** -0.5, causal, -1, -1, 0.0, True, 0)
+    for b in range(B):
+        L, P = int(lens[b]), int(pad[b])
+        assert torch.equal(kc[b, L:L + sq], kn[b])
+        o_ref, l_ref = _oracle(q[b:b + 1], kc[b:b + 1, P:], vc[b:b + 1, P:], [L + sq - P], causal)
+        assert max_abs(out[b:b + 1].float().cpu(), torch.from_numpy(o_ref)) < 2e-2
+        assert max_abs(lse[b:b + 1].cpu(), torch.from_numpy(l_ref).float()) < 2e-3
+
+
+def test_kvcache_paged_capacity_guard_and_single_row_window(kv):
+    torch.manual_seed(7)
+    d, page = 64, 256
+    kp = torch.randn(4, page, 1, d, device="cuda", dtype=torch.float16)
+    vp = torch.randn_like(kp)
+    table = torch.zeros(1, 1, dtype=torch.int32, device="cuda")
+    q = torch.randn(1, 1, 1, d, device="cuda", dtype=torch.float16)
+    over = torch.full((1,), page + 1, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="block_table"):   # reference tests/test_flash_attn.py:2587-2634
+        kv.fwd_kvcache(q, kp, vp, None, None, over, None, None, None, None, table, None, None, d ** -0.5, False, -1, -1, 0.0, True, 0)
+    full = torch.full((1,), page, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="block_table"):
+        kv.fwd_kvcache(q, kp, vp, q, q, full, None, None, None, None, table, None, None, d ** -0.5, False, -1, -1, 0.0, True, 0)
+    out, _ = kv.fwd_kvcache(q, kp, vp, None, None, full, None, None, None, None, table, None, None, d ** -0.5, False, -1, -1, 0.0, True, 0)
+    assert out.shape == (1, 1, 1, d) and not out.isnan().any()
+    # one query row, GQA, a right window bound: the bound hides nothing (the head-packing swap must not apply it to heads)
+    q = torch.randn(2, 1, 16, d, device="cuda", dtype=torch.float16)
+    kc = torch.randn(2, 300, 2, d, device="cuda", dtype=torch.float16)
+    vc = torch.randn_like(kc)
+    lens = torch.tensor([300, 77], dtype=torch.int32, device="cuda")
+    out, lse = kv.fwd_kvcache(q, kc, vc, None, None, lens, None, None, None, None, None, None, None, d ** -0.5, False, -1, 3, 0.0, True, 0)
+    o_ref, l_ref = _oracle(q, kc, vc, lens.cpu().numpy(), False)
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 5e-3 and max_abs(lse.cpu(), torch.from_numpy(l_ref).float()) < 2e-3
