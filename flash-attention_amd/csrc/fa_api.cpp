@@ -35,7 +35,7 @@ int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
-bool head_dim_native(int d) { return d == 64 || d == 128; }
+bool head_dim_native(int d) { return d == 64 || d == 128 || d == 256; }
 
 // Reference flash_api.cpp:422-427 (+ :155-162): windows at least as wide as the key sequence are
 // unbounded, a single query row needs no causal mask, causal means window_right = 0.
@@ -57,7 +57,8 @@ int check_dropout(float p_dropout, const void* rng_state) {
 template <typename K> void fill_dropout(K& k, float p_dropout, const uint64_t* rng_state, int seqlen_k) {
   if (p_dropout > 0.f) {
     k.rng = rng_state;
-    k.drop_thr8 = (uint32_t)std::floor(255.0 * (1.0 - (double)p_dropout));  // csrc/flash_attn_ck convention (uint8 threshold)
+    const float p_keep = 1.0f - p_dropout;  // single precision throughout, as csrc/flash_attn_ck/mha_fwd.cpp derives its uint8 threshold
+    k.drop_thr8 = (uint32_t)std::floor(p_keep * 255.0f);
     k.drop_groups = (seqlen_k + 3) / 4;
     k.rp_keep = 1.f / (1.f - p_dropout);
   }
@@ -95,7 +96,7 @@ int check_common(int b, int h, int h_k, int d, int dtype, float softcap) {
   if (dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_BF16)
     return fail(FA_ERR_INVALID_ARGUMENT, "FlashAttention only supports fp16 and bf16 data type");
   if (!head_dim_native(d))
-    return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: head dimension %d is not built natively (64, 128); pad to the next one on the host", d);
+    return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: head dimension %d is not built natively (64, 128, 256); pad to the next one on the host", d);
   if (softcap < 0.f) return fail(FA_ERR_INVALID_ARGUMENT, "softcap must be non-negative");
   return FA_OK;
 }
@@ -173,6 +174,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     if (a->d == 128) nw = (tiles >= 48 && a->seqlen_q >= 512) ? 38 : (a->seqlen_q > 128 ? 34 : 4);
     else nw = (a->seqlen_q > 128) ? 34 : 4;
   }
+  if (a->d > 128) nw = 4;  // head dim 256: one 4-wave lock-step workgroup per CU (512-register budget)
   // decode: split the keys over several workgroups when (batch x heads) cannot fill the chip
   if (kvcache) {
     int split_tiles = 0;
@@ -236,8 +238,9 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   k.softcap = a->softcap;
   if (int rc = check_dropout(a->p_dropout, a->rng_state)) return rc;
   fill_dropout(k, a->p_dropout, a->rng_state, a->seqlen_k);
-  k.nmb = (a->seqlen_q + fa::bwd_block_m() - 1) / fa::bwd_block_m();
-  k.nnb = (a->seqlen_k + fa::bwd_block_n() - 1) / fa::bwd_block_n();
+  const int bwd_bm = a->d > 128 ? 128 : fa::bwd_block_m();
+  k.nmb = (a->seqlen_q + bwd_bm - 1) / bwd_bm;
+  k.nnb = (a->seqlen_k + fa::bwd_block_n(a->d) - 1) / fa::bwd_block_n(a->d);
   fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb, k.q_units, k.q_unit_size, k.q_unit_hpx);
   fa::choose_units(a->b, a->h_k, 1, k.nnb, k.k_units, k.k_unit_size, k.k_unit_hpx);
   return FA_OK;

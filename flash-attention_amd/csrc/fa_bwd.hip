@@ -33,7 +33,7 @@ namespace fa {
 //   - ds_read_b128 operand rows (16 distinct rows per lane group, same logical chunk),
 //   - ds_read_b64_tr_b16 (a half-wave reads 4 consecutive rows x 64 contiguous logical bytes).
 template <int D> FA_DEVINL int swz16(int row) {
-  return D == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+  return D >= 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
 }
 template <int D> FA_DEVINL int tile_off(int row, int chunk) { return row * (D * 2) + ((chunk ^ swz16<D>(row)) << 4); }
 
@@ -80,13 +80,15 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
 // dK / dV
 // ------------------------------------------------------------------------------------------------
 template <typename E, int D, bool XFORM>
-__global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
+__global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_dkdv_kernel(const BwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   using V4 = typename T::v4;
-  constexpr int NW = 8, NT = NW * 64;
+  // D <= 128: 8 waves (two per SIMD, 256 registers each); D = 256: 4 waves, one per SIMD, with the 512-register budget
+  // the two 32 x 256 accumulators need, and 32-query tiles so that V block + Q/dO double buffers fit 160 KB of LDS
+  constexpr int NW = D > 128 ? 4 : 8, NT = NW * 64;
   constexpr int BNK = NW * 32;   // keys per workgroup
-  constexpr int BMQ = 64;        // queries per streamed tile (two 32-row sub-blocks)
+  constexpr int BMQ = D > 128 ? 32 : 64;  // queries per streamed tile (32-row sub-blocks)
   constexpr int CPR = D / 8, ROW_BYTES = D * 2;
   constexpr int KS = D / 16, DB = D / 32;
   constexpr int VBLK_BYTES = BNK * ROW_BYTES;
@@ -372,7 +374,7 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_dkdv_kernel(const BwdK p) {
 // dQ
 // ------------------------------------------------------------------------------------------------
 template <typename E, int D, int NW, bool XFORM>
-__global__ void __launch_bounds__(NW * 64, 2) fa_bwd_dq_kernel(const BwdK p) {
+__global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(const BwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   using V4 = typename T::v4;
@@ -595,7 +597,7 @@ int bwd_block_m() {
   static const int nw = [] { const char* e = getenv("FA_BWD_DQ_NW"); const int v = e ? atoi(e) : 4; return (v == 8) ? 8 : 4; }();
   return 32 * nw;
 }
-int bwd_block_n() { return 256; }
+int bwd_block_n(int d) { return d > 128 ? 128 : 256; }
 
 template <typename E, int D>
 static int launch_delta_t(const BwdK& p, hipStream_t stream) {
@@ -607,7 +609,8 @@ static int launch_delta_t(const BwdK& p, hipStream_t stream) {
 
 template <typename E, int D, bool XFORM>
 static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
-  constexpr int smem = 256 * D * 2 + 4 * 64 * D * 2 + 4 * 64 * 4;
+  constexpr int NWK = D > 128 ? 4 : 8, BMQ = D > 128 ? 32 : 64;
+  constexpr int smem = NWK * 32 * D * 2 + 4 * BMQ * D * 2 + 4 * BMQ * 4;
   auto kern = fa_bwd_dkdv_kernel<E, D, XFORM>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -615,7 +618,7 @@ static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
     attr_done = true;
   }
   const long long total = units_grid(p.k_units, p.k_unit_size);
-  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), smem, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NWK * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -639,17 +642,23 @@ static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
 }
 template <typename E, int D>
 static int launch_dq_t(const BwdK& p, hipStream_t stream) {
+  if constexpr (D > 128) {
+    return (p.alibi || p.softcap > 0.f || p.rng) ? launch_dq_nw<E, D, 4, true>(p, stream) : launch_dq_nw<E, D, 4, false>(p, stream);
+  } else {
   if (p.alibi || p.softcap > 0.f || p.rng) return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, true>(p, stream) : launch_dq_nw<E, D, 4, true>(p, stream);
   return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, false>(p, stream) : launch_dq_nw<E, D, 4, false>(p, stream);
+  }
 }
 
 #define FA_BWD_DISPATCH(fn)                                            \
   if (dtype_bf16) {                                                    \
     if (d == 128) return fn<__bf16, 128>(p, stream);                   \
     if (d == 64) return fn<__bf16, 64>(p, stream);                     \
+    if (d == 256) return fn<__bf16, 256>(p, stream);                   \
   } else {                                                             \
     if (d == 128) return fn<_Float16, 128>(p, stream);                 \
     if (d == 64) return fn<_Float16, 64>(p, stream);                   \
+    if (d == 256) return fn<_Float16, 256>(p, stream);                 \
   }                                                                    \
   return -2;
 

@@ -44,13 +44,13 @@
 
 namespace fa {
 
-template <int D> FA_DEVINL constexpr int k_swz(int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); }
-template <int D> FA_DEVINL constexpr int v_swz(int row) { return D == 128 ? (row & 3) : ((row >> 1) & 1); }
+template <int D> FA_DEVINL constexpr int k_swz(int row) { return D >= 128 ? (row & 15) : ((row >> 1) & 7); }
+template <int D> FA_DEVINL constexpr int v_swz(int row) { return D >= 128 ? (row & 3) : ((row >> 1) & 1); }
 
 template <int N> using IC = std::integral_constant<int, N>;
 
 template <typename E, int D, int NW, bool XFORM, bool PP>
-__global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
+__global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const FwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   using V4 = typename T::v4;
@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_kernel(const FwdK p) {
   constexpr int LD = (BN * CPR) / NT;  // 16-B chunks each thread moves per tile (K and V each)
   constexpr int KS = D / 16;           // k-steps of the QK^T contraction
   constexpr int DB = D / 32;           // 32-wide d blocks of the output
-  static_assert(D == 64 || D == 128, "head dims built natively: 64, 128");
+  static_assert(D == 64 || D == 128 || D == 256, "head dims built natively: 64, 128, 256");
+  static_assert(D <= 128 || (NW == 4 && !PP), "D = 256: 4 waves (one per SIMD, 512 registers), lock-step schedule");
   static_assert(LD >= 1 && (BN * CPR) % NT == 0, "tile does not divide over the workgroup");
   static_assert(!PP || NW == 8, "ping-pong schedule pairs waves w and w+4");
   constexpr float kLn2 = 0.6931471805599453f, kLog2e = 1.4426950408889634f;
@@ -536,7 +537,9 @@ __global__ void __launch_bounds__(256) fa_splitkv_combine_kernel(const FwdK p) {
 int launch_splitkv_combine(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   const int64_t rows = (int64_t)p.b * p.h * p.sq;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (dtype_bf16 && d == 128) hipLaunchKernelGGL((fa_splitkv_combine_kernel<__bf16, 128>), grid, block, 0, stream, p);
+  if (dtype_bf16 && d == 256) hipLaunchKernelGGL((fa_splitkv_combine_kernel<__bf16, 256>), grid, block, 0, stream, p);
+  else if (d == 256) hipLaunchKernelGGL((fa_splitkv_combine_kernel<_Float16, 256>), grid, block, 0, stream, p);
+  else if (dtype_bf16 && d == 128) hipLaunchKernelGGL((fa_splitkv_combine_kernel<__bf16, 128>), grid, block, 0, stream, p);
   else if (dtype_bf16 && d == 64) hipLaunchKernelGGL((fa_splitkv_combine_kernel<__bf16, 64>), grid, block, 0, stream, p);
   else if (d == 128) hipLaunchKernelGGL((fa_splitkv_combine_kernel<_Float16, 128>), grid, block, 0, stream, p);
   else if (d == 64) hipLaunchKernelGGL((fa_splitkv_combine_kernel<_Float16, 64>), grid, block, 0, stream, p);
@@ -674,10 +677,15 @@ int fwd_block_m(int nw) { return nw == 16 ? 256 : 32 * nw; }
 template <typename E, int D>
 static int launch_fwd_ed(const FwdK& p, int nw, hipStream_t stream) {
   const bool xf = (p.softcap > 0.f) || (p.alibi != nullptr) || (p.rng != nullptr);
+  if constexpr (D > 128) {
+    (void)nw;
+    return xf ? launch_fwd_t<E, D, 4, true, false>(p, stream) : launch_fwd_t<E, D, 4, false, false>(p, stream);
+  } else {
   if (nw == 16) return xf ? launch_fwd_t<E, D, 8, true, true>(p, stream) : launch_fwd_t<E, D, 8, false, true>(p, stream);
   if (nw == 8) return xf ? launch_fwd_t<E, D, 8, true, false>(p, stream) : launch_fwd_t<E, D, 8, false, false>(p, stream);
   if (nw == 4) return xf ? launch_fwd_t<E, D, 4, true, false>(p, stream) : launch_fwd_t<E, D, 4, false, false>(p, stream);
   return -2;
+  }
 }
 
 // nw: 4 / 8 = lock-step schedule with 4 / 8 waves per workgroup, 16 = 8-wave ping-pong schedule
@@ -687,9 +695,11 @@ int launch_fwd(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream)
   if (dtype_bf16) {
     if (d == 128) return launch_fwd_ed<__bf16, 128>(p, nw, stream);
     if (d == 64) return launch_fwd_ed<__bf16, 64>(p, nw, stream);
+    if (d == 256) return launch_fwd_ed<__bf16, 256>(p, nw, stream);
   } else {
     if (d == 128) return launch_fwd_ed<_Float16, 128>(p, nw, stream);
     if (d == 64) return launch_fwd_ed<_Float16, 64>(p, nw, stream);
+    if (d == 256) return launch_fwd_ed<_Float16, 256>(p, nw, stream);
   }
   return -2;
 }

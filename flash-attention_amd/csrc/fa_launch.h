@@ -50,6 +50,6 @@ int launch_bwd_delta(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int bwd_block_m();   // query rows per dQ workgroup
-int bwd_block_n();   // key rows per dK/dV workgroup
+int bwd_block_n(int d);   // key rows per dK/dV workgroup (256; 128 for head dim 256)
 
 }  // namespace fa

@@ -39,8 +39,9 @@ int dtype_code(const Tensor& q) {
 
 int native_head_dim(int64_t d) {
   if (d <= 64) return 64;
-  TORCH_CHECK(d <= 128, "libfa_gfx950: head dimension ", d, " > 128 is not built yet");
-  return 128;
+  if (d <= 128) return 128;
+  TORCH_CHECK(d <= 256, "FlashAttention only supports head dimension at most 256");
+  return 256;
 }
 
 Tensor pad_d(const Tensor& x, int64_t d_to) {
@@ -420,7 +421,7 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tenso
   const int64_t page = paged ? kcache.size(1) : 0;
   const int64_t Sk = paged ? block_table_->size(1) * page : kcache.size(1);
   TORCH_CHECK(B > 0, "batch size must be positive");
-  TORCH_CHECK(D == 64 || D == 128, "libfa_gfx950: fwd_kvcache is built for head dimensions 64 and 128");
+  TORCH_CHECK(D == 64 || D == 128 || D == 256, "libfa_gfx950: fwd_kvcache is built for head dimensions 64, 128 and 256");
   TORCH_CHECK(H % Hk == 0, "Number of heads in key/value must divide number of heads in query");
   TORCH_CHECK(kcache.size(3) == D && vcache.sizes() == kcache.sizes(), "kcache / vcache shape mismatch");
   if (paged) {

@@ -16,7 +16,7 @@ import torch
 
 from . import _cabi
 
-_NATIVE_HEAD_DIMS = (64, 128)
+_NATIVE_HEAD_DIMS = (64, 128, 256)
 
 
 def _dtype_code(t: torch.Tensor) -> int:
@@ -41,7 +41,7 @@ def _native_d(d: int) -> int:
     for n in _NATIVE_HEAD_DIMS:
         if d <= n:
             return n
-    raise RuntimeError(f"libfa_gfx950: head dimension {d} > 128 is not built yet")
+    raise RuntimeError(f"FlashAttention only supports head dimension at most 256 (got {d})")
 
 
 def _pad_d(x: torch.Tensor, d_to: int) -> torch.Tensor:
@@ -419,7 +419,7 @@ def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_,
     page = kcache.shape[1] if paged else 0
     Sk = block_table_.shape[1] * page if paged else kcache.shape[1]
     if D not in _NATIVE_HEAD_DIMS:
-        raise RuntimeError("libfa_gfx950: fwd_kvcache is built for head dimensions 64 and 128")
+        raise RuntimeError("libfa_gfx950: fwd_kvcache is built for head dimensions 64, 128 and 256")
     if H % Hk != 0:
         raise RuntimeError("Number of heads in key/value must divide number of heads in query")
     if paged and page % 256 != 0:

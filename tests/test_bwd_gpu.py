@@ -35,7 +35,7 @@ def _ref_grads(q, k, v, do, causal, window, upcast):
 
 
 GOLDEN = ["mha_full_d64", "mha_causal_d128", "gqa_causal_sq_gt_sk", "mqa_local_d128", "gqa_causal_window_d128",
-          "local_left_only_d64", "local_right_only_d64", "tiny_sq1", "alibi_d64", "d32_full", "d96_causal"]
+          "local_left_only_d64", "local_right_only_d64", "tiny_sq1", "alibi_d64", "d32_full", "d96_causal", "d256_causal"]
 
 
 @pytest.mark.parametrize("name", GOLDEN)

@@ -16,7 +16,7 @@ def fi():
     return flash_attn_interface
 
 
-@pytest.mark.parametrize("d", [40, 59, 64, 96, 111, 128])
+@pytest.mark.parametrize("d", [40, 59, 64, 96, 111, 128, 160, 192, 224, 256])
 @pytest.mark.parametrize("causal", [False, True])
 def test_flash_attn_func_autograd(fi, d, causal):
     torch.manual_seed(0)
