@@ -41,8 +41,12 @@ def _pad_head_dim(*ts):
     return tuple(torch.nn.functional.pad(t, [0, pad]) for t in ts)
 
 
-def _flash_attn_forward(q, k, v, dropout_p, softmax_scale, causal, window_size_left, window_size_right,
-                        softcap, alibi_slopes, return_softmax):
+# The four raw wrappers are registered as custom ops (namespace ``flash_attn_amd``) with fake implementations, like the
+# reference's ``flash_attn::_flash_attn_forward`` etc. (reference :84-144, :153-243, :252-338, :347-452), so that
+# torch.compile / export trace through them without graph breaks; the public functions below call the registered ops.
+def _fwd_impl(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dropout_p: float, softmax_scale: float, causal: bool,
+              window_size_left: int, window_size_right: int, softcap: float, alibi_slopes: Optional[torch.Tensor],
+              return_softmax: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     q, k, v = (_unit_stride_last(t) for t in (q, k, v))
     out, lse, s_dmask, rng_state = flash_attn_gpu.fwd(
         q, k, v, None, alibi_slopes, dropout_p, softmax_scale, causal, window_size_left, window_size_right,
@@ -50,10 +54,23 @@ def _flash_attn_forward(q, k, v, dropout_p, softmax_scale, causal, window_size_l
     return out, lse, s_dmask, rng_state
 
 
-def _flash_attn_varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p,
-                               softmax_scale, causal, window_size_left=-1, window_size_right=-1, softcap=0.0,
-                               alibi_slopes=None, return_softmax=False, block_table=None, leftpad_k=None,
-                               seqused_k=None, zero_tensors=False):
+def _fwd_fake(q, k, v, dropout_p, softmax_scale, causal, window_size_left, window_size_right, softcap, alibi_slopes,
+              return_softmax):
+    B, Sq, H, _ = q.shape
+    out = torch.empty_like(q)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    p = (torch.empty((B, H, Sq, k.shape[1]), dtype=torch.uint8, device=q.device) if return_softmax
+         else torch.empty((0,), dtype=q.dtype, device=q.device))
+    return out, lse, p, torch.empty((2,), dtype=torch.int64, device=q.device)
+
+
+def _varlen_fwd_impl(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor,
+                     max_seqlen_q: int, max_seqlen_k: int, dropout_p: float, softmax_scale: float, causal: bool,
+                     window_size_left: int = -1, window_size_right: int = -1, softcap: float = 0.0,
+                     alibi_slopes: Optional[torch.Tensor] = None, return_softmax: bool = False,
+                     block_table: Optional[torch.Tensor] = None, leftpad_k: Optional[torch.Tensor] = None,
+                     seqused_k: Optional[torch.Tensor] = None, zero_tensors: bool = False
+                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     q, k, v = (_unit_stride_last(t) for t in (q, k, v))
     out, lse, s_dmask, rng_state = flash_attn_gpu.varlen_fwd(
         q, k, v, None, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k, block_table, alibi_slopes, max_seqlen_q,
@@ -62,8 +79,22 @@ def _flash_attn_varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q
     return out, lse, s_dmask, rng_state
 
 
-def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, dropout_p, softmax_scale, causal,
-                         window_size_left, window_size_right, softcap, alibi_slopes, deterministic, rng_state=None):
+def _varlen_fwd_fake(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal,
+                     window_size_left=-1, window_size_right=-1, softcap=0.0, alibi_slopes=None, return_softmax=False,
+                     block_table=None, leftpad_k=None, seqused_k=None, zero_tensors=False):
+    total_q, H, _ = q.shape
+    out = torch.empty_like(q)
+    lse = torch.empty((H, total_q), dtype=torch.float32, device=q.device)
+    p = (torch.empty((H, total_q, max_seqlen_k), dtype=torch.uint8, device=q.device) if return_softmax
+         else torch.empty((0,), dtype=q.dtype, device=q.device))
+    return out, lse, p, torch.empty((2,), dtype=torch.int64, device=q.device)
+
+
+def _bwd_impl(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor,
+              softmax_lse: torch.Tensor, dq: Optional[torch.Tensor], dk: Optional[torch.Tensor], dv: Optional[torch.Tensor],
+              dropout_p: float, softmax_scale: float, causal: bool, window_size_left: int, window_size_right: int,
+              softcap: float, alibi_slopes: Optional[torch.Tensor], deterministic: bool,
+              rng_state: Optional[torch.Tensor] = None) -> torch.Tensor:
     dout, q, k, v, out = (_unit_stride_last(t) for t in (dout, q, k, v, out))
     dq, dk, dv, softmax_d = flash_attn_gpu.bwd(
         dout, q, k, v, out, softmax_lse, dq, dk, dv, alibi_slopes, dropout_p, softmax_scale, causal,
@@ -71,16 +102,43 @@ def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, dropout_p,
     return softmax_d
 
 
-def _flash_attn_varlen_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k,
-                                max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, window_size_left,
-                                window_size_right, softcap, alibi_slopes, deterministic, rng_state=None,
-                                zero_tensors=False):
+def _bwd_fake(dout, q, k, v, out, softmax_lse, dq, dk, dv, dropout_p, softmax_scale, causal, window_size_left,
+              window_size_right, softcap, alibi_slopes, deterministic, rng_state=None):
+    B, Sq, H, _ = q.shape
+    return torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)  # the ROCm shape (reference :333-336)
+
+
+def _varlen_bwd_impl(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor,
+                     softmax_lse: torch.Tensor, dq: Optional[torch.Tensor], dk: Optional[torch.Tensor],
+                     dv: Optional[torch.Tensor], cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor, max_seqlen_q: int,
+                     max_seqlen_k: int, dropout_p: float, softmax_scale: float, causal: bool, window_size_left: int,
+                     window_size_right: int, softcap: float, alibi_slopes: Optional[torch.Tensor], deterministic: bool,
+                     rng_state: Optional[torch.Tensor] = None, zero_tensors: bool = False) -> torch.Tensor:
     dout, q, k, v, out = (_unit_stride_last(t) for t in (dout, q, k, v, out))
     dq, dk, dv, softmax_d = flash_attn_gpu.varlen_bwd(
         dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, alibi_slopes, max_seqlen_q,
         max_seqlen_k, dropout_p, softmax_scale, zero_tensors, causal, window_size_left, window_size_right, softcap,
         deterministic, None, rng_state)
     return softmax_d
+
+
+def _varlen_bwd_fake(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                     dropout_p, softmax_scale, causal, window_size_left, window_size_right, softcap, alibi_slopes,
+                     deterministic, rng_state=None, zero_tensors=False):
+    total_q, H, _ = q.shape
+    return torch.empty((H, total_q), dtype=torch.float32, device=q.device)
+
+
+def _register(name, impl, fake, mutates=()):
+    op = torch.library.custom_op(f"flash_attn_amd::{name}", impl, mutates_args=mutates, device_types="cuda")
+    op.register_fake(fake)
+    return getattr(torch.ops.flash_attn_amd, name)
+
+
+_flash_attn_forward = _register("_flash_attn_forward", _fwd_impl, _fwd_fake)
+_flash_attn_varlen_forward = _register("_flash_attn_varlen_forward", _varlen_fwd_impl, _varlen_fwd_fake)
+_flash_attn_backward = _register("_flash_attn_backward", _bwd_impl, _bwd_fake, ("dq", "dk", "dv"))
+_flash_attn_varlen_backward = _register("_flash_attn_varlen_backward", _varlen_bwd_impl, _varlen_bwd_fake, ("dq", "dk", "dv"))
 
 
 class _AttnFn(torch.autograd.Function):

@@ -106,3 +106,29 @@ def test_extension_error_messages(fi):
                        -1, -1, 0.0, False, None, 2)
     with pytest.raises(RuntimeError):
         ext.fwd(q.float(), q.float(), q.float(), None, None, 0.0, 0.125, False, -1, -1, 0.0, False, None)
+
+
+def test_torch_compile_fullgraph_and_opcheck(fi):
+    """The registered custom ops trace without graph breaks (fullgraph) through forward and backward and agree with eager;
+    torch.library.opcheck validates schema, fake implementation and autograd registration of the forward op
+    (reference precedent: hopper/test_torch_compile_and_export.py)."""
+    torch.manual_seed(3)
+    q = torch.randn(2, 128, 4, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    k = torch.randn(2, 160, 2, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    v = torch.randn(2, 160, 2, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    g = torch.randn(2, 128, 4, 64, device="cuda", dtype=torch.bfloat16)
+
+    def f(q, k, v):
+        return fi.flash_attn_func(q, k, v, causal=True, window_size=(64, 0)) * 2.0
+
+    eager = f(q, k, v)
+    ge = torch.autograd.grad(eager, (q, k, v), g)
+    compiled = torch.compile(f, backend="aot_eager", fullgraph=True)
+    out = compiled(q, k, v)
+    gc = torch.autograd.grad(out, (q, k, v), g)
+    assert torch.equal(out, eager)
+    for a, b in zip(gc, ge):
+        assert torch.equal(a, b)
+    torch.library.opcheck(torch.ops.flash_attn_amd._flash_attn_forward.default,
+                          (q.detach(), k.detach(), v.detach(), 0.0, 0.125, True, -1, -1, 0.0, None, False),
+                          test_utils=("test_schema", "test_faketensor"))
