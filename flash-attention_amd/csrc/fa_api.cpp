@@ -87,6 +87,42 @@ int64_t splitkv_bytes(const FaFwdParams* a, int n_splits) {
   return (int64_t)n_splits * a->b * a->h * a->seqlen_q * (a->d + 1) * (int64_t)sizeof(float);
 }
 
+// Forward schedule code: 34 / 38 = software-pipelined kernel (fa_fwd_il.hip) with 4 / 8 waves per workgroup,
+// 4 / 8 = lock-step kernel with 4 / 8 waves, 16 = 8-wave ping-pong (fa_fwd.hip).  wl / wr = normalised window.
+int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
+  // Schedule (measured on MI355X, tools/ab_bench.py; FA_FWD_NW overrides):
+  //   34 / 38 = software-pipelined kernel (fa_fwd_il.hip) with 4 / 8 waves per workgroup,
+  //   4 / 8   = lock-step kernel with 4 / 8 waves, 16 = 8-wave ping-pong (fa_fwd.hip).
+  // 8-wave pipelined workgroups (Q block in LDS, one workgroup per CU) win on long key loops (>= ~48 tiles per
+  // query block); 4-wave pipelined workgroups (Q fragments in registers, two workgroups per CU hide each other's
+  // prologue/epilogue) win on shorter loops and under causal masks at S <= 8k.  D = 64 has half the MFMA work
+  // per softmax element and prefers 4-wave workgroups throughout.
+  int nw = env_int("FA_FWD_NW", 0);
+  if (nw != 4 && nw != 8 && nw != 16 && nw != 34 && nw != 38) {
+    const bool right_bounded = (wr >= 0);
+    const long avg_keys = right_bounded ? (a->seqlen_k + 1) / 2 : a->seqlen_k;
+    const long span = (wl >= 0) ? std::min<long>(avg_keys, wl + (wr >= 0 ? wr : a->seqlen_k) + 256) : avg_keys;
+    const long tiles = span / 64;
+    if (a->d == 128) nw = (tiles >= 48 && a->seqlen_q >= 512) ? 38 : (a->seqlen_q > 128 ? 34 : 4);
+    else nw = (a->seqlen_q > 128) ? 34 : 4;
+  }
+  return nw;
+}
+// query rows per workgroup of the schedule the forward will run (the lock-step variants serve softcap / ALiBi / dropout /
+// head dim 256 / split keys)
+int fwd_block_rows(const FaFwdParams* a, int nw, bool split) {
+  if (a->d > 128 || split) return 128;
+  if (nw == 34 || nw == 38) return 32 * (nw - 30);  // (the lock-step fallback of a pipelined schedule keeps the wave count)
+  return nw == 16 ? 256 : 32 * nw;
+}
+// varlen work list: worth a pre-pass when a max_seqlen-sized grid would be mostly empty slots
+int64_t varlen_list_entries(const FaFwdParams* a, int bm) {
+  if (env_int("FA_VARLEN_LIST", 1) == 0) return 0;  // debugging switch: always the dense grid
+  const int64_t dense = (int64_t)a->b * ((a->seqlen_q + bm - 1) / bm);
+  const int64_t bound = (int64_t)a->total_q / bm + a->b;
+  return (dense * 4 > bound * 5 && dense >= 64) ? bound : 0;
+}
+
 int check_common(int b, int h, int h_k, int d, int dtype, float softcap) {
   if (b <= 0) return fail(FA_ERR_INVALID_ARGUMENT, "batch size must be positive");
   if (h <= 0 || h_k <= 0 || h % h_k != 0)
@@ -158,22 +194,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     if (!(k.rescale_thr >= 0.f) || k.rescale_thr > 16.f) k.rescale_thr = 0.f;
   }
 
-  // Schedule (measured on MI355X, tools/ab_bench.py; FA_FWD_NW overrides):
-  //   34 / 38 = software-pipelined kernel (fa_fwd_il.hip) with 4 / 8 waves per workgroup,
-  //   4 / 8   = lock-step kernel with 4 / 8 waves, 16 = 8-wave ping-pong (fa_fwd.hip).
-  // 8-wave pipelined workgroups (Q block in LDS, one workgroup per CU) win on long key loops (>= ~48 tiles per
-  // query block); 4-wave pipelined workgroups (Q fragments in registers, two workgroups per CU hide each other's
-  // prologue/epilogue) win on shorter loops and under causal masks at S <= 8k.  D = 64 has half the MFMA work
-  // per softmax element and prefers 4-wave workgroups throughout.
-  int nw = env_int("FA_FWD_NW", 0);
-  if (nw != 4 && nw != 8 && nw != 16 && nw != 34 && nw != 38) {
-    const bool right_bounded = (wr >= 0);
-    const long avg_keys = right_bounded ? (a->seqlen_k + 1) / 2 : a->seqlen_k;
-    const long span = (wl >= 0) ? std::min<long>(avg_keys, wl + (wr >= 0 ? wr : a->seqlen_k) + 256) : avg_keys;
-    const long tiles = span / 64;
-    if (a->d == 128) nw = (tiles >= 48 && a->seqlen_q >= 512) ? 38 : (a->seqlen_q > 128 ? 34 : 4);
-    else nw = (a->seqlen_q > 128) ? 34 : 4;
-  }
+  int nw = fwd_schedule_nw(a, wl, wr);
   if (a->d > 128) nw = 4;  // head dim 256: one 4-wave lock-step workgroup per CU (512-register budget)
   // decode: split the keys over several workgroups when (batch x heads) cannot fill the chip
   if (kvcache) {
@@ -197,6 +218,18 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   if ((nw == 34 || nw == 38) && !il) nw -= 30;
   const int bm = il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
   k.nmb = (a->seqlen_q + bm - 1) / bm;
+  if (varlen && !kvcache) {  // uneven packed batch: enumerate the non-empty query blocks, heaviest first
+    const int64_t entries = varlen_list_entries(a, bm);
+    if (entries > 0 && a->workspace && a->workspace_bytes >= (entries + 1) * 8) {
+      fa::SchedK sk{};
+      sk.cu_a = a->cu_seqlens_q; sk.cu_o = a->cu_seqlens_k; sk.seqused_o = a->seqused_k;
+      sk.list = (int2*)a->workspace; sk.nb = a->b; sk.blk = bm; sk.bound = (int)entries; sk.wl = wl; sk.wr = wr; sk.keys_blocked = 0;
+      if (fa::launch_varlen_schedule(sk, (hipStream_t)stream) != 0)
+        return fail(FA_ERR_LAUNCH, "schedule kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+      k.work_list = (const int2*)a->workspace;
+      k.work_bound = (int)entries;
+    }
+  }
   fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb * k.n_splits, k.n_units, k.unit_size, k.unit_hpx);
   int rc = il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, a->d, nw - 30, (hipStream_t)stream)
                     : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
@@ -246,10 +279,44 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   return FA_OK;
 }
 
+// varlen backward work lists: query blocks for the dQ kernel, key blocks for the dK/dV kernel (entries each, 0 = dense grids)
+void bwd_list_entries(const FaBwdParams* a, int64_t& q_entries, int64_t& k_entries) {
+  q_entries = k_entries = 0;
+  if (!a->cu_seqlens_q || !a->cu_seqlens_k || env_int("FA_VARLEN_LIST", 1) == 0) return;
+  const int bm = a->d > 128 ? 128 : fa::bwd_block_m(), bn = fa::bwd_block_n(a->d);
+  const int64_t dq_dense = (int64_t)a->b * ((a->seqlen_q + bm - 1) / bm), dq_bound = (int64_t)a->total_q / bm + a->b;
+  const int64_t dk_dense = (int64_t)a->b * ((a->seqlen_k + bn - 1) / bn), dk_bound = (int64_t)a->total_k / bn + a->b;
+  if (dq_dense * 4 > dq_bound * 5 && dq_dense >= 64) q_entries = dq_bound;
+  if (dk_dense * 4 > dk_bound * 5 && dk_dense >= 64) k_entries = dk_bound;
+}
+
 int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   fa::BwdK k;
   if (int rc = fill_bwd(a, varlen, k)) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (varlen) {
+    int64_t qe, ke;
+    bwd_list_entries(a, qe, ke);
+    const int64_t need = (qe ? (qe + 1) * 8 : 0) + (ke ? (ke + 1) * 8 : 0);
+    if (need > 0 && a->workspace && a->workspace_bytes >= need) {
+      char* ws = (char*)a->workspace;
+      fa::SchedK sk{};
+      sk.nb = a->b; sk.wl = k.wl; sk.wr = k.wr;
+      if (qe) {
+        sk.cu_a = a->cu_seqlens_q; sk.cu_o = a->cu_seqlens_k; sk.list = (int2*)ws; sk.bound = (int)qe; sk.keys_blocked = 0;
+        sk.blk = a->d > 128 ? 128 : fa::bwd_block_m();
+        if (fa::launch_varlen_schedule(sk, s) != 0) return fail(FA_ERR_LAUNCH, "schedule kernel launch failed");
+        k.q_list = (const int2*)ws; k.q_bound = (int)qe;
+        ws += (qe + 1) * 8;
+      }
+      if (ke) {
+        sk.cu_a = a->cu_seqlens_k; sk.cu_o = a->cu_seqlens_q; sk.list = (int2*)ws; sk.bound = (int)ke; sk.keys_blocked = 1;
+        sk.blk = fa::bwd_block_n(a->d);
+        if (fa::launch_varlen_schedule(sk, s) != 0) return fail(FA_ERR_LAUNCH, "schedule kernel launch failed");
+        k.k_list = (const int2*)ws; k.k_bound = (int)ke;
+      }
+    }
+  }
   const int bf = a->dtype == FA_DTYPE_BF16;
   // Nothing to differentiate: the caller's dq/dk/dv hold no rows (Sq == 0 / Sk == 0 with fixed
   // shapes are handled by the binder, which zero-fills as flash_api.cpp:992-999 does).
@@ -329,13 +396,23 @@ int fa_set_rng_state(uint64_t seed, uint64_t offset, uint64_t* rng_state, void* 
 
 int64_t fa_fwd_workspace_bytes(const FaFwdParams* params) {
   if (!params) return 0;
+  if (params->cu_seqlens_q) {  // varlen forward: the work list of an uneven packed batch
+    int causal = params->is_causal, wl = params->window_left, wr = params->window_right;
+    normalize_window(params->seqlen_q, params->seqlen_k, params->alibi_slopes != nullptr, causal, wl, wr);
+    const int nw = params->d > 128 ? 4 : fwd_schedule_nw(params, wl, wr);
+    const int64_t entries = varlen_list_entries(params, fwd_block_rows(params, nw, false));
+    return entries > 0 ? (entries + 1) * 8 : 0;
+  }
   int split_tiles = 0;
   return splitkv_bytes(params, choose_splits(params, split_tiles));
 }
 
 int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {
-  (void)params;
-  return 0;  // the two-pass backward (dK/dV kernel + dQ kernel) needs no fp32 dq accumulator
+  // the two-pass backward (dK/dV kernel + dQ kernel) needs no fp32 dq accumulator; an uneven packed batch gets work lists
+  if (!params) return 0;
+  int64_t qe, ke;
+  bwd_list_entries(params, qe, ke);
+  return (qe ? (qe + 1) * 8 : 0) + (ke ? (ke + 1) * 8 : 0);
 }
 int fa_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, false); }
 int fa_varlen_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, true); }

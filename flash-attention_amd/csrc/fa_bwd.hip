@@ -107,12 +107,17 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   // each XCD walks all key blocks of its units, so it sees every key-block index equally often.  (With a plain (n, h, b) grid XCD x
   // would only ever get key blocks n = x mod 8 -- under a causal mask a 2.4x work imbalance between XCDs.)
   // Within a head the low key blocks come first: they see the most queries under a causal mask.
-  const int w = xcd_interleave(blockIdx.x, p.k_units, p.k_unit_size, p.k_unit_hpx);
-  if (w < 0) return;
-  const int bhk = w / p.nnb;
-  const int n_block = w - bhk * p.nnb;
-  const int b = bhk / p.h_k;
-  const int hk = bhk - b * p.h_k;
+  int b, hk, n_block;
+  if (p.k_list) {  // varlen: non-empty key blocks only, heaviest first
+    if (!work_list_item(p.k_list, blockIdx.x, p.h_k, p.h_k, b, hk, n_block)) return;
+  } else {
+    const int w = xcd_interleave(blockIdx.x, p.k_units, p.k_unit_size, p.k_unit_hpx);
+    if (w < 0) return;
+    const int bhk = w / p.nnb;
+    n_block = w - bhk * p.nnb;
+    b = bhk / p.h_k;
+    hk = bhk - b * p.h_k;
+  }
   int sq = p.sq, sk = p.sk;
   int64_t q_row0 = 0, k_row0 = 0;
   int64_t q_boff = (int64_t)b * p.q_bs, do_boff = (int64_t)b * p.do_bs;
@@ -390,12 +395,19 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, qi = lane & 31;
 
-  const int w = xcd_interleave(blockIdx.x, p.q_units, p.q_unit_size, p.q_unit_hpx);
-  if (w < 0) return;
-  const int bh = w / p.nmb;
-  const int mbr = w - bh * p.nmb;
-  const int m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
-  const int b = bh / p.h, h = bh - b * p.h, hk = h / p.hk_ratio;
+  int b, h, m_block;
+  if (p.q_list) {  // varlen: non-empty query blocks only, heaviest first (fa_varlen_schedule_kernel)
+    if (!work_list_item(p.q_list, blockIdx.x, p.h, p.h_k, b, h, m_block)) return;
+  } else {
+    const int w = xcd_interleave(blockIdx.x, p.q_units, p.q_unit_size, p.q_unit_hpx);
+    if (w < 0) return;
+    const int bh = w / p.nmb;
+    const int mbr = w - bh * p.nmb;
+    m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
+    b = bh / p.h;
+    h = bh - b * p.h;
+  }
+  const int hk = h / p.hk_ratio;
 
   int sq = p.sq, sk = p.sk;
   int64_t q_row0 = 0, k_row0 = 0;
@@ -617,7 +629,7 @@ static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
     attr_done = true;
   }
-  const long long total = units_grid(p.k_units, p.k_unit_size);
+  const long long total = p.k_list ? (long long)p.k_bound * p.h_k : units_grid(p.k_units, p.k_unit_size);
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NWK * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -636,7 +648,7 @@ static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
     attr_done = true;
   }
-  const long long total = units_grid(p.q_units, p.q_unit_size);
+  const long long total = p.q_list ? (long long)p.q_bound * p.h : units_grid(p.q_units, p.q_unit_size);
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -122,6 +122,32 @@ FA_DEVINL int xcd_interleave(int bid, int n_units, int unit_size, int hpx) {
   return unit < n_units ? unit * unit_size + item : -1;
 }
 
+// ---- varlen work list ---------------------------------------------------------------------------------
+// A packed batch with uneven lengths leaves most (batch, block) slots of a max_seqlen-sized grid empty.  The
+// schedule kernel writes the non-empty query (or key) blocks, heaviest first, as {batch, block} pairs after a
+// header {count, 0}; workgroup `bid` then takes (head, item): KV heads are dealt to the XCDs (all blocks and all query
+// heads of one KV head share an L2) when there are >= 8 of them, heads round-robin otherwise.
+FA_DEVINL bool work_list_item(const int2* __restrict__ list, int bid, int h, int h_k, int& b, int& head, int& blk) {
+  constexpr int NX = 8;
+  const int count = list[0].x;
+  int item;
+  if (h_k % NX == 0) {
+    const int ratio = h / h_k, per = h_k / NX;
+    const int x = bid % NX, r = bid / NX;
+    const int g = r % ratio, hl = (r / ratio) % per;
+    item = r / (ratio * per);
+    head = (x * per + hl) * ratio + g;
+  } else {
+    head = bid % h;
+    item = bid / h;
+  }
+  if (item >= count) return false;
+  const int2 e = list[1 + item];
+  b = e.x;
+  blk = e.y;
+  return true;
+}
+
 // ---- dropout random stream --------------------------------------------------------------------------
 // Counter-based: the random byte of element (batch b, query head h, query i, key j) is a pure function of
 // (seed, offset, b, h, i, j), so the forward and both backward kernels regenerate the same mask in their own

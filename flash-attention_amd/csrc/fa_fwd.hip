@@ -75,16 +75,21 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   const int hi = lane >> 5, qi = lane & 31;
 
   // ---- which (batch, head, query block) -------------------------------------------------------
-  const int w = xcd_interleave(blockIdx.x, p.n_units, p.unit_size, p.unit_hpx);
-  if (w < 0) return;
-  const int nmbs = p.nmb * p.n_splits;  // n_splits >= 1: key splits of one query block are adjacent work items
-  const int bh = w / nmbs;
-  int mbr = w - bh * nmbs;
-  const int split = mbr % p.n_splits;
-  mbr /= p.n_splits;
-  const int m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
-  const int b = bh / p.h;
-  const int h = bh - b * p.h;
+  int b, h, m_block, split = 0;
+  if (p.work_list) {  // varlen: non-empty blocks only, heaviest first
+    if (!work_list_item(p.work_list, blockIdx.x, p.h, p.h_k, b, h, m_block)) return;
+  } else {
+    const int w = xcd_interleave(blockIdx.x, p.n_units, p.unit_size, p.unit_hpx);
+    if (w < 0) return;
+    const int nmbs = p.nmb * p.n_splits;  // n_splits >= 1: key splits of one query block are adjacent work items
+    const int bh = w / nmbs;
+    int mbr = w - bh * nmbs;
+    split = mbr % p.n_splits;
+    mbr /= p.n_splits;
+    m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
+    b = bh / p.h;
+    h = bh - b * p.h;
+  }
   const int hk = h / p.hk_ratio;
 
   int sq = p.sq, sk = p.sk;
@@ -608,6 +613,63 @@ int launch_rotary(const RotaryK& p, int dtype_bf16, hipStream_t stream) {
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   if (dtype_bf16) hipLaunchKernelGGL(fa_rotary_kernel<__bf16>, grid, block, 0, stream, p);
   else hipLaunchKernelGGL(fa_rotary_kernel<_Float16>, grid, block, 0, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Varlen work list (FA3 has a scheduler pre-pass for the same reason, hopper/flash_prepare_scheduler.cu): one workgroup
+// enumerates the non-empty blocks of the blocked side (query blocks for the forward / dQ, key blocks for dK/dV), estimates
+// each block's work from the mask geometry and writes them heaviest first by a counting sort on work in 64-row tiles.  The
+// order inside a bucket depends on atomics, the results of the attention kernels do not.
+__global__ void __launch_bounds__(1024) fa_varlen_schedule_kernel(const SchedK p) {
+  __shared__ int hist[1024];
+  __shared__ int total;
+  const int t = threadIdx.x;
+  hist[t] = 0;
+  if (t == 0) total = 0;
+  __syncthreads();
+  auto work_key = [&](int len_a, int len_o, int blkidx) {
+    const int a0 = blkidx * p.blk, a1 = min(a0 + p.blk, len_a) - 1;
+    int lo, hi;
+    if (p.keys_blocked == 0) {  // a = queries, o = keys: visible keys of rows a0..a1 (mask.h:172-203 geometry)
+      const int shift = len_o - len_a;
+      hi = len_o - 1; lo = 0;
+      if (p.wr >= 0) hi = min(hi, a1 + shift + p.wr);
+      if (p.wl >= 0) lo = max(0, a0 + shift - p.wl);
+    } else {                    // a = keys, o = queries: queries that see keys a0..a1
+      const int shift = len_a - len_o;
+      hi = len_o - 1; lo = 0;
+      if (p.wr >= 0) lo = max(0, a0 - shift - p.wr);
+      if (p.wl >= 0) hi = min(hi, a1 - shift + p.wl);
+    }
+    const int w = max(0, hi - lo + 1);
+    return 1023 - min(1023, (w + 63) >> 6);  // bucket 0 = heaviest
+  };
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int b = t; b < p.nb; b += 1024) {
+      const int len_a = p.cu_a[b + 1] - p.cu_a[b];
+      int len_o = p.cu_o[b + 1] - p.cu_o[b];
+      if (p.seqused_o) len_o = min(len_o, p.seqused_o[b]);
+      const int nblk = (len_a + p.blk - 1) / p.blk;
+      for (int m = 0; m < nblk; ++m) {
+        const int key = work_key(len_a, len_o, m);
+        const int pos = atomicAdd(&hist[key], 1);   // pass 0: count; pass 1: hist holds the bucket cursors
+        if (pass == 1 && pos < p.bound) p.list[1 + pos] = make_int2(b, m);
+      }
+      if (pass == 0) atomicAdd(&total, nblk);
+    }
+    __syncthreads();
+    if (pass == 0) {
+      if (t == 0) {  // exclusive scan, heaviest bucket first
+        int run = 0;
+        for (int k = 0; k < 1024; ++k) { const int c = hist[k]; hist[k] = run; run += c; }
+        p.list[0] = make_int2(min(total, p.bound), 0);
+      }
+      __syncthreads();
+    }
+  }
+}
+int launch_varlen_schedule(const SchedK& p, hipStream_t stream) {
+  hipLaunchKernelGGL(fa_varlen_schedule_kernel, dim3(1), dim3(1024), 0, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

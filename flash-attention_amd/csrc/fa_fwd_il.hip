@@ -62,13 +62,18 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, qi = lane & 31;
 
-  const int w = xcd_interleave(blockIdx.x, p.n_units, p.unit_size, p.unit_hpx);
-  if (w < 0) return;
-  const int bh = w / p.nmb;
-  const int mbr = w - bh * p.nmb;
-  const int m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
-  const int b = bh / p.h;
-  const int h = bh - b * p.h;
+  int b, h, m_block;
+  if (p.work_list) {  // varlen: non-empty blocks only, heaviest first (fa_varlen_schedule_kernel)
+    if (!work_list_item(p.work_list, blockIdx.x, p.h, p.h_k, b, h, m_block)) return;
+  } else {
+    const int w = xcd_interleave(blockIdx.x, p.n_units, p.unit_size, p.unit_hpx);
+    if (w < 0) return;
+    const int bh = w / p.nmb;
+    const int mbr = w - bh * p.nmb;
+    m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
+    b = bh / p.h;
+    h = bh - b * p.h;
+  }
   const int hk = h / p.hk_ratio;
 
   int sq = p.sq, sk = p.sk;
@@ -585,7 +590,7 @@ static int launch_fwd_il_t(const FwdK& p, hipStream_t stream) {
     if (hipFuncGetAttributes(&fattr, (const void*)kern) != hipSuccess || fattr.sharedSizeBytes != 0) return -1;
     attr_done = true;
   }
-  const long long total = units_grid(p.n_units, p.unit_size);
+  const long long total = p.work_list ? (long long)p.work_bound * p.h : units_grid(p.n_units, p.unit_size);
   if (total <= 0) return 0;
 #ifdef FA_IL_EXPERIMENTS  // occupancy experiments: extra (unused) dynamic LDS
   if (const char* e = getenv("FA_IL_LDS_PAD")) {

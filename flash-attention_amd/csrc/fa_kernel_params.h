@@ -2,6 +2,7 @@
 // public C-ABI structs of include/fa_gfx950.h after validation/normalisation (fa_api.cpp).
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 namespace fa {
 
@@ -36,6 +37,8 @@ struct FwdK {
   float scale_log2;          // softmax_scale * log2(e)
   float softcap;             // 0 = off
   float rescale_thr;         // O rescale deferred until a row max grows by more than this (log2 units)
+  int32_t work_bound;        // entries the list can hold (grid = work_bound * h)
+  const int2* work_list;     // varlen: {count,0}, then {batch, query block} pairs, heaviest first (nullptr => dense grid)
   // split-KV (decode): n_splits > 1 => workgroup (.., split) scans key tiles [split*split_tiles, (split+1)*split_tiles) and
   // writes a normalised fp32 partial output + its log-sum-exp; fa_splitkv_combine_kernel merges them
   int32_t n_splits, split_tiles;
@@ -83,6 +86,9 @@ struct BwdK {
   float scale;
   float scale_log2;
   float softcap;
+  int32_t q_bound, k_bound;
+  const int2* q_list;        // varlen work lists of the dQ kernel (query blocks) and the dK/dV kernel (key blocks)
+  const int2* k_list;
   const uint64_t* rng;       // dropout, as in FwdK
   uint32_t drop_thr8;
   int32_t drop_groups;

@@ -34,6 +34,12 @@ struct KvAppendK {
 };
 int launch_kv_append(const KvAppendK& p, hipStream_t stream);
 // Software-pipelined forward (fa_fwd_il.hip); nw = 4 or 8 waves per workgroup.  No softcap / ALiBi variant.
+// varlen work-list pre-pass: blocks of `blk` rows of side a (cu_a), work estimated against side o (cu_o)
+struct SchedK {
+  const int32_t* cu_a; const int32_t* cu_o; const int32_t* seqused_o;
+  int2* list; int32_t nb, blk, bound, wl, wr, keys_blocked;
+};
+int launch_varlen_schedule(const SchedK& p, hipStream_t stream);
 struct RotaryK {
   const void* x; void* y; const void* cos; const void* sin; const int32_t* offsets;
   int64_t x_bs, x_rs, x_hs, y_bs, y_rs, y_hs, cos_rs;

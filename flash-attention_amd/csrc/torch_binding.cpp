@@ -232,6 +232,12 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
         a.randval_batch_stride = 0; a.randval_head_stride = p.stride(0); a.randval_row_stride = p.stride(1);
       }
     }
+    Tensor ws;  // work list of an uneven packed batch (0 bytes = dense grid)
+    const int64_t ws_bytes = fa_fwd_workspace_bytes(&a);
+    if (ws_bytes > 0) {
+      ws = at::empty({ws_bytes}, q.options().dtype(at::kByte));
+      a.workspace = ws.data_ptr(); a.workspace_bytes = ws_bytes;
+    }
     fa_check(fa_varlen_fwd(&a, cur_stream(q)));
   }
   if (Dn != D) {

@@ -225,7 +225,12 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
                 a.randval = _ptr(p_out)
                 a.randval_batch_stride, a.randval_head_stride, a.randval_row_stride = 0, p_out.stride(0), p_out.stride(1)
         with torch.cuda.device(q.device):
-            _cabi.check(_cabi.load().fa_varlen_fwd(C.byref(a), C.c_void_p(_stream_ptr(q.device))))
+            lib = _cabi.load()
+            ws_bytes = lib.fa_fwd_workspace_bytes(C.byref(a))  # work list of an uneven packed batch (0 = dense grid)
+            if ws_bytes > 0:
+                ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=q.device)
+                a.workspace, a.workspace_bytes = _ptr(ws), ws_bytes
+            _cabi.check(lib.fa_varlen_fwd(C.byref(a), C.c_void_p(_stream_ptr(q.device))))
     if Dn != D:
         res = out[..., :D]
         if out_ is not None:

@@ -196,3 +196,47 @@ def test_softcap_backward_vs_oracle(be, d, alibi):
     for got, r in zip((dq, dk, dv), ref[:3]):
         r = torch.from_numpy(r)
         assert max_abs(got.float().cpu(), r) < 3e-2 * max(1.0, float(r.abs().max())), float(r.abs().max())
+
+
+@pytest.mark.parametrize("causal,window", [(True, (-1, -1)), (False, (-1, -1)), (False, (300, 100))])
+@pytest.mark.parametrize("hk", [8, 2])
+def test_varlen_work_list_equals_dense_grid(be, monkeypatch, hk, causal, window):
+    """Uneven packed batch (long-tail lengths, empty sequences included): the scheduled work list (forward, dQ and dK/dV)
+    gives bit-for-bit the results of the dense max_seqlen grid, and both match the oracle on sampled sequences."""
+    from oracle import attention_oracle as orc
+    g = torch.Generator().manual_seed(5)
+    lens = [int(x) for x in (torch.rand(90, generator=g) ** 4 * 1500).long()] + [2048, 0, 1, 1900]
+    lens_k = [max(0, l + int(d)) for l, d in zip(lens, torch.randint(-40, 40, (len(lens),), generator=g))] if not causal else lens
+    H, d = 8, 128
+    cu_q = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0] + list(np.cumsum(lens_k)), dtype=torch.int32, device="cuda")
+    torch.manual_seed(0)
+    q = torch.randn(sum(lens), H, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(sum(lens_k), hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    do = torch.randn_like(q)
+    scale = d ** -0.5
+
+    def run():
+        out, lse, _, _ = be.varlen_fwd(q, k, v, None, cu_q, cu_k, None, None, None, None, max(lens), max(lens_k), 0.0, scale, False, causal,
+                                       window[0], window[1], 0.0, False, None)
+        dq, dk, dv, _ = be.varlen_bwd(do, q, k, v, out, lse, None, None, None, cu_q, cu_k, None, max(lens), max(lens_k), 0.0, scale, False,
+                                      causal, window[0], window[1], 0.0, False, None, None)
+        return out, lse, dq, dk, dv
+
+    monkeypatch.setenv("FA_FWD_NW", "34")
+    listed = run()
+    monkeypatch.setenv("FA_VARLEN_LIST", "0")
+    dense = run()
+    for a, b_ in zip(listed, dense):
+        assert torch.equal(a, b_)
+    for b in (0, 5, 90, 91, 92, 93):
+        qs, ks = slice(int(cu_q[b]), int(cu_q[b + 1])), slice(int(cu_k[b]), int(cu_k[b + 1]))
+        if lens[b] == 0:
+            assert float(listed[3][ks].abs().max()) == 0.0 if lens_k[b] else True   # no query sees these keys: exact zeros
+            continue
+        o_ref, _ = orc.attention_fwd(q[qs][None], k[ks][None], v[ks][None], scale, causal, window)
+        assert max_abs(listed[0][qs].float().cpu(), torch.from_numpy(o_ref[0])) < 2e-2
+        rq, rk, rv, _ = orc.attention_bwd(do[qs][None], q[qs][None], k[ks][None], v[ks][None], None, None, scale, causal, window)
+        for got, ref in ((listed[2][qs], rq[0]), (listed[3][ks], rk[0]), (listed[4][ks], rv[0])):
+            assert max_abs(got.float().cpu(), torch.from_numpy(ref)) < 4e-2 * max(1.0, float(np.abs(ref).max()))
