@@ -141,7 +141,7 @@ def main():
                        "batch": B, "heads": H, "seqlen": S, "head_dim": D, "causal": causal, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(flops / ms / 1e9, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "fa::fa_fwd_il_kernel<bf16,128,8> (software-pipelined forward)", "algorithmic_flops_per_launch": flops, "kernel_ms": round(ms, 4)},
+                         "kernel": "fa::fa_fwd_il_kernel<bf16,128,4,3> (software-pipelined forward, 4-wave workgroups; schedule chosen in fa_api.cpp)", "algorithmic_flops_per_launch": flops, "kernel_ms": round(ms, 4)},
             "fwd_bwd": {"tflops": round(3.5 * flops / (ms + ms_bwd) / 1e9, 2), "bwd_tflops": round(2.5 * flops / ms_bwd / 1e9, 2),
                         "bwd_ms": round(ms_bwd, 4), "frac_of_peak": round(3.5 * flops / (ms + ms_bwd) / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)},
         }
