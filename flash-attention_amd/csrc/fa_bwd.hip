@@ -21,10 +21,18 @@
 // dS = P*(dP - delta) (:584-595), P and dS rounded to the input dtype before their contractions,
 // softmax_scale applied once at the end (:733, flash_bwd_preprocess_kernel.h:250).
 #include <cstdlib>
+#include <type_traits>
 
 #include "fa_device.h"
 #include "fa_kernel_params.h"
 #include "fa_launch.h"
+
+#ifndef FA_BWD_PF
+#define FA_BWD_PF 3    // dK/dV kernel: row-major LDS operands are read this many MFMA slots minus one ahead
+#endif
+#ifndef FA_BWD_PFT
+#define FA_BWD_PFT 3   // same for the transposed operands of the dV / dK products
+#endif
 
 namespace fa {
 
@@ -93,8 +101,9 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   constexpr int KS = D / 16, DB = D / 32;
   constexpr int VBLK_BYTES = BNK * ROW_BYTES;
   constexpr int QT_BYTES = BMQ * ROW_BYTES;
-  // LDS: V block | Q0 | Q1 | dO0 | dO1 | aux0 aux1   (aux = BMQ x LSE*log2e followed by BMQ x delta)
-  constexpr int OFF_Q = VBLK_BYTES, OFF_DO = OFF_Q + 2 * QT_BYTES, OFF_AUX = OFF_DO + 2 * QT_BYTES;
+  // LDS: Q0 | Q1 | dO0 | dO1 | V block | aux0 aux1   (aux = BMQ x LSE*log2e followed by BMQ x delta).  The streamed tiles
+  // sit below 64 KB so that (buffer, sub-block) offsets fit the 16-bit immediate of ds_read.
+  constexpr int OFF_Q = 0, OFF_DO = 2 * QT_BYTES, OFF_V = 4 * QT_BYTES, OFF_AUX = OFF_V + VBLK_BYTES;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char FA_LDS* lds = (char FA_LDS*)smem;
@@ -162,7 +171,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
       const int idx = tid + i * NT;
       const int row = idx / CPR, ch = idx % CPR;
       const u32x4 x = ld_global_16B(vp + (int64_t)(n0 + row) * p.v_rs + ch * 8, n0 + row < sk);
-      *(u32x4 FA_LDS*)(lds + tile_off<D>(row, ch)) = x;
+      *(u32x4 FA_LDS*)(lds + OFF_V + tile_off<D>(row, ch)) = x;
     }
   }
 
@@ -234,8 +243,18 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   lds_dma_wait_all();
   __syncthreads();
 
-  for (int it = 0; it < n_items; ++it) {
-    const int cur = it & 1;
+  // Per-lane operand offsets inside a 32-row sub-tile.  Row-major fragment of k-step ks: k0 ^ (ks << 5) (the row offset has
+  // zero low bits, so the swizzled chunk index (2ks+hi)^swz folds into one XOR); the V block adds a multiple of 8 KB.
+  // The 8 + 8 + 8 derived addresses are recomputed where they are used (one v_xor each) behind an opaque copy of the
+  // base: hoisted out of the loop they cost 24 registers the accumulators need, and a spill reload waits on vmcnt(0),
+  // i.e. on the Q/dO DMA prefetch in flight.
+  const int k0 = row_off + ((hi ^ rswz) << 4);
+  const int kv0 = k0 + OFF_V + wave * 32 * ROW_BYTES;
+  const int aux_lane = OFF_AUX + 4 * hi * 4;
+  auto opaque = [](int x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); return x; };
+
+  auto item = [&](auto curc, int it) __attribute__((always_inline)) {
+    constexpr int cur = decltype(curc)::value;
     const bool has_next = it + 1 < n_items;
     if (has_next) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
     const int m0 = item_m0(it);
@@ -243,8 +262,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
     const bool drop = XFORM && (p.rng != nullptr);
     // stream key of this (batch, query head) plus this lane's key group; rows are added per 4-query group below
     const uint32_t drop_col = drop ? (drop_bh_key(p.rng, b * p.h + item_head(it)) + (uint32_t)(my_key >> 2)) : 0u;
-    const char FA_LDS* qbuf = lds + OFF_Q + cur * QT_BYTES;
-    const char FA_LDS* dobuf = lds + OFF_DO + cur * QT_BYTES;
+    constexpr int QB_OFF = OFF_Q + cur * QT_BYTES, DOB_OFF = OFF_DO + cur * QT_BYTES;
 
 #pragma unroll
     for (int qb = 0; qb < BMQ / 32; ++qb) {
@@ -253,23 +271,39 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
       if (p.wr >= 0) active = active && (wk0 <= q0 + 31 + shift + p.wr);
       if (p.wl >= 0) active = active && (wk1 >= q0 + shift - p.wl);
       if (!active) continue;
+      const int sub = qb * 32 * ROW_BYTES;
 
-      // S[query][key] = Q.K^T ; dP[query][key] = dO.V^T   (column = key = lane)
+      // S[query][key] = Q.K^T ; dP[query][key] = dO.V^T   (column = key = lane).  The two accumulation chains alternate
+      // (op j = k-step j/2 of S for even j, of dP for odd j) and the LDS operands are read PF-1 ops ahead.
       f32x16 s, dp;
+      {
+        constexpr int NOPS = 2 * KS, PF = FA_BWD_PF;
+        u32x4 ra[PF], rb[2];
+        const int k0p = opaque(k0), kv0p = opaque(kv0);
+        auto rd = [&](int j) __attribute__((always_inline)) {
+          const int ks = j >> 1;
+          if ((j & 1) == 0) {
+            ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (QB_OFF + sub) + (k0p ^ (ks << 5)));
+          } else {
+            ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (DOB_OFF + sub) + (k0p ^ (ks << 5)));
+            rb[ks & 1] = *(const u32x4 FA_LDS*)(lds + (kv0p ^ (ks << 5)));
+          }
+        };
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int j = 0; j < PF - 1; ++j) rd(j);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int coff = row_off + qb * 32 * ROW_BYTES + (((2 * ks + hi) ^ rswz) << 4);
-        const u32x4 qa = *(const u32x4 FA_LDS*)(qbuf + coff);
-        s = T::mfma(bitcast_u32x4<V8>(qa), kf[ks], s);
-      }
+        for (int j = 0; j < NOPS; ++j) {
+          if (j + PF - 1 < NOPS) rd(j + PF - 1);
+          __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this op's MFMA
+          const int ks = j >> 1;
+          f32x16 c = (j & 1) ? dp : s;
+          if (j < 2) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int coff = row_off + qb * 32 * ROW_BYTES + (((2 * ks + hi) ^ rswz) << 4);
-        const u32x4 da = *(const u32x4 FA_LDS*)(dobuf + coff);
-        const u32x4 vb = *(const u32x4 FA_LDS*)(lds + row_off + wave * 32 * ROW_BYTES + (((2 * ks + hi) ^ rswz) << 4));
-        dp = T::mfma(bitcast_u32x4<V8>(da), bitcast_u32x4<V8>(vb), dp);
+            for (int r = 0; r < 16; ++r) c[r] = 0.f;
+          }
+          if ((j & 1) == 0) s = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), kf[ks], c);
+          else dp = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), bitcast_u32x4<V8>(rb[ks & 1]), c);
+        }
       }
 
       f32x16 dcap;  // d(softcap*tanh(x/softcap))/dx = 1 - tanh^2 (reference flash_bwd_kernel.h:588 / utils.h:395-409)
@@ -303,11 +337,11 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
 
       // P = exp2(S*c - LSE*log2e); dS = P * (dP - delta): rows are queries acc_row(r,hi)
       V8 pfrag[2], dsfrag[2];
+      const int auxp = opaque(aux_lane);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int qoff = (cur * 2 * BMQ + qb * 32 + 8 * g + 4 * hi) * 4;
-        const f32x4 l4 = *(const f32x4 FA_LDS*)(lds + OFF_AUX + qoff);
-        const f32x4 d4 = *(const f32x4 FA_LDS*)(lds + OFF_AUX + BMQ * 4 + qoff);
+        const f32x4 l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (cur * 2 * BMQ + qb * 32 + 8 * g) * 4);
+        const f32x4 d4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (cur * 2 * BMQ + qb * 32 + 8 * g) * 4 + BMQ * 4);
         // Dropout: the 4 lanes of a quad hold the 4 keys of one key group; lane a hashes query row a of this 4-row
         // group (4 bytes = those 4 keys) and the quad exchanges words, so each lane reads its key's byte of every row.
         uint32_t hq = 0u;
@@ -335,17 +369,26 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
       }
 
       // dV^T[d][key] += dO^T[d][query] . P[query][key] ;  dK^T[d][key] += Q^T[d][query] . dS[query][key]
+      // op i: source = dO (even) / Q (odd), d-block (i>>1) % DB, query half t = i / (2*DB); transpose reads PFT-1 ops ahead
+      {
+        constexpr int NOPS = 4 * DB, PFT = FA_BWD_PFT;
+        s16x4 tlo[PFT], thi[PFT];
+        const int t0p = opaque(tr_base[0]), t1p = opaque(tr_base[1]);
+        auto rd = [&](int i) __attribute__((always_inline)) {
+          const int db = (i >> 1) % DB, t = i / (2 * DB);
+          const int base = ((i & 1) ? QB_OFF : DOB_OFF) + sub + 16 * t * ROW_BYTES;
+          tlo[i % PFT] = lds_read_tr16(lds + base + (t0p ^ (db << 6)));
+          thi[i % PFT] = lds_read_tr16(lds + base + (t1p ^ (db << 6)));
+        };
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+        for (int i = 0; i < PFT - 1; ++i) rd(i);
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-          const int base = (qb * 32 + 16 * t) * ROW_BYTES;
-          const s16x4 d_lo = lds_read_tr16(dobuf + base + (tr_base[0] ^ (db << 6)));
-          const s16x4 d_hi = lds_read_tr16(dobuf + base + (tr_base[1] ^ (db << 6)));
-          dv_acc[db] = T::mfma(combine_tr<V8>(d_lo, d_hi), pfrag[t], dv_acc[db]);
-          const s16x4 q_lo4 = lds_read_tr16(qbuf + base + (tr_base[0] ^ (db << 6)));
-          const s16x4 q_hi4 = lds_read_tr16(qbuf + base + (tr_base[1] ^ (db << 6)));
-          dk_acc[db] = T::mfma(combine_tr<V8>(q_lo4, q_hi4), dsfrag[t], dk_acc[db]);
+        for (int i = 0; i < NOPS; ++i) {
+          if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const int db = (i >> 1) % DB, t = i / (2 * DB);
+          if ((i & 1) == 0) dv_acc[db] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), pfrag[t], dv_acc[db]);
+          else dk_acc[db] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), dsfrag[t], dk_acc[db]);
         }
       }
     }
@@ -353,6 +396,10 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
     if (has_next) store_item(cur ^ 1);
     lds_dma_wait_all();
     __syncthreads();
+  };
+  for (int it = 0; it < n_items; it += 2) {
+    item(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < n_items) item(std::integral_constant<int, 1>{}, it + 1);
   }
 
   // ---- epilogue: dK = scale * acc, dV = acc; every key row of the block is written (zeros included) --
