@@ -549,34 +549,49 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
     __syncthreads();
   }
 
-  for (int n = n_min; n < n_max; ++n) {
-    const int cur = (n - n_min) & 1;
+  // per-lane operand bases (see the dK/dV kernel): k-step ks of a row-major fragment = k0 ^ (ks << 5)
+  const int k0 = row_off + ((hi ^ rswz) << 4);
+  auto opaque = [](int x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); return x; };
+
+  auto tile = [&](auto curc, int n) __attribute__((always_inline)) {
+    constexpr int cur = decltype(curc)::value;
+    constexpr int KB_OFF = cur * TILE_BYTES, VB_OFF = (2 + cur) * TILE_BYTES;
     const int kv0 = n * BN;
     const bool has_next = n + 1 < n_max;
     if (has_next) load_tile(n + 1, cur ^ 1);  // lands in the other buffers while this tile is computed
 
     const bool active = wave_valid && (kv0 <= w_kmax) && (kv0 + BN - 1 >= w_kmin);
     if (active) {
-      const char FA_LDS* kbuf = lds + cur * TILE_BYTES;
-      const char FA_LDS* vbuf = lds + (2 + cur) * TILE_BYTES;
       const bool need_mask = (kv0 + BN - 1 > w_full_hi) || (kv0 < w_full_lo);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        // S^T[key][query] = K.Q^T ; dP^T[key][query] = V.dO^T   (column = query = lane)
+        const int sub = kb * 32 * ROW_BYTES;
+        // S^T[key][query] = K.Q^T ; dP^T[key][query] = V.dO^T   (column = query = lane); the two chains alternate and
+        // the LDS operands are read PF-1 ops ahead
         f32x16 s, dp;
+        {
+          constexpr int NOPS = 2 * KS, PF = FA_BWD_PF;
+          u32x4 ra[PF];
+          const int k0p = opaque(k0);
+          auto rd = [&](int j) __attribute__((always_inline)) {
+            const int ks = j >> 1;
+            ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (((j & 1) ? VB_OFF : KB_OFF) + sub) + (k0p ^ (ks << 5)));
+          };
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+          for (int j = 0; j < PF - 1; ++j) rd(j);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int coff = row_off + kb * 32 * ROW_BYTES + (((2 * ks + hi) ^ rswz) << 4);
-          const u32x4 ka = *(const u32x4 FA_LDS*)(kbuf + coff);
-          s = T::mfma(bitcast_u32x4<V8>(ka), qf[ks], s);
-        }
+          for (int j = 0; j < NOPS; ++j) {
+            if (j + PF - 1 < NOPS) rd(j + PF - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int ks = j >> 1;
+            f32x16 c = (j & 1) ? dp : s;
+            if (j < 2) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int coff = row_off + kb * 32 * ROW_BYTES + (((2 * ks + hi) ^ rswz) << 4);
-          const u32x4 va = *(const u32x4 FA_LDS*)(vbuf + coff);
-          dp = T::mfma(bitcast_u32x4<V8>(va), dof[ks], dp);
+              for (int r = 0; r < 16; ++r) c[r] = 0.f;
+            }
+            if ((j & 1) == 0) s = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), qf[ks], c);
+            else dp = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), dof[ks], c);
+          }
         }
         f32x16 dcap;
         if constexpr (XFORM) {
@@ -619,21 +634,34 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
           if constexpr (XFORM) dsv *= dcap[r];
           dsfrag[r >> 3][r & 7] = (E)dsv;
         }
-        // dQ^T[d][query] += K^T[d][key] . dS^T[key][query]
+        // dQ^T[d][query] += K^T[d][key] . dS^T[key][query]; transpose reads PFT-1 ops ahead
+        {
+          constexpr int NOPS = 2 * DB, PFT = FA_BWD_PFT;
+          s16x4 tlo[PFT], thi[PFT];
+          const int t0p = opaque(tr_base[0]), t1p = opaque(tr_base[1]);
+          auto rd = [&](int i) __attribute__((always_inline)) {
+            const int db = i % DB, t = i / DB;
+            const int base = KB_OFF + sub + 16 * t * ROW_BYTES;
+            tlo[i % PFT] = lds_read_tr16(lds + base + (t0p ^ (db << 6)));
+            thi[i % PFT] = lds_read_tr16(lds + base + (t1p ^ (db << 6)));
+          };
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+          for (int i = 0; i < PFT - 1; ++i) rd(i);
 #pragma unroll
-          for (int db = 0; db < DB; ++db) {
-            const int base = (kb * 32 + 16 * t) * ROW_BYTES;
-            const s16x4 lo = lds_read_tr16(kbuf + base + (tr_base[0] ^ (db << 6)));
-            const s16x4 hi4 = lds_read_tr16(kbuf + base + (tr_base[1] ^ (db << 6)));
-            dq_acc[db] = T::mfma(combine_tr<V8>(lo, hi4), dsfrag[t], dq_acc[db]);
+          for (int i = 0; i < NOPS; ++i) {
+            if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            dq_acc[i % DB] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), dsfrag[i / DB], dq_acc[i % DB]);
           }
         }
       }
     }
     lds_dma_wait_all();
     __syncthreads();
+  };
+  for (int n = n_min; n < n_max; n += 2) {
+    tile(std::integral_constant<int, 0>{}, n);
+    if (n + 1 < n_max) tile(std::integral_constant<int, 1>{}, n + 1);
   }
 
   if (!row_valid) return;
