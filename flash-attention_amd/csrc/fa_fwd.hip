@@ -215,6 +215,25 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
     for (int i = 0; i < LD; ++i) *(u32x4 FA_LDS*)(lds + (2 + buf) * TILE_BYTES + st_v[i]) = vreg[i];
   };
 
+  // LDS-DMA staging (lock-step schedule): global_load_lds, 1 KiB per wave instruction, no staging registers and no
+  // ds_write pass.  The destination is lane-linear, so the XOR swizzles are applied to the per-lane SOURCE chunk; rows
+  // past the last key are clamped to the last key (finite data; their scores are masked to -inf).
+  constexpr int RPD = 1024 / ROW_BYTES, NDMA = TILE_BYTES / 1024, DPW = NDMA / NW;
+  static_assert(NDMA % NW == 0 && DPW >= 1, "tile does not divide over the waves");
+  auto dma_tile = [&](auto isvc, int buf, int n) __attribute__((always_inline)) {
+    constexpr bool ISV = decltype(isvc)::value != 0;
+    const int64_t rs = ISV ? p.v_rs : p.k_rs;
+    const E* base = (ISV ? vp : kp) + tile_row_off(n, ISV ? p.v_bs : p.k_bs, rs);
+    char FA_LDS* dst = lds + (ISV ? 2 + buf : buf) * TILE_BYTES + wave * DPW * 1024;
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int row = (wave * DPW + i) * RPD + lane / CPR, pc = lane % CPR;
+      const int grow = min(n * BN + row, sk - 1) - n * BN;
+      const int c = ISV ? ((((pc >> 2) ^ v_swz<D>(row)) << 2) | (pc & 3)) : (pc ^ k_swz<D>(row));
+      lds_dma_16B(base + (int64_t)grow * rs + c * 8, dst + i * 1024);
+    }
+  };
+
   // ---- per-lane LDS read addresses (loop invariant; buffers and sub-tiles are immediates) ----------
   int kaddr[KS];
 #pragma unroll
@@ -390,29 +409,24 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   if constexpr (!PP) {
     // ------------------------------ lock-step schedule ------------------------------
     if (n_tiles > 0) {
-      load_k(n_min);
-      load_v(n_min);
-      store_k(IC<0>{});
-      store_v(IC<0>{});
+      dma_tile(IC<0>{}, 0, n_min);
+      dma_tile(IC<1>{}, 0, n_min);
+      lds_dma_wait_all();
       __syncthreads();
     }
     auto step = [&](auto bufc, int j) __attribute__((always_inline)) {
       constexpr int buf = decltype(bufc)::value;
-      const bool has_next = (j + 1 < n_tiles);
-      if (has_next) {  // lands while this tile is being computed
-        load_k(n_min + j + 1);
-        load_v(n_min + j + 1);
+      if (j + 1 < n_tiles) {  // lands in the other buffers while this tile is being computed
+        dma_tile(IC<0>{}, buf ^ 1, n_min + j + 1);
+        dma_tile(IC<1>{}, buf ^ 1, n_min + j + 1);
       }
       if (tile_active(j)) {
         qk(bufc);
         softmax_step(j);
         pv(bufc);
       }
-      if (has_next) {
-        store_k(IC<buf ^ 1>{});
-        store_v(IC<buf ^ 1>{});
-      }
-      __syncthreads();
+      lds_dma_wait_all();  // this wave's pieces have landed ...
+      __syncthreads();     // ... and everybody's are visible before the next tile reads them
     };
     for (int j = 0; j < n_tiles; j += 2) {
       step(IC<0>{}, j);
