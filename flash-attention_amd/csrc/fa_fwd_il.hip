@@ -22,6 +22,9 @@
 #ifndef FA_ABL
 #define FA_ABL 0  // timing ablations of the steady-state step (results become wrong): see tools/ablate_fwd.sh
 #endif
+#ifndef FA_IL_GENERIC_PIN
+#define FA_IL_GENERIC_PIN 1  // pin the operand prefetch of the generic (head / tail) steps above their MFMAs
+#endif
 #ifndef FA_IL_AHEAD
 #define FA_IL_AHEAD 4  // LDS operand reads issued this many MFMA slots ahead (LDS latency ~130-200 cycles, slot ~35)
 #endif
@@ -236,6 +239,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
         kfrag[nx % PF] = *(const u32x4 FA_LDS*)(kbuf + (kb_lane ^ (nx << 5)));
         if constexpr (QLDS) qfrag[nx % PF] = *(const u32x4 FA_LDS*)(lds + (qbase ^ (nx << 5)));
       }
+      if (FA_IL_GENERIC_PIN) __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this k-step's MFMA
       f32x16 c = s;
       if (ks == 0) {
 #pragma unroll
@@ -262,6 +266,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
         vlo[nx % PFV] = lds_read_tr16(vbuf + (vb_lane ^ ((nx % DB) << 6)) + (16 * (nx / DB)) * ROW_BYTES);
         vhi[nx % PFV] = lds_read_tr16(vbuf + (vb_lane ^ ((nx % DB) << 6)) + (16 * (nx / DB) + 8) * ROW_BYTES);
       }
+      if (FA_IL_GENERIC_PIN) __builtin_amdgcn_sched_barrier(0);
       o_acc[i % DB] = T::mfma(combine_tr<V8>(vlo[i % PFV], vhi[i % PFV]), pf[i / DB], o_acc[i % DB]);
     }
   };

@@ -24,12 +24,18 @@ It restates, in float64 numpy, the arithmetic the reference defines for
 * softcap ``s -> softcap * tanh(s * scale / softcap)``: ``src/utils.h:395-409``,
   ALiBi bias ``-slope * |i + Sk - Sq - j|``: ``src/alibi.h``.
 
+No ``oracle/_ref`` build: the reference's kernels are CUDA (``csrc/flash_attn`` needs nvcc + the un-vendored
+``csrc/cutlass`` submodule) or ROCm-CK (``csrc/flash_attn_ck`` needs the empty ``csrc/composable_kernel`` submodule,
+ROCm/composable_kernel ``amd-master``), so nothing on this path compiles from its own few source files here; the
+reference's CPU-runnable Python oracle is what pins this file.
+
 Parity pinning: ``tests/golden/*.npz`` were produced by importing the
 reference's own ``tests/test_util.py::attention_ref`` (+ torch autograd for the
 gradients) in the build container (``tests/golden/make_golden.py``); the
 ``-m "not gpu"`` suite checks this oracle against every one of them, and
 against the documented 2x5 / 5x2 causal-mask pictures of
-``flash_attn_interface.py:1176-1185``.
+``flash_attn_interface.py:1176-1185``.  The dropout branch (explicit keep-mask, 1/(1-p) scaling) is pinned the same
+way (``dropout_ref_cases.npz``: ``attention_ref(dropout_p, dropout_mask)`` + autograd).
 """
 from __future__ import annotations
 
