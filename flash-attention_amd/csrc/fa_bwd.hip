@@ -87,8 +87,10 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
 // ------------------------------------------------------------------------------------------------
 // dK / dV
 // ------------------------------------------------------------------------------------------------
-template <typename E, int D, bool XFORM>
+template <typename E, int D, int FEAT>
 __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_dkdv_kernel(const BwdK p) {
+  constexpr bool XFORM = (FEAT & (FEAT_CAP | FEAT_ALIBI)) != 0;  // scores pass through the scaled domain
+  constexpr bool F_CAP = (FEAT & FEAT_CAP) != 0, F_ALIBI = (FEAT & FEAT_ALIBI) != 0, F_DROP = (FEAT & FEAT_DROP) != 0;
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   using V4 = typename T::v4;
@@ -258,8 +260,10 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
     const bool has_next = it + 1 < n_items;
     if (has_next) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
     const int m0 = item_m0(it);
-    const float slope = (XFORM && p.alibi) ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
-    const bool drop = XFORM && (p.rng != nullptr);
+    const bool use_alibi = F_ALIBI && (FEAT != FEAT_ALL || p.alibi != nullptr);
+    const bool use_cap = F_CAP && (FEAT != FEAT_ALL || p.softcap > 0.f);
+    const float slope = use_alibi ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
+    const bool drop = F_DROP && (FEAT != FEAT_ALL || p.rng != nullptr);
     // stream key of this (batch, query head) plus this lane's key group; rows are added per 4-query group below
     const uint32_t drop_col = drop ? (drop_bh_key(p.rng, b * p.h + item_head(it)) + (uint32_t)(my_key >> 2)) : 0u;
     constexpr int QB_OFF = OFF_Q + cur * QT_BYTES, DOB_OFF = OFF_DO + cur * QT_BYTES;
@@ -308,17 +312,22 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
 
       f32x16 dcap;  // d(softcap*tanh(x/softcap))/dx = 1 - tanh^2 (reference flash_bwd_kernel.h:588 / utils.h:395-409)
       if constexpr (XFORM) {
+        const float rcap = use_cap ? 1.f / p.softcap : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int qrow = q0 + acc_row(r, hi);
           float y = s[r] * p.scale;
-          dcap[r] = 1.f;
-          if (p.softcap > 0.f) {
-            const float t = tanhf(y / p.softcap);
-            y = p.softcap * t;
-            dcap[r] = 1.f - t * t;
+          if constexpr (F_CAP) {
+            dcap[r] = 1.f;
+            if (use_cap) {
+              const float t = fast_tanh(y * rcap);
+              y = p.softcap * t;
+              dcap[r] = 1.f - t * t;
+            }
           }
-          if (p.alibi) y -= slope * fabsf((float)(qrow + shift - my_key));
+          if constexpr (F_ALIBI) {
+            if (use_alibi) y -= slope * fabsf((float)(qrow + shift - my_key));
+          }
           s[r] = y;
         }
       }
@@ -345,7 +354,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
         // Dropout: the 4 lanes of a quad hold the 4 keys of one key group; lane a hashes query row a of this 4-row
         // group (4 bytes = those 4 keys) and the quad exchanges words, so each lane reads its key's byte of every row.
         uint32_t hq = 0u;
-        if constexpr (XFORM) {
+        if constexpr (F_DROP) {
           if (drop) hq = hash32(drop_col + (uint32_t)(q0 + 8 * g + 4 * hi + (ki & 3)) * (uint32_t)p.drop_groups);
         }
 #pragma unroll
@@ -353,7 +362,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
           const int r = 4 * g + j;
           const float pv = fast_exp2(__builtin_fmaf(s[r], cs, -l4[j]));
           float pkeep = pv, dpe = dp[r];
-          if constexpr (XFORM) {
+          if constexpr (F_DROP) {
             if (drop) {  // Z = keep / (1 - p): dV uses P*Z (the 1/(1-p) is applied to dV at the end), dS = P*(dP*Z - delta)
               const uint32_t hj = quad_bcast(hq, j);
               const bool keep = ((hj >> (8 * (ki & 3))) & 0xffu) <= p.drop_thr8;
@@ -362,7 +371,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
             }
           }
           float dsv = pv * (dpe - d4[j]);
-          if constexpr (XFORM) dsv *= dcap[r];
+          if constexpr (F_CAP) dsv *= dcap[r];
           pfrag[r >> 3][r & 7] = (E)pkeep;
           dsfrag[r >> 3][r & 7] = (E)dsv;
         }
@@ -404,7 +413,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
 
   // ---- epilogue: dK = scale * acc, dV = acc; every key row of the block is written (zeros included) --
   if (!key_valid) return;
-  const float dv_scale = (XFORM && p.rng) ? p.rp_keep : 1.f;
+  const float dv_scale = (F_DROP && p.rng) ? p.rp_keep : 1.f;
   E* dkrow = (E*)p.dk + dk_boff + (k_row0 + my_key) * p.dk_rs + (int64_t)hk * p.dk_hs;
   E* dvrow = (E*)p.dv + dv_boff + (k_row0 + my_key) * p.dv_rs + (int64_t)hk * p.dv_hs;
 #pragma unroll
@@ -425,8 +434,10 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
 // ------------------------------------------------------------------------------------------------
 // dQ
 // ------------------------------------------------------------------------------------------------
-template <typename E, int D, int NW, bool XFORM>
+template <typename E, int D, int NW, int FEAT>
 __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(const BwdK p) {
+  constexpr bool XFORM = (FEAT & (FEAT_CAP | FEAT_ALIBI)) != 0;
+  constexpr bool F_CAP = (FEAT & FEAT_CAP) != 0, F_ALIBI = (FEAT & FEAT_ALIBI) != 0, F_DROP = (FEAT & FEAT_DROP) != 0;
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   using V4 = typename T::v4;
@@ -489,8 +500,10 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   const int lim_lo = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
 
   const float cs = XFORM ? kLog2e : p.scale_log2;
-  const float slope = (XFORM && p.alibi) ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
-  const bool drop = XFORM && (p.rng != nullptr);
+  const bool use_alibi = F_ALIBI && (FEAT != FEAT_ALL || p.alibi != nullptr);
+  const bool use_cap = F_CAP && (FEAT != FEAT_ALL || p.softcap > 0.f);
+  const float slope = use_alibi ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
+  const bool drop = F_DROP && (FEAT != FEAT_ALL || p.rng != nullptr);
   const uint32_t drop_row = drop ? (drop_bh_key(p.rng, b * p.h + h) + (uint32_t)my_row * (uint32_t)p.drop_groups) : 0u;
 
   // Q and dO fragments (B operands), LSE and delta (lane-local scalars)
@@ -595,17 +608,22 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
         }
         f32x16 dcap;
         if constexpr (XFORM) {
+          const float rcap = use_cap ? 1.f / p.softcap : 0.f;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kv0 + 32 * kb + acc_row(r, hi);
             float y = s[r] * p.scale;
-            dcap[r] = 1.f;
-            if (p.softcap > 0.f) {
-              const float t = tanhf(y / p.softcap);
-              y = p.softcap * t;
-              dcap[r] = 1.f - t * t;
+            if constexpr (F_CAP) {
+              dcap[r] = 1.f;
+              if (use_cap) {
+                const float t = fast_tanh(y * rcap);
+                y = p.softcap * t;
+                dcap[r] = 1.f - t * t;
+              }
             }
-            if (p.alibi) y -= slope * fabsf((float)(my_row + shift - key));
+            if constexpr (F_ALIBI) {
+              if (use_alibi) y -= slope * fabsf((float)(my_row + shift - key));
+            }
             s[r] = y;
           }
         }
@@ -623,7 +641,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
         for (int r = 0; r < 16; ++r) {
           const float pv = fast_exp2(__builtin_fmaf(s[r], cs, -lse_l));
           float dpe = dp[r];
-          if constexpr (XFORM) {
+          if constexpr (F_DROP) {
             if (drop) {  // acc rows 4g..4g+3 are keys key0..key0+3: one hash per group, byte r&3
               const int key0 = kv0 + 32 * kb + 8 * (r >> 2) + 4 * hi;
               const uint32_t bytes = hash32(drop_row + (uint32_t)(key0 >> 2));
@@ -631,7 +649,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
             }
           }
           float dsv = pv * (dpe - delta_l);
-          if constexpr (XFORM) dsv *= dcap[r];
+          if constexpr (F_CAP) dsv *= dcap[r];
           dsfrag[r >> 3][r & 7] = (E)dsv;
         }
         // dQ^T[d][query] += K^T[d][key] . dS^T[key][query]; transpose reads PFT-1 ops ahead
@@ -694,11 +712,11 @@ static int launch_delta_t(const BwdK& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <typename E, int D, bool XFORM>
+template <typename E, int D, int FEAT>
 static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
   constexpr int NWK = D > 128 ? 4 : 8, BMQ = D > 128 ? 32 : 64;
   constexpr int smem = NWK * 32 * D * 2 + 4 * BMQ * D * 2 + 4 * BMQ * 4;
-  auto kern = fa_bwd_dkdv_kernel<E, D, XFORM>;
+  auto kern = fa_bwd_dkdv_kernel<E, D, FEAT>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
@@ -711,13 +729,19 @@ static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
 
 template <typename E, int D>
 static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
-  return (p.alibi || p.softcap > 0.f || p.rng) ? launch_dkdv_a<E, D, true>(p, stream) : launch_dkdv_a<E, D, false>(p, stream);
+  switch (feat_code(p.softcap > 0.f, p.alibi != nullptr, p.rng != nullptr)) {
+    case FEAT_NONE: return launch_dkdv_a<E, D, FEAT_NONE>(p, stream);
+    case FEAT_CAP: return launch_dkdv_a<E, D, FEAT_CAP>(p, stream);
+    case FEAT_ALIBI: return launch_dkdv_a<E, D, FEAT_ALIBI>(p, stream);
+    case FEAT_DROP: return launch_dkdv_a<E, D, FEAT_DROP>(p, stream);
+    default: return launch_dkdv_a<E, D, FEAT_ALL>(p, stream);
+  }
 }
 
-template <typename E, int D, int NW, bool XFORM>
+template <typename E, int D, int NW, int FEAT>
 static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2;
-  auto kern = fa_bwd_dq_kernel<E, D, NW, XFORM>;
+  auto kern = fa_bwd_dq_kernel<E, D, NW, FEAT>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
@@ -727,13 +751,19 @@ static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+template <typename E, int D, int FEAT>
+static int launch_dq_f(const BwdK& p, hipStream_t stream) {
+  if constexpr (D > 128) return launch_dq_nw<E, D, 4, FEAT>(p, stream);
+  else return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, FEAT>(p, stream) : launch_dq_nw<E, D, 4, FEAT>(p, stream);
+}
 template <typename E, int D>
 static int launch_dq_t(const BwdK& p, hipStream_t stream) {
-  if constexpr (D > 128) {
-    return (p.alibi || p.softcap > 0.f || p.rng) ? launch_dq_nw<E, D, 4, true>(p, stream) : launch_dq_nw<E, D, 4, false>(p, stream);
-  } else {
-  if (p.alibi || p.softcap > 0.f || p.rng) return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, true>(p, stream) : launch_dq_nw<E, D, 4, true>(p, stream);
-  return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, false>(p, stream) : launch_dq_nw<E, D, 4, false>(p, stream);
+  switch (feat_code(p.softcap > 0.f, p.alibi != nullptr, p.rng != nullptr)) {
+    case FEAT_NONE: return launch_dq_f<E, D, FEAT_NONE>(p, stream);
+    case FEAT_CAP: return launch_dq_f<E, D, FEAT_CAP>(p, stream);
+    case FEAT_ALIBI: return launch_dq_f<E, D, FEAT_ALIBI>(p, stream);
+    case FEAT_DROP: return launch_dq_f<E, D, FEAT_DROP>(p, stream);
+    default: return launch_dq_f<E, D, FEAT_ALL>(p, stream);
   }
 }
 

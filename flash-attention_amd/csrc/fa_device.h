@@ -122,6 +122,20 @@ FA_DEVINL int xcd_interleave(int bid, int n_units, int unit_size, int hpx) {
   return unit < n_units ? unit * unit_size + item : -1;
 }
 
+// Score-transform features of the non-plain kernel variants (template int FEAT): softcap, ALiBi, dropout.  A variant
+// with exactly one feature carries only that feature's code and registers; FEAT_ALL checks the parameters at run time.
+enum { FEAT_NONE = 0, FEAT_CAP = 1, FEAT_ALIBI = 2, FEAT_DROP = 4, FEAT_ALL = 7 };
+inline int feat_code(bool cap, bool alibi, bool drop) {
+  const int f = (cap ? FEAT_CAP : 0) | (alibi ? FEAT_ALIBI : 0) | (drop ? FEAT_DROP : 0);
+  return (f == FEAT_NONE || f == FEAT_CAP || f == FEAT_ALIBI || f == FEAT_DROP) ? f : FEAT_ALL;
+}
+// tanh(x) = 1 - 2 / (2^(2x log2 e) + 1): two transcendentals instead of libm's polynomial; relative error ~1e-4 near 0,
+// exact limits at +-inf (softcap: reference utils.h:395-409 uses the hardware tanh approximation as well)
+FA_DEVINL float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
 // ---- varlen work list ---------------------------------------------------------------------------------
 // A packed batch with uneven lengths leaves most (batch, block) slots of a max_seqlen-sized grid empty.  The
 // schedule kernel writes the non-empty query (or key) blocks, heaviest first, as {batch, block} pairs after a

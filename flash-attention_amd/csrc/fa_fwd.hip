@@ -49,8 +49,10 @@ template <int D> FA_DEVINL constexpr int v_swz(int row) { return D >= 128 ? (row
 
 template <int N> using IC = std::integral_constant<int, N>;
 
-template <typename E, int D, int NW, bool XFORM, bool PP>
+template <typename E, int D, int NW, int FEAT, bool PP>
 __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const FwdK p) {
+  constexpr bool XFORM = (FEAT & (FEAT_CAP | FEAT_ALIBI)) != 0;  // scores pass through the scaled domain
+  constexpr bool F_CAP = (FEAT & FEAT_CAP) != 0, F_ALIBI = (FEAT & FEAT_ALIBI) != 0, F_DROP = (FEAT & FEAT_DROP) != 0;
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   using V4 = typename T::v4;
@@ -153,11 +155,13 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   const int lim_hi = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
   const int lim_lo = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
 
-  // XFORM (softcap / ALiBi) is a compile-time variant so the common kernel carries none of it
+  // softcap / ALiBi / dropout are compile-time variants (FEAT) so the common kernel carries none of them
   const float cs = XFORM ? kLog2e : p.scale_log2;  // multiplier taking S to the log2 domain
-  const float slope = (XFORM && p.alibi) ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
-  // dropout lives in the XFORM variant too (runtime switch): per-(batch, head) stream key and this lane's row base
-  const bool drop = XFORM && (p.rng != nullptr);
+  const bool use_alibi = F_ALIBI && (FEAT != FEAT_ALL || p.alibi != nullptr);
+  const bool use_cap = F_CAP && (FEAT != FEAT_ALL || p.softcap > 0.f);
+  const float slope = use_alibi ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
+  // dropout: per-(batch, head) stream key and this lane's row base
+  const bool drop = F_DROP && (FEAT != FEAT_ALL || p.rng != nullptr);
   const uint32_t drop_row = drop ? (drop_bh_key(p.rng, b * p.h + h) + (uint32_t)my_row * (uint32_t)p.drop_groups) : 0u;
   uint8_t* rv_row = (drop && p.randval) ? (p.randval + (int64_t)b * p.rv_bs + (int64_t)h * p.rv_hs + (q_row0 + my_row) * p.rv_rs) : nullptr;
   const float thr = p.rescale_thr;
@@ -294,15 +298,20 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   auto softmax_step = [&](int j) __attribute__((always_inline)) {
     const int kv0 = (n_min + j) * BN;
     if constexpr (XFORM) {  // softcap / ALiBi: move to the scaled domain first (reference utils.h:395-409, alibi.h)
+      const float rcap = use_cap ? 1.f / p.softcap : 0.f;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float y = s[kb][r] * p.scale;
-          if (p.softcap > 0.f) y = p.softcap * tanhf(y / p.softcap);
-          if (p.alibi) {
-            const int key = kv0 + 32 * kb + acc_row(r, hi);
-            y -= slope * fabsf((float)(my_row + shift - key));
+          if constexpr (F_CAP) {
+            if (use_cap) y = p.softcap * fast_tanh(y * rcap);
+          }
+          if constexpr (F_ALIBI) {
+            if (use_alibi) {
+              const int key = kv0 + 32 * kb + acc_row(r, hi);
+              y -= slope * fabsf((float)(my_row + shift - key));
+            }
           }
           s[kb][r] = y;
         }
@@ -357,7 +366,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
         psum1 += p1;
       }
     l_run += psum0 + psum1;
-    if constexpr (XFORM) {
+    if constexpr (F_DROP) {
       if (drop) {  // the row sum above is that of the un-dropped probabilities (flash_fwd_kernel.h:357-368)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -733,10 +742,10 @@ int launch_kv_append(const KvAppendK& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <typename E, int D, int NW, bool XFORM, bool PP>
+template <typename E, int D, int NW, int FEAT, bool PP>
 static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2;
-  auto kern = fa_fwd_kernel<E, D, NW, XFORM, PP>;
+  auto kern = fa_fwd_kernel<E, D, NW, FEAT, PP>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
@@ -750,17 +759,30 @@ static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
 
 int fwd_block_m(int nw) { return nw == 16 ? 256 : 32 * nw; }
 
-template <typename E, int D>
-static int launch_fwd_ed(const FwdK& p, int nw, hipStream_t stream) {
-  const bool xf = (p.softcap > 0.f) || (p.alibi != nullptr) || (p.rng != nullptr);
+template <typename E, int D, int FEAT>
+static int launch_fwd_f(const FwdK& p, int nw, hipStream_t stream) {
   if constexpr (D > 128) {
     (void)nw;
-    return xf ? launch_fwd_t<E, D, 4, true, false>(p, stream) : launch_fwd_t<E, D, 4, false, false>(p, stream);
+    return launch_fwd_t<E, D, 4, FEAT, false>(p, stream);
   } else {
-  if (nw == 16) return xf ? launch_fwd_t<E, D, 8, true, true>(p, stream) : launch_fwd_t<E, D, 8, false, true>(p, stream);
-  if (nw == 8) return xf ? launch_fwd_t<E, D, 8, true, false>(p, stream) : launch_fwd_t<E, D, 8, false, false>(p, stream);
-  if (nw == 4) return xf ? launch_fwd_t<E, D, 4, true, false>(p, stream) : launch_fwd_t<E, D, 4, false, false>(p, stream);
-  return -2;
+    if (nw == 8) return launch_fwd_t<E, D, 8, FEAT, false>(p, stream);
+    if (nw == 4) return launch_fwd_t<E, D, 4, FEAT, false>(p, stream);
+    if constexpr (FEAT == FEAT_NONE || FEAT == FEAT_ALL) {  // the ping-pong schedule is built plain and all-features only
+      if (nw == 16) return launch_fwd_t<E, D, 8, FEAT, true>(p, stream);
+    }
+    return -2;
+  }
+}
+template <typename E, int D>
+static int launch_fwd_ed(const FwdK& p, int nw, hipStream_t stream) {
+  int feat = feat_code(p.softcap > 0.f, p.alibi != nullptr, p.rng != nullptr);
+  if (nw == 16 && feat != FEAT_NONE) feat = FEAT_ALL;
+  switch (feat) {
+    case FEAT_NONE: return launch_fwd_f<E, D, FEAT_NONE>(p, nw, stream);
+    case FEAT_CAP: return launch_fwd_f<E, D, FEAT_CAP>(p, nw, stream);
+    case FEAT_ALIBI: return launch_fwd_f<E, D, FEAT_ALIBI>(p, nw, stream);
+    case FEAT_DROP: return launch_fwd_f<E, D, FEAT_DROP>(p, nw, stream);
+    default: return launch_fwd_f<E, D, FEAT_ALL>(p, nw, stream);
   }
 }
 
