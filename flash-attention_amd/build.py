@@ -53,7 +53,7 @@ def _sources(names):
 def build_lib(force=False):
     hdrs = _sources(["fa_device.h", "fa_kernel_params.h", "fa_launch.h"]) + [os.path.join(ROOT, "include", "fa_gfx950.h")]
     units = ["fa_fwd.hip", "fa_fwd_il.hip", "fa_bwd.hip", "fa_api.cpp"]
-    objs = []
+    objs, cmds = [], []
     for u in units:
         src = os.path.join(CSRC, u)
         obj = os.path.join(CSRC, os.path.splitext(u)[0] + ".o")
@@ -62,8 +62,12 @@ def build_lib(force=False):
             if u.endswith(".cpp"):
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")
-            _run(cmd)
+            cmds.append(cmd)
         objs.append(obj)
+    if cmds:  # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
+            list(ex.map(_run, cmds))
     if force or not _newer(LIB, objs):
         _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

@@ -734,6 +734,8 @@ static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
     case FEAT_CAP: return launch_dkdv_a<E, D, FEAT_CAP>(p, stream);
     case FEAT_ALIBI: return launch_dkdv_a<E, D, FEAT_ALIBI>(p, stream);
     case FEAT_DROP: return launch_dkdv_a<E, D, FEAT_DROP>(p, stream);
+    case FEAT_CAP | FEAT_DROP: return launch_dkdv_a<E, D, (FEAT_CAP | FEAT_DROP)>(p, stream);
+    case FEAT_ALIBI | FEAT_DROP: return launch_dkdv_a<E, D, (FEAT_ALIBI | FEAT_DROP)>(p, stream);
     default: return launch_dkdv_a<E, D, FEAT_ALL>(p, stream);
   }
 }
@@ -763,6 +765,8 @@ static int launch_dq_t(const BwdK& p, hipStream_t stream) {
     case FEAT_CAP: return launch_dq_f<E, D, FEAT_CAP>(p, stream);
     case FEAT_ALIBI: return launch_dq_f<E, D, FEAT_ALIBI>(p, stream);
     case FEAT_DROP: return launch_dq_f<E, D, FEAT_DROP>(p, stream);
+    case FEAT_CAP | FEAT_DROP: return launch_dq_f<E, D, (FEAT_CAP | FEAT_DROP)>(p, stream);
+    case FEAT_ALIBI | FEAT_DROP: return launch_dq_f<E, D, (FEAT_ALIBI | FEAT_DROP)>(p, stream);
     default: return launch_dq_f<E, D, FEAT_ALL>(p, stream);
   }
 }

@@ -127,7 +127,7 @@ FA_DEVINL int xcd_interleave(int bid, int n_units, int unit_size, int hpx) {
 enum { FEAT_NONE = 0, FEAT_CAP = 1, FEAT_ALIBI = 2, FEAT_DROP = 4, FEAT_ALL = 7 };
 inline int feat_code(bool cap, bool alibi, bool drop) {
   const int f = (cap ? FEAT_CAP : 0) | (alibi ? FEAT_ALIBI : 0) | (drop ? FEAT_DROP : 0);
-  return (f == FEAT_NONE || f == FEAT_CAP || f == FEAT_ALIBI || f == FEAT_DROP) ? f : FEAT_ALL;
+  return (f == (FEAT_CAP | FEAT_ALIBI)) ? FEAT_ALL : f;  // every combination but softcap+ALiBi(+dropout) has its own variant
 }
 // tanh(x) = 1 - 2 / (2^(2x log2 e) + 1): two transcendentals instead of libm's polynomial; relative error ~1e-4 near 0,
 // exact limits at +-inf (softcap: reference utils.h:395-409 uses the hardware tanh approximation as well)

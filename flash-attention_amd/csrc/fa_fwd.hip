@@ -782,6 +782,8 @@ static int launch_fwd_ed(const FwdK& p, int nw, hipStream_t stream) {
     case FEAT_CAP: return launch_fwd_f<E, D, FEAT_CAP>(p, nw, stream);
     case FEAT_ALIBI: return launch_fwd_f<E, D, FEAT_ALIBI>(p, nw, stream);
     case FEAT_DROP: return launch_fwd_f<E, D, FEAT_DROP>(p, nw, stream);
+    case FEAT_CAP | FEAT_DROP: return launch_fwd_f<E, D, (FEAT_CAP | FEAT_DROP)>(p, nw, stream);
+    case FEAT_ALIBI | FEAT_DROP: return launch_fwd_f<E, D, (FEAT_ALIBI | FEAT_DROP)>(p, nw, stream);
     default: return launch_fwd_f<E, D, FEAT_ALL>(p, nw, stream);
   }
 }

@@ -142,3 +142,27 @@ def test_dropout_through_the_public_interface():
         assert max_abs(got.float().cpu(), torch.from_numpy(ref)) < 6e-2 * max(1.0, float(np.abs(ref).max()))
     with pytest.raises(RuntimeError, match="return_softmax"):
         fi._flash_attn_forward(q.detach(), k.detach(), v.detach(), 0.0, d ** -0.5, True, -1, -1, 0.0, None, True)
+
+
+@pytest.mark.parametrize("feature", ["alibi", "softcap"])
+def test_dropout_combined_with_alibi_or_softcap(be, feature):
+    """The two-feature kernel variants (ALiBi + dropout, softcap + dropout), forward and backward, against the oracle."""
+    from oracle import attention_oracle as orc
+    torch.manual_seed(21)
+    B, sq, sk, h, hk, d, p = 2, 150, 260, 4, 2, 64, 0.2
+    q = torch.randn(B, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    do = torch.randn(B, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    alibi = torch.rand(B, h, device="cuda") * 0.3 if feature == "alibi" else None
+    cap = 15.0 if feature == "softcap" else 0.0
+    scale = d ** -0.5
+    out, lse, rv, rng = be.fwd(q, k, v, None, alibi, p, scale, True, -1, -1, cap, True, None)
+    keep = _keep(rv, p).cpu().numpy()
+    al = None if alibi is None else alibi.cpu().numpy()
+    o_ref, _ = orc.attention_fwd(q, k, v, scale, True, (-1, -1), cap, al, p, keep)
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 3e-2
+    dq, dk, dv, _ = be.bwd(do, q, k, v, out, lse, None, None, None, alibi, p, scale, True, -1, -1, cap, False, None, rng)
+    rq, rk, rvv, _ = orc.attention_bwd(do, q, k, v, None, None, scale, True, (-1, -1), cap, al, p, keep)
+    for got, ref in ((dq, rq), (dk, rk), (dv, rvv)):
+        assert max_abs(got.float().cpu(), torch.from_numpy(ref)) < 6e-2 * max(1.0, float(np.abs(ref).max()))
