@@ -193,12 +193,12 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
       const int row = (wave * QDMA + i) * RPD + d_row;
       const int grow = min(m0 + row, sq - 1);
       const int c = d_pc ^ k_swz_il<D>(row);
-      lds_dma_16B(qp + (int64_t)grow * rs + c * 8, lds + Q_OFF + (wave * QDMA + i) * 1024);
+      lds_dma_16B(qp + (int64_t)(FA_ABL == 11 ? 0 : grow) * rs + c * 8, lds + Q_OFF + (wave * QDMA + i) * 1024);
     }
   } else {
     const E* qrow = qp + (int64_t)my_row * p.q_rs + 8 * hi;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qreg[ks] = bitcast_u32x4<V8>(ld_global_16B(qrow + 16 * ks, row_valid));
+    for (int ks = 0; ks < KS; ++ks) qreg[ks] = bitcast_u32x4<V8>(ld_global_16B((FA_ABL == 11 ? qp + 8 * hi : qrow) + 16 * ks, row_valid));
   }
   const int qbase = Q_OFF + (wave * 32 + qi) * ROW_BYTES + ((hi ^ k_swz_il<D>(qi)) << 4);
 
@@ -569,8 +569,12 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   const float l_tot = half_sum(l_run);
   const bool dead = (l_tot == 0.f) || (l_tot != l_tot);
   const float inv = dead ? 1.f : 1.f / l_tot;
-  if (row_valid) {
-    E* orow = op + (int64_t)my_row * p.o_rs;
+  // O tile through LDS (the K/V buffers are free after the last barrier): in the accumulator layout a store instruction
+  // would write 16 bytes into each of 32 rows (512 partial-line writes per wave); staged, each instruction writes whole
+  // 256-byte rows.  Measured on config 3: the direct epilogue cost ~60 us of the 660 us kernel (tools/overhead_fit.py).
+  {
+    constexpr int RS = ROW_BYTES + 16;  // padded row: the 32 lanes of a ds_write_b64 group hit distinct banks
+    char FA_LDS* stage = lds + wave * 32 * RS;
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -578,9 +582,16 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
         V4 ov;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) ov[jj] = (E)(o_acc[db][4 * g + jj] * inv);
-        *reinterpret_cast<V4*>(orow + 32 * db + 8 * g + 4 * hi) = ov;
+        *reinterpret_cast<V4 FA_LDS*>(stage + qi * RS + (32 * db + 8 * g + 4 * hi) * 2) = ov;
       }
-    if (hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
+    constexpr int RPI = 64 / CPR;  // rows per store instruction
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int row = i * RPI + lane / CPR, ch = lane % CPR;
+      const u32x4 x = *reinterpret_cast<const u32x4 FA_LDS*>(stage + row * RS + ch * 16);
+      if (w_row0 + row < sq && FA_ABL != 10) *reinterpret_cast<u32x4*>(op + (int64_t)(w_row0 + row) * p.o_rs + ch * 8) = x;
+    }
+    if (row_valid && hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
   }
 }
 
