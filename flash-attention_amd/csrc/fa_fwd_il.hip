@@ -185,22 +185,20 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   // Q block -> LDS once (its fragments are re-read per step instead of living in 32 registers), or, for
   // 4-wave workgroups, Q fragments in registers so that two workgroups fit one CU's LDS.
   V8 qreg[QLDS ? 1 : KS];
-  if constexpr (QLDS) {
+  constexpr int QSTAGE = QLDS ? Q_OFF : 2 * TILE_BYTES;  // 4 waves: staged in the (still unused) V buffers, then to registers
+  {
     const int64_t rs = p.q_rs;
     constexpr int QDMA = (BM * ROW_BYTES) / 1024 / NW;  // DMA instructions per wave
+    static_assert(QLDS || BM * ROW_BYTES <= 2 * TILE_BYTES, "Q block does not fit the V buffers");
 #pragma unroll
     for (int i = 0; i < QDMA; ++i) {
       const int row = (wave * QDMA + i) * RPD + d_row;
       const int grow = min(m0 + row, sq - 1);
       const int c = d_pc ^ k_swz_il<D>(row);
-      lds_dma_16B(qp + (int64_t)(FA_ABL == 11 ? 0 : grow) * rs + c * 8, lds + Q_OFF + (wave * QDMA + i) * 1024);
+      lds_dma_16B(qp + (int64_t)(FA_ABL == 11 ? 0 : grow) * rs + c * 8, lds + QSTAGE + (wave * QDMA + i) * 1024);
     }
-  } else {
-    const E* qrow = qp + (int64_t)my_row * p.q_rs + 8 * hi;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qreg[ks] = bitcast_u32x4<V8>(ld_global_16B((FA_ABL == 11 ? qp + 8 * hi : qrow) + 16 * ks, row_valid));
   }
-  const int qbase = Q_OFF + (wave * 32 + qi) * ROW_BYTES + ((hi ^ k_swz_il<D>(qi)) << 4);
+  const int qbase = QSTAGE + (wave * 32 + qi) * ROW_BYTES + ((hi ^ k_swz_il<D>(qi)) << 4);
 
   // per-lane LDS read bases: K fragment of k-step ks at kbase ^ (ks << 5); V d-block db at vbase ^ (db << 6)
   const int kbase = qi * ROW_BYTES + ((hi ^ k_swz_il<D>(qi)) << 4);
@@ -472,6 +470,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   if (n_tiles > 0) dma_tile(ICi<0>{}, 0, 0);
   lds_dma_wait_all();
   __syncthreads();
+  if constexpr (!QLDS) {  // Q fragments LDS -> registers (coalesced DMA instead of 16-byte loads at row stride), then free the V buffers
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qreg[ks] = bitcast_u32x4<V8>(*(const u32x4 FA_LDS*)(unsigned long)(unsigned)(qbase ^ (ks << 5)));
+    __syncthreads();
+  }
 
   // iteration u (0..n_tiles): steps 2u-1 and 2u read K_u (kbuf[u&1]) and V_{u-1} (vbuf[(u-1)&1]);
   // K_{u+1} and V_u are DMA'd during the iteration into the buffers it does not read.
