@@ -506,16 +506,33 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   const bool drop = F_DROP && (FEAT != FEAT_ALL || p.rng != nullptr);
   const uint32_t drop_row = drop ? (drop_bh_key(p.rng, b * p.h + h) + (uint32_t)my_row * (uint32_t)p.drop_groups) : 0u;
 
-  // Q and dO fragments (B operands), LSE and delta (lane-local scalars)
+  // Q and dO fragments (B operands), LSE and delta (lane-local scalars).  The fragments are staged through the (still
+  // idle) LDS by coalesced DMA -- each wave its own 32 rows -- instead of 16-byte loads at row stride.
   V8 qf[KS], dof[KS];
   {
-    const E* qrow = (const E*)p.q + q_boff + (q_row0 + my_row) * p.q_rs + (int64_t)h * p.q_hs + 8 * hi;
-    const E* dorow = (const E*)p.dout + do_boff + (q_row0 + my_row) * p.do_rs + (int64_t)h * p.do_hs + 8 * hi;
+    constexpr int RPDQ = 1024 / ROW_BYTES, QDPW = 32 * ROW_BYTES / 1024;  // rows per DMA instruction, instructions per wave
+    const E* qsrc = (const E*)p.q + q_boff + q_row0 * p.q_rs + (int64_t)h * p.q_hs;
+    const E* dosrc = (const E*)p.dout + do_boff + q_row0 * p.do_rs + (int64_t)h * p.do_hs;
+    const int fr0 = wave * 32 * ROW_BYTES + qi * ROW_BYTES + ((hi ^ swz16<D>(qi)) << 4);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      qf[ks] = bitcast_u32x4<V8>(ld_global_16B(qrow + 16 * ks, row_valid));
-      dof[ks] = bitcast_u32x4<V8>(ld_global_16B(dorow + 16 * ks, row_valid));
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+      for (int i = 0; i < QDPW; ++i) {
+        const int row = wave * 32 + i * RPDQ + lane / CPR;
+        const int c = (lane % CPR) ^ swz16<D>(row);
+        const int grow = min(m0 + row, sq - 1);
+        const E* src = which ? (dosrc + (int64_t)grow * p.do_rs) : (qsrc + (int64_t)grow * p.q_rs);
+        lds_dma_16B(src + c * 8, lds + (wave * QDPW + i) * 1024);
+      }
+      lds_dma_wait_all();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 x = *(const u32x4 FA_LDS*)(lds + (fr0 ^ (ks << 5)));
+        if (which) dof[ks] = bitcast_u32x4<V8>(x); else qf[ks] = bitcast_u32x4<V8>(x);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the next DMA may overwrite the rows
     }
+    __syncthreads();  // the K/V tile DMA below reuses this LDS
   }
   float lse_l = INFINITY, delta_l = 0.f;
   if (row_valid) {
