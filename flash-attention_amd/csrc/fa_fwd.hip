@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane = query row, 8 consecutive d per k-step -----
   V8 qf[KS];
-  {
+  const bool q_staged = !PP && sq >= 64;  // lock-step schedule: the Q block goes through LDS by coalesced DMA (prologue below)
+  if (!q_staged) {  // few query rows (decode) or ping-pong schedule: 16-byte loads at row stride
     const E* qrow = qp + (int64_t)my_row * p.q_rs + 8 * hi;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = bitcast_u32x4<V8>(ld_global_16B(qrow + 16 * ks, row_valid));
@@ -417,6 +418,22 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
 
   if constexpr (!PP) {
     // ------------------------------ lock-step schedule ------------------------------
+    if (q_staged) {  // Q block: each wave DMAs its own 32 rows into the idle LDS (K-style swizzle) and copies its fragments to registers
+      constexpr int QDPW = 32 * ROW_BYTES / 1024;
+#pragma unroll
+      for (int i = 0; i < QDPW; ++i) {
+        const int row = wave * 32 + i * RPD + lane / CPR, pc = lane % CPR;
+        const int grow = min(m0 + row, sq - 1);
+        lds_dma_16B(qp + (int64_t)grow * p.q_rs + (pc ^ k_swz<D>(row)) * 8, lds + (wave * QDPW + i) * 1024);
+      }
+      lds_dma_wait_all();
+      const int qb = (wave * 32 + qi) * ROW_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = bitcast_u32x4<V8>(*(const u32x4 FA_LDS*)(lds + qb + (((2 * ks + hi) ^ k_swz<D>(qi)) << 4)));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();  // the K/V tile DMA below reuses this LDS
+    }
     if (n_tiles > 0) {
       dma_tile(IC<0>{}, 0, n_min);
       dma_tile(IC<1>{}, 0, n_min);
