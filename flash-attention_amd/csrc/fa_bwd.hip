@@ -412,23 +412,15 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   }
 
   // ---- epilogue: dK = scale * acc, dV = acc; every key row of the block is written (zeros included) --
-  if (!key_valid) return;
+  if (!wave_valid) return;
+  // dK / dV tiles through the freed Q/dO buffers: whole-row stores (fa_device.h store_tile_via_lds); every key row of the
+  // block is written (zeros included: empty-sequence contract of the CK tests)
   const float dv_scale = (F_DROP && p.rng) ? p.rp_keep : 1.f;
-  E* dkrow = (E*)p.dk + dk_boff + (k_row0 + my_key) * p.dk_rs + (int64_t)hk * p.dk_hs;
-  E* dvrow = (E*)p.dv + dv_boff + (k_row0 + my_key) * p.dv_rs + (int64_t)hk * p.dv_hs;
-#pragma unroll
-  for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      V4 a, c;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a[j] = (E)(dk_acc[db][4 * g + j] * p.scale);
-        c[j] = (E)(dv_acc[db][4 * g + j] * dv_scale);
-      }
-      *reinterpret_cast<V4*>(dkrow + 32 * db + 8 * g + 4 * hi) = a;
-      *reinterpret_cast<V4*>(dvrow + 32 * db + 8 * g + 4 * hi) = c;
-    }
+  E* dktile = (E*)p.dk + dk_boff + (k_row0 + wk0) * p.dk_rs + (int64_t)hk * p.dk_hs;
+  E* dvtile = (E*)p.dv + dv_boff + (k_row0 + wk0) * p.dv_rs + (int64_t)hk * p.dv_hs;
+  char FA_LDS* stage = lds + wave * 32 * (ROW_BYTES + 16);
+  store_tile_via_lds<E, D>(stage, dk_acc, p.scale, dktile, p.dk_rs, sk - wk0, lane);
+  store_tile_via_lds<E, D>(stage, dv_acc, dv_scale, dvtile, p.dv_rs, sk - wk0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -699,17 +691,10 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
     if (n + 1 < n_max) tile(std::integral_constant<int, 1>{}, n + 1);
   }
 
-  if (!row_valid) return;
-  E* dqrow = (E*)p.dq + dq_boff + (q_row0 + my_row) * p.dq_rs + (int64_t)h * p.dq_hs;
-#pragma unroll
-  for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      V4 a;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = (E)(dq_acc[db][4 * g + j] * p.scale);
-      *reinterpret_cast<V4*>(dqrow + 32 * db + 8 * g + 4 * hi) = a;
-    }
+  if (!wave_valid) return;
+  // dQ tile through the freed K/V buffers: whole-row stores (fa_device.h store_tile_via_lds)
+  E* dqtile = (E*)p.dq + dq_boff + (q_row0 + w_row0) * p.dq_rs + (int64_t)h * p.dq_hs;
+  store_tile_via_lds<E, D>(lds + wave * 32 * (ROW_BYTES + 16), dq_acc, p.scale, dqtile, p.dq_rs, sq - w_row0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -759,7 +744,7 @@ static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
 
 template <typename E, int D, int NW, int FEAT>
 static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
-  constexpr int smem = 4 * 64 * D * 2;
+  constexpr int smem = 4 * 64 * D * 2 + NW * 32 * 16;  // K/V double buffers (+ the row padding of the staged dQ epilogue)
   auto kern = fa_bwd_dq_kernel<E, D, NW, FEAT>;
   static bool attr_done = false;
   if (!attr_done) {

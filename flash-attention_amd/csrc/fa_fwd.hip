@@ -525,19 +525,9 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
     }
     return;
   }
-  if (row_valid) {
-    E* orow = op + (int64_t)my_row * p.o_rs;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        V4 ov;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) ov[jj] = (E)(o_acc[db][4 * g + jj] * inv);
-        *reinterpret_cast<V4*>(orow + 32 * db + 8 * g + 4 * hi) = ov;
-      }
-    if (hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
-  }
+  // O tile through the freed K/V buffers: whole-row stores (fa_device.h store_tile_via_lds)
+  store_tile_via_lds<E, D>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op + (int64_t)w_row0 * p.o_rs, p.o_rs, sq - w_row0, lane);
+  if (row_valid && hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
 }
 
 // Merge of the split-KV partials (reference combine_attn_seqk_parallel, flash_fwd_kernel.h:1117-1299): one wave per
@@ -761,7 +751,7 @@ int launch_kv_append(const KvAppendK& p, hipStream_t stream) {
 
 template <typename E, int D, int NW, int FEAT, bool PP>
 static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
-  constexpr int smem = 4 * 64 * D * 2;
+  constexpr int smem = 4 * 64 * D * 2 + NW * 32 * 16;  // K/V double buffers (+ the row padding of the staged O epilogue)
   auto kern = fa_fwd_kernel<E, D, NW, FEAT, PP>;
   static bool attr_done = false;
   if (!attr_done) {

@@ -572,28 +572,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   const float l_tot = half_sum(l_run);
   const bool dead = (l_tot == 0.f) || (l_tot != l_tot);
   const float inv = dead ? 1.f : 1.f / l_tot;
-  // O tile through LDS (the K/V buffers are free after the last barrier): in the accumulator layout a store instruction
-  // would write 16 bytes into each of 32 rows (512 partial-line writes per wave); staged, each instruction writes whole
-  // 256-byte rows.  Measured on config 3: the direct epilogue cost ~60 us of the 660 us kernel (tools/overhead_fit.py).
+  // O tile through LDS (the K/V buffers are free after the last barrier; fa_device.h store_tile_via_lds).  Measured on
+  // config 3: the direct epilogue cost ~60 us of the 660 us kernel (tools/overhead_fit.py).
   {
-    constexpr int RS = ROW_BYTES + 16;  // padded row: the 32 lanes of a ds_write_b64 group hit distinct banks
-    char FA_LDS* stage = lds + wave * 32 * RS;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        V4 ov;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) ov[jj] = (E)(o_acc[db][4 * g + jj] * inv);
-        *reinterpret_cast<V4 FA_LDS*>(stage + qi * RS + (32 * db + 8 * g + 4 * hi) * 2) = ov;
-      }
-    constexpr int RPI = 64 / CPR;  // rows per store instruction
-#pragma unroll
-    for (int i = 0; i < 32 / RPI; ++i) {
-      const int row = i * RPI + lane / CPR, ch = lane % CPR;
-      const u32x4 x = *reinterpret_cast<const u32x4 FA_LDS*>(stage + row * RS + ch * 16);
-      if (w_row0 + row < sq && FA_ABL != 10) *reinterpret_cast<u32x4*>(op + (int64_t)(w_row0 + row) * p.o_rs + ch * 8) = x;
-    }
+    if (FA_ABL != 10)
+      store_tile_via_lds<E, D>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op + (int64_t)w_row0 * p.o_rs, p.o_rs, sq - w_row0, lane);
     if (row_valid && hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
   }
 }
