@@ -63,6 +63,75 @@ def test_cabi_rejects_bad_arguments_without_touching_the_gpu(built):
         _cabi.check(_cabi.FA_ERR_INVALID_ARGUMENT)
 
 
+def test_cabi_contract_of_the_later_entry_points(built):
+    """Dropout, KV-cache, rotary and workspace entry points: argument contract checked on the host, no launch."""
+    from flash_attn_amd import _cabi
+    lib = _cabi.load()
+    assert lib.fa_sizeof_rotary_params() == ctypes.sizeof(_cabi.FaRotaryParams)
+    dummy = ctypes.c_void_p(0x1000)  # never dereferenced: every call below is rejected before a launch
+
+    def fwd_params():
+        a = _cabi.FaFwdParams()
+        a.b, a.h, a.h_k, a.d, a.dtype = 2, 4, 2, 128, _cabi.FA_DTYPE_BF16
+        a.q = a.k = a.v = a.o = a.softmax_lse = dummy
+        a.seqlen_q, a.seqlen_k, a.total_q = 16, 512, 32
+        return a
+
+    a = fwd_params()
+    a.p_dropout = 0.1                                   # dropout needs the device rng_state
+    assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"rng_state" in lib.fa_last_error()
+    a = fwd_params()
+    a.p_dropout = 1.0
+    assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"p_dropout" in lib.fa_last_error()
+    a = fwd_params()
+    a.randval = dummy                                   # return_softmax payload only with dropout
+    assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"return_softmax" in lib.fa_last_error()
+    a = fwd_params()
+    a.num_splits = 4                                    # key splits belong to the KV-cache entry point
+    assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"num_splits" in lib.fa_last_error()
+    a = fwd_params()
+    a.block_table = dummy                               # so do paged caches
+    assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"fa_fwd_kvcache" in lib.fa_last_error()
+    a = fwd_params()
+    a.block_table, a.page_block_size = dummy, 100       # page size must be a multiple of 256 (flash_api.cpp:1318)
+    assert lib.fa_fwd_kvcache(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"256" in lib.fa_last_error()
+    a = fwd_params()
+    a.block_table, a.page_block_size, a.leftpad_k, a.seqused_k = dummy, 256, dummy, dummy
+    assert lib.fa_fwd_kvcache(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"leftpad_k" in lib.fa_last_error()
+    a = fwd_params()
+    a.p_dropout, a.rng_state = 0.1, dummy               # inference path: no dropout
+    assert lib.fa_fwd_kvcache(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"inference" in lib.fa_last_error()
+    # workspace sizing is pure host arithmetic: decode with idle CUs wants split-KV scratch, a full grid does not
+    a = fwd_params()
+    a.b, a.seqlen_q, a.seqlen_k, a.total_q = 1, 1, 32768, 1
+    need = lib.fa_fwd_workspace_bytes(ctypes.byref(a))
+    assert need > 0 and need % ((a.d + 1) * 4 * a.b * a.h * a.seqlen_q) == 0
+    a.b = 512
+    assert lib.fa_fwd_workspace_bytes(ctypes.byref(a)) == 0
+    a.b, a.num_splits = 1, 8
+    assert lib.fa_fwd_workspace_bytes(ctypes.byref(a)) == 8 * (a.d + 1) * 4 * a.h
+    # varlen: a work list is requested only when the max_seqlen grid would be mostly empty
+    a = fwd_params()
+    a.cu_seqlens_q = a.cu_seqlens_k = dummy
+    a.b, a.seqlen_q, a.seqlen_k, a.total_q = 160, 16384, 16384, 65536
+    assert lib.fa_fwd_workspace_bytes(ctypes.byref(a)) > 0
+    a.b, a.seqlen_q, a.seqlen_k = 16, 4096, 4096
+    assert lib.fa_fwd_workspace_bytes(ctypes.byref(a)) == 0
+    r = _cabi.FaRotaryParams()
+    r.x = r.y = r.cos = r.sin = dummy
+    r.b, r.s, r.h, r.d, r.rotary_dim, r.seqlen_ro, r.dtype = 1, 1, 1, 128, 24, 8, _cabi.FA_DTYPE_FP16
+    assert lib.fa_rotary(ctypes.byref(r), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"divisible by 16" in lib.fa_last_error()
+    r.rotary_dim = 256
+    assert lib.fa_rotary(ctypes.byref(r), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"headdim" in lib.fa_last_error()
+    bw = _cabi.FaBwdParams()
+    bw.b, bw.h, bw.h_k, bw.d, bw.dtype = 1, 2, 2, 64, _cabi.FA_DTYPE_BF16
+    for f in ("dout", "q", "k", "v", "o", "softmax_lse", "dq", "dk", "dv", "softmax_d"):
+        setattr(bw, f, dummy)
+    bw.p_dropout = 0.2
+    assert lib.fa_bwd(ctypes.byref(bw), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"rng_state" in lib.fa_last_error()
+    assert lib.fa_set_rng_state(1, 2, None, None) == _cabi.FA_ERR_INVALID_ARGUMENT
+
+
 def test_torch_extension_is_the_reference_backend_module(built):
     import flash_attn_2_cuda as m
     for fn in ("fwd", "varlen_fwd", "bwd", "varlen_bwd", "fwd_kvcache"):
