@@ -555,13 +555,21 @@ __global__ void __launch_bounds__(256) fa_splitkv_combine_kernel(const FwdK p) {
   float acc[EPL];
 #pragma unroll
   for (int t = 0; t < EPL; ++t) acc[t] = 0.f;
-  for (int s = 0; s < p.n_splits; ++s) {
-    const float ws = __shfl(wgt, s);
-    if (ws != 0.f) {
+  // 8 partials in flight per round (independent loads, no branch: an empty partial has weight 0 and holds zeros)
+  for (int s0 = 0; s0 < p.n_splits; s0 += 8) {
+    float part[8][EPL], ws[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int s = min(s0 + j, p.n_splits - 1);
+      ws[j] = (s0 + j < p.n_splits) ? __shfl(wgt, s) : 0.f;
       const float* src = p.o_accum + ((int64_t)s * rows + r) * D + lane * EPL;
 #pragma unroll
-      for (int t = 0; t < EPL; ++t) acc[t] += ws * src[t];
+      for (int t = 0; t < EPL; ++t) part[j][t] = src[t];
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int t = 0; t < EPL; ++t) acc[t] += ws[j] * part[j][t];
   }
   E* dst = (E*)p.o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + (int64_t)h * p.o_hs + lane * EPL;
 #pragma unroll
