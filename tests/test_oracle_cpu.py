@@ -114,3 +114,27 @@ def test_oracle_dropout_matches_reference_golden(dropout_cases, name):
     dq, dk, dv, _ = orc.attention_bwd(do, q, k, v, None, None, None, bool(causal), (wl, wr), 0.0, None, pd, case["keep"])
     for got, ref in ((dq, case["dq"]), (dk, case["dk"]), (dv, case["dv"])):
         assert np.abs(got - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_baseline_config1_oracle_vs_reference_cpu_sdpa():
+    """BASELINE config 1 (B=2 H=4 S=128 D=64 fp32 non-causal, CPU): the oracle against the reference CPU SDPA
+    (torch F.scaled_dot_product_attention) and a naive softmax(QK^T)V; plus the causal / GQA variants SDPA offers
+    (SDPA's is_causal is top-left aligned, identical to flash's bottom-right only when Sq == Sk)."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    B, H, S, D = 2, 4, 128, 64
+    q, k, v = (torch.randn(B, S, H, D, generator=g) for _ in range(3))
+    out, lse = orc.attention_fwd(q.numpy(), k.numpy(), v.numpy())
+    sdpa = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2)
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * D ** -0.5
+    naive = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v)
+    assert np.abs(out - sdpa.numpy()).max() < 1e-5 and np.abs(out - naive.numpy()).max() < 1e-5  # fp32 roundoff of the references
+    assert np.abs(lse - torch.logsumexp(s, -1).numpy()).max() < 1e-5
+    out_c, _ = orc.attention_fwd(q.numpy(), k.numpy(), v.numpy(), None, True)
+    sdpa_c = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), is_causal=True).transpose(1, 2)
+    assert np.abs(out_c - sdpa_c.numpy()).max() < 1e-5
+    kg, vg = k[:, :, :2], v[:, :, :2]
+    out_g, _ = orc.attention_fwd(q.numpy(), kg.numpy(), vg.numpy())
+    sdpa_g = F.scaled_dot_product_attention(q.transpose(1, 2), kg.transpose(1, 2), vg.transpose(1, 2), enable_gqa=True).transpose(1, 2)
+    assert np.abs(out_g - sdpa_g.numpy()).max() < 1e-5
