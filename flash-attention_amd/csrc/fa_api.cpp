@@ -147,11 +147,12 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     return fail(FA_ERR_INVALID_ARGUMENT, varlen ? "fa_varlen_fwd needs cu_seqlens_q and cu_seqlens_k"
                                                 : "fa_fwd takes fixed-length batches (cu_seqlens must be NULL)");
   if (a->seqlen_q < 0 || a->seqlen_k < 0) return fail(FA_ERR_INVALID_ARGUMENT, "negative sequence length");
-  if (!kvcache && (a->cache_batch_idx || a->block_table || a->seqused_k_add || a->leftpad_k))
-    return fail(FA_ERR_INVALID_ARGUMENT, "cache_batch_idx / block_table / seqused_k_add / leftpad_k are fa_fwd_kvcache arguments");
+  if (!kvcache && (a->cache_batch_idx || a->seqused_k_add))
+    return fail(FA_ERR_INVALID_ARGUMENT, "cache_batch_idx / seqused_k_add are fa_fwd_kvcache arguments");
+  if (!kvcache && !varlen && (a->block_table || a->leftpad_k))
+    return fail(FA_ERR_INVALID_ARGUMENT, "block_table / leftpad_k are fa_varlen_fwd and fa_fwd_kvcache arguments");
   if (a->leftpad_k && a->block_table)
     return fail(FA_ERR_INVALID_ARGUMENT, "We don't support Paged KV and leftpad_k running at the same time yet");
-  if (a->leftpad_k && !a->seqused_k) return fail(FA_ERR_INVALID_ARGUMENT, "leftpad_k needs seqused_k (cache_seqlens)");
   if (a->block_table) {
     if (a->cache_batch_idx) return fail(FA_ERR_INVALID_ARGUMENT, "Paged KVcache does not support cache_batch_idx");
     if (a->page_block_size <= 0 || a->page_block_size % 256 != 0)

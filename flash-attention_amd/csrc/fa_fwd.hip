@@ -113,9 +113,11 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
     k_boff = 0;
     v_boff = 0;
   }
-  if (p.seqused_k) {  // keys in use, never beyond the addressable capacity; a left-padded cache starts at row leftpad_k[b]
-    const int lp = p.leftpad_k ? p.leftpad_k[b] : 0;
-    sk = max(0, min(p.seqused_k[b] + p.seqused_add, p.sk) - lp);
+  if (p.block_table) k_row0 = 0;  // paged K/V: the page table supplies the rows, cu_seqlens_k only the lengths
+  if (p.seqused_k) sk = min(p.seqused_k[b] + p.seqused_add, p.sk);  // keys in use, never beyond the addressable capacity
+  if (p.leftpad_k) {  // a left-padded sequence starts at row leftpad_k[b] (reference block_info.h:17-36)
+    const int lp = p.leftpad_k[b];
+    sk = max(0, sk - lp);
     k_row0 += lp;
   }
   const int m0 = m_block * BM;

@@ -86,9 +86,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   if (p.block_table) { k_boff = 0; v_boff = 0; }  // paged cache: the page index supplies the first-dimension offset
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; o_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
-  if (p.seqused_k) {  // keys in use, never beyond the addressable capacity; a left-padded cache starts at row leftpad_k[b]
-    const int lp = p.leftpad_k ? p.leftpad_k[b] : 0;
-    sk = max(0, min(p.seqused_k[b] + p.seqused_add, p.sk) - lp);
+  if (p.block_table) k_row0 = 0;  // paged K/V: the page table supplies the rows, cu_seqlens_k only the lengths
+  if (p.seqused_k) sk = min(p.seqused_k[b] + p.seqused_add, p.sk);  // keys in use, never beyond the addressable capacity
+  if (p.leftpad_k) {  // a left-padded sequence starts at row leftpad_k[b] (reference block_info.h:17-36)
+    const int lp = p.leftpad_k[b];
+    sk = max(0, sk - lp);
     k_row0 += lp;
   }
   const int m0 = m_block * BM;

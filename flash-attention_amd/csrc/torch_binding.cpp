@@ -168,23 +168,42 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
                                    const int64_t num_splits) {
   common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
   TORCH_CHECK(!return_softmax || p_dropout > 0.0, "return_softmax is only supported when p_dropout > 0.0");
-  TORCH_CHECK(!block_table_.has_value(), "libfa_gfx950: paged KV (block_table) is not built");
-  TORCH_CHECK(!leftpad_k_.has_value(), "libfa_gfx950: leftpad_k is not built");
+  const bool paged = block_table_.has_value();  // k / v are (num_blocks, page, Hk, D), addressed through block_table (flash_api.cpp:586-649)
+  if (paged) {
+    CHECK_DEVICE(*block_table_);
+    TORCH_CHECK(block_table_->dtype() == at::kInt, "block_table must have dtype torch.int32");
+    TORCH_CHECK(block_table_->stride(-1) == 1, "block_table must have contiguous last dimension");
+    TORCH_CHECK(k.dim() == 4 && v.dim() == 4, "With block_table, k and v must be 4-D (num_blocks, page_block_size, nheads_k, headdim)");
+    TORCH_CHECK(k.size(1) % 256 == 0, "Paged KV cache block size must be divisible by 256");
+    TORCH_CHECK(!leftpad_k_.has_value(), "We don't support Paged KV and leftpad_k running at the same time yet");
+  }
+  if (leftpad_k_.has_value()) {
+    TORCH_CHECK(leftpad_k_->dtype() == at::kInt, "leftpad_k must have dtype int32");
+    CHECK_DEVICE(*leftpad_k_); TORCH_CHECK(leftpad_k_->is_contiguous(), "leftpad_k must be contiguous");
+  }
   TORCH_CHECK(num_splits <= 1, "num_splits > 1 is not supported");
   TORCH_CHECK(cu_seqlens_q.dtype() == at::kInt, "cu_seqlens_q must have dtype int32");
   TORCH_CHECK(cu_seqlens_k.dtype() == at::kInt, "cu_seqlens_k must have dtype int32");
   CHECK_DEVICE(cu_seqlens_q); CHECK_DEVICE(cu_seqlens_k);
   TORCH_CHECK(cu_seqlens_q.is_contiguous() && cu_seqlens_k.is_contiguous(), "cu_seqlens_q/k must be contiguous");
-  TORCH_CHECK(q.dim() == 3 && k.dim() == 3 && v.dim() == 3, "q, k, v must be 3-D (total, nheads, headdim)");
-  const int64_t total_q = q.size(0), H = q.size(1), D = q.size(2), total_k = k.size(0), Hk = k.size(1);
+  TORCH_CHECK(q.dim() == 3 && (paged || (k.dim() == 3 && v.dim() == 3)), "q, k, v must be 3-D (total, nheads, headdim)");
+  const int64_t total_q = q.size(0), H = q.size(1), D = q.size(2);
+  const int64_t total_k = paged ? k.size(0) * k.size(1) : k.size(0), Hk = paged ? k.size(2) : k.size(1);
   const int64_t B = cu_seqlens_q.numel() - 1;
   TORCH_CHECK(B > 0, "batch size must be positive");
   CHECK_SHAPE(cu_seqlens_q, B + 1);
   CHECK_SHAPE(cu_seqlens_k, B + 1);
   TORCH_CHECK(D <= 256 && D % 8 == 0, "head_size must be a multiple of 8 and at most 256");
   TORCH_CHECK(H % Hk == 0, "Number of heads in key/value must divide number of heads in query");
-  CHECK_SHAPE(k, total_k, Hk, D);
-  CHECK_SHAPE(v, total_k, Hk, D);
+  if (paged) {
+    CHECK_SHAPE(k, k.size(0), k.size(1), Hk, D);
+    TORCH_CHECK(v.sizes() == k.sizes(), "paged k / v shape mismatch");
+    CHECK_SHAPE(*block_table_, B, block_table_->size(1));
+  } else {
+    CHECK_SHAPE(k, total_k, Hk, D);
+    CHECK_SHAPE(v, total_k, Hk, D);
+  }
+  if (leftpad_k_.has_value()) CHECK_SHAPE(*leftpad_k_, B);
   if (seqused_k.has_value()) {
     TORCH_CHECK(seqused_k->dtype() == at::kInt, "seqused_k must have dtype int32");
     CHECK_DEVICE(*seqused_k);
@@ -214,8 +233,16 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
     FaFwdParams a{};
     a.q = qp.data_ptr(); a.k = kp.data_ptr(); a.v = vp.data_ptr(); a.o = out.data_ptr(); a.softmax_lse = lse.data_ptr<float>();
     a.q_row_stride = qp.stride(0); a.q_head_stride = qp.stride(1);
-    a.k_row_stride = kp.stride(0); a.k_head_stride = kp.stride(1);
-    a.v_row_stride = vp.stride(0); a.v_head_stride = vp.stride(1);
+    if (paged) {
+      a.k_batch_stride = kp.stride(0); a.k_row_stride = kp.stride(1); a.k_head_stride = kp.stride(2);
+      a.v_batch_stride = vp.stride(0); a.v_row_stride = vp.stride(1); a.v_head_stride = vp.stride(2);
+      a.block_table = block_table_->data_ptr<int>(); a.block_table_batch_stride = block_table_->stride(0);
+      a.page_block_size = (int)kp.size(1);
+    } else {
+      a.k_row_stride = kp.stride(0); a.k_head_stride = kp.stride(1);
+      a.v_row_stride = vp.stride(0); a.v_head_stride = vp.stride(1);
+    }
+    a.leftpad_k = leftpad_k_.has_value() ? leftpad_k_->data_ptr<int>() : nullptr;
     a.o_row_stride = out.stride(0); a.o_head_stride = out.stride(1);
     a.cu_seqlens_q = cu_seqlens_q.data_ptr<int>(); a.cu_seqlens_k = cu_seqlens_k.data_ptr<int>();
     a.seqused_k = seqused_k.has_value() ? seqused_k->data_ptr<int>() : nullptr;

@@ -165,10 +165,18 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
     _common_checks(q, k, v, p_dropout, alibi_slopes_, gen_)
     if return_softmax and not p_dropout > 0.0:
         raise RuntimeError("return_softmax is only supported when p_dropout > 0.0")
-    if block_table_ is not None:
-        raise RuntimeError("libfa_gfx950: paged KV (block_table) is not built")
-    if leftpad_k_ is not None:
-        raise RuntimeError("libfa_gfx950: leftpad_k is not built")
+    paged = block_table_ is not None  # k / v are (num_blocks, page, Hk, D), addressed through block_table (B, max_blocks)
+    if paged:
+        if block_table_.dtype != torch.int32 or block_table_.stride(-1) != 1:
+            raise RuntimeError("block_table must have dtype torch.int32 and a contiguous last dimension")
+        if k.dim() != 4 or v.dim() != 4:
+            raise RuntimeError("With block_table, k and v must be 4-D (num_blocks, page_block_size, nheads_k, headdim)")
+        if k.shape[1] % 256 != 0:
+            raise RuntimeError("Paged KV cache block size must be divisible by 256")
+        if leftpad_k_ is not None:
+            raise RuntimeError("We don't support Paged KV and leftpad_k running at the same time yet")
+    if leftpad_k_ is not None and (leftpad_k_.dtype != torch.int32 or not leftpad_k_.is_contiguous()):
+        raise RuntimeError("leftpad_k must be a contiguous int32 tensor of shape (batch_size)")
     if num_splits > 1:
         raise RuntimeError("num_splits > 1 is not supported")
     for cu in (cu_seqlens_q, cu_seqlens_k):
@@ -176,10 +184,12 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
             raise RuntimeError("cu_seqlens_q/k must have dtype int32")
         if not cu.is_contiguous():
             raise RuntimeError("cu_seqlens_q/k must be contiguous")
-    _check_dev(cu_seqlens_q, cu_seqlens_k, seqused_k)
+    _check_dev(cu_seqlens_q, cu_seqlens_k, seqused_k, block_table_, leftpad_k_)
     total_q, H, D = q.shape
-    total_k, Hk = k.shape[0], k.shape[1]
+    total_k, Hk = (k.shape[0] * k.shape[1], k.shape[2]) if paged else (k.shape[0], k.shape[1])
     B = cu_seqlens_q.numel() - 1
+    if paged and tuple(block_table_.shape[:1]) != (B,):
+        raise RuntimeError("block_table must have shape (batch_size, max_num_blocks_per_seq)")
     if B <= 0:
         raise RuntimeError("batch size must be positive")
     if cu_seqlens_k.numel() != B + 1:
@@ -209,8 +219,14 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
         a = _cabi.FaFwdParams()
         a.q, a.k, a.v, a.o, a.softmax_lse = _ptr(qp), _ptr(kp), _ptr(vp), _ptr(out), _ptr(lse)
         a.q_row_stride, a.q_head_stride = qp.stride(0), qp.stride(1)
-        a.k_row_stride, a.k_head_stride = kp.stride(0), kp.stride(1)
-        a.v_row_stride, a.v_head_stride = vp.stride(0), vp.stride(1)
+        if paged:
+            a.k_batch_stride, a.k_row_stride, a.k_head_stride = kp.stride(0), kp.stride(1), kp.stride(2)
+            a.v_batch_stride, a.v_row_stride, a.v_head_stride = vp.stride(0), vp.stride(1), vp.stride(2)
+            a.block_table, a.block_table_batch_stride, a.page_block_size = _ptr(block_table_), block_table_.stride(0), kp.shape[1]
+        else:
+            a.k_row_stride, a.k_head_stride = kp.stride(0), kp.stride(1)
+            a.v_row_stride, a.v_head_stride = vp.stride(0), vp.stride(1)
+        a.leftpad_k = _ptr(leftpad_k_)
         a.o_row_stride, a.o_head_stride = out.stride(0), out.stride(1)
         a.cu_seqlens_q, a.cu_seqlens_k, a.seqused_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k), _ptr(seqused_k)
         a.alibi_slopes, a.alibi_batch_stride = _ptr(alibi), alibi_bs

@@ -75,9 +75,10 @@ typedef struct FaFwdParams {
   float softmax_scale;
   float softcap;                /* 0 = off                              */
   int32_t seqused_k_add;        /* added to seqused_k[b] (keys appended in the same call)            */
-  /* KV-cache extensions (fa_fwd_kvcache only; NULL / 0 otherwise) */
-  const int32_t* cache_batch_idx;   /* optional (B): batch entry -> row of the cache                 */
-  const int32_t* block_table;       /* optional (B, max_blocks) int32: paged cache, k/v are (num_blocks, page, Hk, D) */
+  /* KV-cache extensions (NULL / 0 otherwise) */
+  const int32_t* cache_batch_idx;   /* fa_fwd_kvcache, optional (B): batch entry -> row of the cache */
+  const int32_t* block_table;       /* fa_fwd_kvcache / fa_varlen_fwd, optional (B, max_blocks) int32: paged K/V, k/v are
+                                       (num_blocks, page, Hk, D) and k/v_batch_stride is the page stride */
   int64_t block_table_batch_stride;
   int32_t page_block_size;          /* keys per page, multiple of 256 (reference flash_api.cpp:1318)  */
   int32_t num_splits;               /* fa_fwd_kvcache: 0 = heuristic, 1 = no split, >1 = split the keys this many ways */
@@ -92,8 +93,9 @@ typedef struct FaFwdParams {
   /* split-KV scratch (fa_fwd_kvcache): fa_fwd_workspace_bytes() bytes, 256-B aligned; may be NULL if that is 0 */
   void* workspace;
   int64_t workspace_bytes;
-  const int32_t* leftpad_k;         /* fa_fwd_kvcache, optional (B): the cache of entry b starts at row leftpad_k[b]; seqused_k
-                                       counts from row 0 (reference block_info.h:17-36); not with block_table */
+  const int32_t* leftpad_k;         /* fa_varlen_fwd / fa_fwd_kvcache, optional (B): the keys of entry b start at row leftpad_k[b];
+                                       lengths (seqused_k / cu_seqlens_k) count from row 0 (reference block_info.h:17-36);
+                                       not together with block_table */
 } FaFwdParams;
 
 /* Append step of the KV-cache path: copy knew/vnew (B, S_new, Hk, D) into the cache at rows

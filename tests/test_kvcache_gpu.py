@@ -221,3 +221,41 @@ def test_kvcache_paged_capacity_guard_and_single_row_window(kv):
     out, lse = kv.fwd_kvcache(q, kc, vc, None, None, lens, None, None, None, None, None, None, None, d ** -0.5, False, -1, 3, 0.0, True, 0)
     o_ref, l_ref = _oracle(q, kc, vc, lens.cpu().numpy(), False)
     assert max_abs(out.float().cpu(), torch.from_numpy(o_ref)) < 5e-3 and max_abs(lse.cpu(), torch.from_numpy(l_ref).float()) < 2e-3
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_varlen_forward_with_paged_kv_and_with_leftpad(kv, causal):
+    """mha_varlen_fwd's optional arguments (flash_api.cpp:586-649): K/V in pages addressed by block_table (lengths from
+    cu_seqlens_k), and leftpad_k on packed K/V; both against the oracle on the logical sequences."""
+    from oracle import attention_oracle as orc
+    torch.manual_seed(8)
+    H, hk, d, page, per = 8, 2, 128, 256, 3
+    lens_q, lens_k = [50, 1, 700], [300, 1, 700]
+    cu_q = torch.tensor([0] + list(np.cumsum(lens_q)), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0] + list(np.cumsum(lens_k)), dtype=torch.int32, device="cuda")
+    q = torch.randn(sum(lens_q), H, d, device="cuda", dtype=torch.bfloat16)
+    kp = torch.randn(3 * per + 2, page, hk, d, device="cuda", dtype=torch.bfloat16)
+    vp = torch.randn_like(kp)
+    table = torch.randperm(3 * per + 2, device="cuda")[: 3 * per].reshape(3, per).to(torch.int32)
+    out, lse, _, _ = kv.varlen_fwd(q, kp, vp, None, cu_q, cu_k, None, None, table, None, max(lens_q), max(lens_k), 0.0, d ** -0.5, False,
+                                   causal, -1, -1, 0.0, False, None)
+    k_log, v_log = kp[table.long()].reshape(3, per * page, hk, d), vp[table.long()].reshape(3, per * page, hk, d)
+    for b in range(3):
+        qs = slice(int(cu_q[b]), int(cu_q[b + 1]))
+        o_ref, l_ref = orc.attention_fwd(q[qs][None], k_log[b:b + 1, :lens_k[b]], v_log[b:b + 1, :lens_k[b]], None, causal)
+        assert max_abs(out[qs].float().cpu(), torch.from_numpy(o_ref[0])) < 2e-2
+        assert max_abs(lse[:, qs].cpu(), torch.from_numpy(l_ref[0]).float()) < 2e-3
+    # leftpad on packed keys: sequence b uses rows cu_k[b] + pad[b] .. cu_k[b+1] - 1
+    k = torch.randn(sum(lens_k), hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    pad = torch.tensor([17, 0, 130], dtype=torch.int32, device="cuda")
+    out, lse, _, _ = kv.varlen_fwd(q, k, v, None, cu_q, cu_k, None, pad, None, None, max(lens_q), max(lens_k), 0.0, d ** -0.5, False,
+                                   causal, -1, -1, 0.0, False, None)
+    for b in range(3):
+        qs = slice(int(cu_q[b]), int(cu_q[b + 1]))
+        ks = slice(int(cu_k[b]) + int(pad[b]), int(cu_k[b + 1]))
+        o_ref, l_ref = orc.attention_fwd(q[qs][None], k[ks][None], v[ks][None], None, causal)
+        assert max_abs(out[qs].float().cpu(), torch.from_numpy(o_ref[0])) < 2e-2
+        fin = torch.from_numpy(np.isfinite(l_ref[0]))   # causal with fewer keys than queries: the first rows see no key (lse = +inf)
+        assert torch.equal(torch.isposinf(lse[:, qs].cpu()), ~fin)
+        assert max_abs(lse[:, qs].cpu()[fin], torch.from_numpy(l_ref[0]).float()[fin]) < 2e-3
