@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -34,6 +35,41 @@ int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return (s && *s) ? atoi(s) : dflt;
 }
+
+// Environment knobs are read once per process (getenv on every launch races with setenv and costs a libc lock);
+// fa_knobs_reload() re-reads them.  Old snapshots are never freed (a handful of bytes per reload).
+std::atomic<const fa::Knobs*> g_knobs{nullptr};
+const fa::Knobs* read_knobs() {
+  fa::Knobs* k = new fa::Knobs();
+  k->fwd_nw = env_int("FA_FWD_NW", 0);
+  const char* t = getenv("FA_RESCALE_THR");
+  k->rescale_thr = (t && *t) ? (float)atof(t) : 8.f;
+  if (!(k->rescale_thr >= 0.f) || k->rescale_thr > 16.f) k->rescale_thr = 0.f;
+  k->varlen_list = env_int("FA_VARLEN_LIST", 1);
+  k->il_sched = env_int("FA_IL_SCHED", 3);
+  k->bwd_dq_nw = env_int("FA_BWD_DQ_NW", 4);
+  k->bwd_mode = env_int("FA_BWD_MODE", 0);
+  k->lds_pad = env_int("FA_IL_LDS_PAD", 0);
+  return k;
+}
+
+}  // namespace
+namespace fa {
+const Knobs& knobs() {
+  const Knobs* k = g_knobs.load(std::memory_order_acquire);
+  if (!k) {
+    const Knobs* fresh = read_knobs();
+    if (g_knobs.compare_exchange_strong(k, fresh, std::memory_order_acq_rel)) k = fresh;
+    else delete fresh;
+  }
+  return *k;
+}
+LastSchedule& last_schedule() {
+  thread_local LastSchedule ls{};
+  return ls;
+}
+}  // namespace fa
+namespace {
 
 bool head_dim_native(int d) { return d == 64 || d == 128 || d == 256; }
 
@@ -97,7 +133,7 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
   // query block); 4-wave pipelined workgroups (Q fragments in registers, two workgroups per CU hide each other's
   // prologue/epilogue) win on shorter loops and under causal masks at S <= 8k.  D = 64 has half the MFMA work
   // per softmax element and prefers 4-wave workgroups throughout.
-  int nw = env_int("FA_FWD_NW", 0);
+  int nw = fa::knobs().fwd_nw;
   if (nw != 4 && nw != 8 && nw != 16 && nw != 34 && nw != 38) {
     const bool right_bounded = (wr >= 0);
     const long avg_keys = right_bounded ? (a->seqlen_k + 1) / 2 : a->seqlen_k;
@@ -117,7 +153,7 @@ int fwd_block_rows(const FaFwdParams* a, int nw, bool split) {
 }
 // varlen work list: worth a pre-pass when a max_seqlen-sized grid would be mostly empty slots
 int64_t varlen_list_entries(const FaFwdParams* a, int bm) {
-  if (env_int("FA_VARLEN_LIST", 1) == 0) return 0;  // debugging switch: always the dense grid
+  if (fa::knobs().varlen_list == 0) return 0;  // debugging switch: always the dense grid
   const int64_t dense = (int64_t)a->b * ((a->seqlen_q + bm - 1) / bm);
   const int64_t bound = (int64_t)a->total_q / bm + a->b;
   return (dense * 4 > bound * 5 && dense >= 64) ? bound : 0;
@@ -189,11 +225,9 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   // units (P stays <= 2^thr; fp32 accumulators and the relative precision of bf16/fp16 P are unaffected).
   // 0 reproduces the reference's rescale-on-any-growth rule exactly.  Default 8 (measured +4..10 %,
   // parity suite unchanged); override with FA_RESCALE_THR.
-  {
-    const char* t = getenv("FA_RESCALE_THR");
-    k.rescale_thr = (t && *t) ? (float)atof(t) : 8.f;
-    if (!(k.rescale_thr >= 0.f) || k.rescale_thr > 16.f) k.rescale_thr = 0.f;
-  }
+  // fp16 P must stay below 65504: the threshold is capped at 15 there (bf16 has fp32's exponent range).
+  k.rescale_thr = fa::knobs().rescale_thr;
+  if (a->dtype == FA_DTYPE_FP16 && k.rescale_thr > 15.f) k.rescale_thr = 15.f;
 
   int nw = fwd_schedule_nw(a, wl, wr);
   if (a->d > 128) nw = 4;  // head dim 256: one 4-wave lock-step workgroup per CU (512-register budget)
@@ -236,6 +270,9 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
                     : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
   if (rc == 0 && k.n_splits > 1) rc = fa::launch_splitkv_combine(k, a->dtype == FA_DTYPE_BF16, a->d, (hipStream_t)stream);
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
+  if (rc == -3)
+    return fail(FA_ERR_UNSUPPORTED, "k/v row stride too large: one 64-key tile (64 * row_stride * 2 bytes) must span less than 2 GiB "
+                                    "(the kernels address a tile with 32-bit lane offsets)");
   if (rc != 0) return fail(FA_ERR_LAUNCH, "forward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   return FA_OK;
 }
@@ -283,7 +320,7 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
 // varlen backward work lists: query blocks for the dQ kernel, key blocks for the dK/dV kernel (entries each, 0 = dense grids)
 void bwd_list_entries(const FaBwdParams* a, int64_t& q_entries, int64_t& k_entries) {
   q_entries = k_entries = 0;
-  if (!a->cu_seqlens_q || !a->cu_seqlens_k || env_int("FA_VARLEN_LIST", 1) == 0) return;
+  if (!a->cu_seqlens_q || !a->cu_seqlens_k || fa::knobs().varlen_list == 0) return;
   const int bm = a->d > 128 ? 128 : fa::bwd_block_m(), bn = fa::bwd_block_n(a->d);
   const int64_t dq_dense = (int64_t)a->b * ((a->seqlen_q + bm - 1) / bm), dq_bound = (int64_t)a->total_q / bm + a->b;
   const int64_t dk_dense = (int64_t)a->b * ((a->seqlen_k + bn - 1) / bn), dk_bound = (int64_t)a->total_k / bn + a->b;
@@ -325,6 +362,7 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   int rc = fa::launch_bwd_delta(k, bf, a->d, s);
   if (rc == 0) rc = fa::launch_bwd_dkdv(k, bf, a->d, s);
   if (rc == 0) rc = fa::launch_bwd_dq(k, bf, a->d, s);
+  if (rc == 0) { fa::last_schedule().bwd_dq_nw = fa::bwd_block_m() / 32; fa::last_schedule().bwd_list = (k.q_list != nullptr) + 2 * (k.k_list != nullptr); }
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no backward kernel for head dim %d", a->d);
   if (rc != 0) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   return FA_OK;
@@ -340,6 +378,14 @@ int fa_sizeof_bwd_params(void) { return (int)sizeof(FaBwdParams); }
 int fa_sizeof_kvappend_params(void) { return (int)sizeof(FaKvAppendParams); }
 int fa_sizeof_rotary_params(void) { return (int)sizeof(FaRotaryParams); }
 const char* fa_last_error(void) { return g_err; }
+void fa_knobs_reload(void) { g_knobs.store(read_knobs(), std::memory_order_release); }
+int fa_last_schedule(int32_t* out, int n) {
+  const fa::LastSchedule& ls = fa::last_schedule();
+  const int32_t v[FA_SCHEDULE_FIELDS] = {ls.fwd_kernel, ls.fwd_nw, ls.fwd_feat, ls.fwd_splits, ls.fwd_list, ls.d, ls.bf16, ls.bwd_dq_nw, ls.bwd_list};
+  for (int i = 0; i < n && i < FA_SCHEDULE_FIELDS; ++i) out[i] = v[i];
+  return FA_SCHEDULE_FIELDS;
+}
+const char* fa_last_kernel_name(void) { return fa::last_schedule().name; }
 
 int fa_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, false); }
 int fa_varlen_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, true); }

@@ -701,8 +701,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
 // launchers
 // ------------------------------------------------------------------------------------------------
 int bwd_block_m() {
-  static const int nw = [] { const char* e = getenv("FA_BWD_DQ_NW"); const int v = e ? atoi(e) : 4; return (v == 8) ? 8 : 4; }();
-  return 32 * nw;
+  return 32 * (knobs().bwd_dq_nw == 8 ? 8 : 4);
 }
 int bwd_block_n(int d) { return d > 128 ? 128 : 256; }
 
@@ -719,11 +718,8 @@ static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
   constexpr int NWK = D > 128 ? 4 : 8, BMQ = D > 128 ? 32 : 64;
   constexpr int smem = NWK * 32 * D * 2 + 4 * BMQ * D * 2 + 4 * BMQ * 4;
   auto kern = fa_bwd_dkdv_kernel<E, D, FEAT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_mask{0};
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem) != 0) return -1;
   const long long total = p.k_list ? (long long)p.k_bound * p.h_k : units_grid(p.k_units, p.k_unit_size);
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NWK * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -746,11 +742,8 @@ template <typename E, int D, int NW, int FEAT>
 static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2 + NW * 32 * 16;  // K/V double buffers (+ the row padding of the staged dQ epilogue)
   auto kern = fa_bwd_dq_kernel<E, D, NW, FEAT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_mask{0};
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem) != 0) return -1;
   const long long total = p.q_list ? (long long)p.q_bound * p.h : units_grid(p.q_units, p.q_unit_size);
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;

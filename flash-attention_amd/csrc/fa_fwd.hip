@@ -35,6 +35,7 @@
 //   PP = true   ping-pong (8 waves): the tile is split into a VALU interval SM(j) and a matrix
 //               interval MF(j) = {S_{j+1} = K_{j+1}.Q^T, O += V_j^T.P_j}; waves 4-7 run the same
 //               stream one interval late, so each SIMD always has one wave in each kind of interval.
+#include <cstdio>
 #include <algorithm>
 #include <type_traits>
 
@@ -763,15 +764,17 @@ template <typename E, int D, int NW, int FEAT, bool PP>
 static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2 + NW * 32 * 16;  // K/V double buffers (+ the row padding of the staged O epilogue)
   auto kern = fa_fwd_kernel<E, D, NW, FEAT, PP>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_mask{0};
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem) != 0) return -1;
   const long long total = units_grid(p.n_units, p.unit_size);
   if (total <= 0) return 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  if (hipGetLastError() != hipSuccess) return -1;
+  LastSchedule& ls = last_schedule();
+  ls.fwd_kernel = 1; ls.fwd_nw = PP ? 16 : NW; ls.fwd_feat = FEAT; ls.fwd_splits = p.n_splits; ls.fwd_list = p.work_list != nullptr; ls.d = D;
+  ls.bf16 = std::is_same<E, __bf16>::value;
+  snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_kernel<%s,%d,%d,feat%d,%s>", ls.bf16 ? "bf16" : "f16", D, NW, FEAT, PP ? "pingpong" : "lockstep");
+  return 0;
 }
 
 int fwd_block_m(int nw) { return nw == 16 ? 256 : 32 * nw; }
@@ -808,7 +811,7 @@ static int launch_fwd_ed(const FwdK& p, int nw, hipStream_t stream) {
 // nw: 4 / 8 = lock-step schedule with 4 / 8 waves per workgroup, 16 = 8-wave ping-pong schedule
 int launch_fwd(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream) {
   // the scalar-base + 32-bit lane-offset tile loads need one tile's extent to fit 32 bits
-  if ((uint64_t)64 * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 31)) return -2;
+  if ((uint64_t)64 * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 31)) return -3;
   if (dtype_bf16) {
     if (d == 128) return launch_fwd_ed<__bf16, 128>(p, nw, stream);
     if (d == 64) return launch_fwd_ed<__bf16, 64>(p, nw, stream);

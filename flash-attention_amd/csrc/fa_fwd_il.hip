@@ -16,6 +16,7 @@
 //
 // One iteration of the tile loop = two steps = one 64-key K tile and the previous V tile, double-buffered
 // in LDS exactly as in the lock-step kernel (64 KB), one barrier per iteration.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -587,33 +588,32 @@ template <typename E, int D, int NW, int SCHED>
 static int launch_fwd_il_t(const FwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2 + (NW == 8 ? NW * 32 * D * 2 : 0);
   auto kern = fa_fwd_il_kernel<E, D, NW, SCHED>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
-    hipFuncAttributes fattr;  // the kernel addresses LDS by byte offset: the dynamic segment must start at 0
-    if (hipFuncGetAttributes(&fattr, (const void*)kern) != hipSuccess || fattr.sharedSizeBytes != 0) return -1;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_mask{0};  // the kernel addresses LDS by byte offset: the dynamic segment must start at 0
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
   const long long total = p.work_list ? (long long)p.work_bound * p.h : units_grid(p.n_units, p.unit_size);
   if (total <= 0) return 0;
 #ifdef FA_IL_EXPERIMENTS  // occupancy experiments: extra (unused) dynamic LDS
-  if (const char* e = getenv("FA_IL_LDS_PAD")) {
-    const int padded = smem + atoi(e);
+  if (knobs().lds_pad > 0) {
+    const int padded = smem + knobs().lds_pad;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), padded, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
   }
 #endif
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  if (hipGetLastError() != hipSuccess) return -1;
+  LastSchedule& ls = last_schedule();
+  ls.fwd_kernel = 2; ls.fwd_nw = NW; ls.fwd_feat = 0; ls.fwd_splits = 1; ls.fwd_list = p.work_list != nullptr; ls.d = D;
+  ls.bf16 = std::is_same<E, __bf16>::value;
+  snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_il_kernel<%s,%d,%d,%d>", ls.bf16 ? "bf16" : "f16", D, NW, SCHED);
+  return 0;
 }
 
 // nw = 4 or 8 waves per workgroup (query block = 32*nw rows)
 int launch_fwd_il(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream) {
   // FA_IL_SCHED=0: compiler-ordered steady-state step; default: hand-placed slots, operand reads 3 slots ahead
-  const char* sched_env = getenv("FA_IL_SCHED");
-  const int sched = sched_env ? atoi(sched_env) : 3;
-  if ((uint64_t)64 * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 31)) return -2;
+  const int sched = knobs().il_sched;
+  if ((uint64_t)64 * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 31)) return -3;
   if (p.softcap > 0.f || p.alibi != nullptr || p.rng != nullptr || p.n_splits > 1) return -2;
 #define FA_IL_CASE(E_, D_, NW_)                                                                       \
   if (d == D_ && nw == NW_)                                                                           \

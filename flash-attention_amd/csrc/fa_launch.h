@@ -1,9 +1,53 @@
 // Host-side launch entry points of the kernel translation units (internal to libfa_gfx950.so).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "fa_kernel_params.h"
 
 namespace fa {
+
+// Run-time knobs (environment, read ONCE per process; fa_knobs_reload() re-reads them -- tests and the A/B tools
+// call it after changing the environment).  Defined in fa_api.cpp.
+struct Knobs {
+  int fwd_nw;          // FA_FWD_NW: 0 = heuristic; 4 / 8 / 16 lock-step, 34 / 38 pipelined, 64 = 64-rows-per-wave kernel
+  float rescale_thr;   // FA_RESCALE_THR: deferred-rescale threshold in log2 units (default 8; 0 = the reference's rule)
+  int varlen_list;     // FA_VARLEN_LIST: 0 = always the dense varlen grid
+  int il_sched;        // FA_IL_SCHED: 0 = compiler-ordered pipelined step, else hand-placed slots
+  int bwd_dq_nw;       // FA_BWD_DQ_NW: waves per dQ workgroup (4 or 8)
+  int bwd_mode;        // FA_BWD_MODE: 0 = heuristic
+  int lds_pad;         // FA_IL_LDS_PAD (occupancy experiments, FA_IL_EXPERIMENTS builds only)
+};
+const Knobs& knobs();
+
+// What the last fa_fwd* / fa_bwd* call of this thread launched (fa_last_schedule in the C ABI).
+struct LastSchedule {
+  int fwd_kernel;   // 0 none, 1 fa_fwd_kernel (lock-step), 2 fa_fwd_il_kernel (pipelined), 3 fa_fwd_w64_kernel
+  int fwd_nw;       // waves per workgroup (16 = 8-wave ping-pong)
+  int fwd_feat;     // FEAT_* variant of the lock-step kernel
+  int fwd_splits;   // split-KV factor
+  int fwd_list;     // 1 = varlen work list
+  int d, bf16;
+  int bwd_dq_nw, bwd_list;
+  char name[96];
+};
+LastSchedule& last_schedule();
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: `mask` (one per kernel instantiation) records the devices
+// it has been set on.  Concurrent first calls may both set it (idempotent).  Also checks that the kernel has no static
+// LDS in front of the dynamic segment when the kernel addresses LDS by absolute byte offset.
+inline int ensure_dyn_lds(std::atomic<unsigned long long>& mask, const void* kern, int smem, bool need_base0 = false) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (dev < 64 && (mask.load(std::memory_order_acquire) & bit)) return 0;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return -1;
+  if (need_base0) {
+    hipFuncAttributes fattr;
+    if (hipFuncGetAttributes(&fattr, kern) != hipSuccess || fattr.sharedSizeBytes != 0) return -1;
+  }
+  if (dev < 64) mask.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
 
 // Choose the XCD mapping (see xcd_interleave): whole KV groups split by head range when the KV head count is a
 // multiple of 8; otherwise round-robin over KV groups, falling back to heads and then to single blocks whenever

@@ -412,7 +412,7 @@ std::vector<Tensor> mha_varlen_bwd(const Tensor& dout, const Tensor& q, const Te
 }
 
 // mha_fwd_kvcache (flash_api.cpp:1243-1532): inference forward against a (contiguous, batch-indexed or paged) KV
-// cache, optionally appending new keys/values first.  Rotary embedding and leftpad_k are not built.
+// cache, optionally appending new keys/values first (rotary embedding of the new keys / queries and leftpad_k included).
 std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tensor& vcache, OptTensor& k_, OptTensor& v_,
                                     OptTensor& seqlens_k_, OptTensor& rotary_cos_, OptTensor& rotary_sin_,
                                     OptTensor& cache_batch_idx_, OptTensor& leftpad_k_, OptTensor& block_table_,

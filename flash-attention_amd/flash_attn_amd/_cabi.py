@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-FA_ABI_VERSION = 4
+FA_ABI_VERSION = 5
 FA_DTYPE_FP16, FA_DTYPE_BF16 = 0, 1
 FA_OK, FA_ERR_INVALID_ARGUMENT, FA_ERR_UNSUPPORTED, FA_ERR_LAUNCH, FA_ERR_WORKSPACE = 0, -1, -2, -3, -4
 
@@ -86,7 +86,7 @@ class FaBwdParams(C.Structure):
 
 EXPORTS = (
     "fa_abi_version", "fa_sizeof_fwd_params", "fa_sizeof_bwd_params", "fa_sizeof_kvappend_params", "fa_sizeof_rotary_params",
-    "fa_last_error", "fa_rotary",
+    "fa_last_error", "fa_rotary", "fa_knobs_reload", "fa_last_schedule", "fa_last_kernel_name",
     "fa_fwd", "fa_varlen_fwd", "fa_fwd_kvcache", "fa_kvcache_append", "fa_set_rng_state", "fa_fwd_workspace_bytes",
     "fa_bwd_workspace_bytes", "fa_bwd", "fa_varlen_bwd",
 )
@@ -129,6 +129,11 @@ def load():
         fn.argtypes = [C.POINTER(FaBwdParams), C.c_void_p]
         fn.restype = C.c_int
     lib.fa_sizeof_rotary_params.restype = C.c_int
+    lib.fa_knobs_reload.argtypes = []
+    lib.fa_knobs_reload.restype = None
+    lib.fa_last_schedule.argtypes = [C.POINTER(C.c_int32), C.c_int]
+    lib.fa_last_schedule.restype = C.c_int
+    lib.fa_last_kernel_name.restype = C.c_char_p
     lib.fa_rotary.argtypes = [C.POINTER(FaRotaryParams), C.c_void_p]
     lib.fa_rotary.restype = C.c_int
     lib.fa_set_rng_state.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]

@@ -19,6 +19,26 @@ from . import _cabi
 _NATIVE_HEAD_DIMS = (64, 128, 256)
 
 
+def reload_knobs() -> None:
+    """Re-read the FA_* environment knobs (the library reads them once per process)."""
+    _cabi.load().fa_knobs_reload()
+
+
+_SCHED_FIELDS = ("fwd_kernel", "fwd_nw", "fwd_feat", "fwd_splits", "fwd_list", "d", "bf16", "bwd_dq_nw", "bwd_list")
+FWD_KERNEL_NAMES = {0: "none", 1: "fa_fwd_kernel", 2: "fa_fwd_il_kernel", 3: "fa_fwd_w64_kernel"}
+
+
+def last_schedule() -> dict:
+    """Kernels enqueued by this thread's last forward / backward call (C ABI fa_last_schedule)."""
+    import ctypes as C
+    lib = _cabi.load()
+    buf = (C.c_int32 * len(_SCHED_FIELDS))()
+    lib.fa_last_schedule(buf, len(_SCHED_FIELDS))
+    d = dict(zip(_SCHED_FIELDS, [int(x) for x in buf]))
+    d["name"] = lib.fa_last_kernel_name().decode()
+    return d
+
+
 def _dtype_code(t: torch.Tensor) -> int:
     if t.dtype == torch.bfloat16:
         return _cabi.FA_DTYPE_BF16

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 4
+#define FA_ABI_VERSION 5
 
 enum { FA_DTYPE_FP16 = 0, FA_DTYPE_BF16 = 1 };
 
@@ -189,6 +189,19 @@ int fa_sizeof_kvappend_params(void);
 int fa_sizeof_rotary_params(void);
 /* Last error message of the calling thread ("" if none). */
 const char* fa_last_error(void);
+
+/* Run-time knobs (FA_FWD_NW, FA_RESCALE_THR, FA_VARLEN_LIST, FA_IL_SCHED, FA_BWD_DQ_NW; INTEGRATION.md "Run-time knobs")
+ * are read from the environment once per process; this re-reads them (tests / A-B tools after changing the environment). */
+void fa_knobs_reload(void);
+/* Which kernels the calling thread's last fa_fwd* / fa_bwd* call enqueued (for tests and the benchmark's labels; the
+ * reference exposes nothing comparable -- its dispatch is compile-time, flash_fwd_launch_template.h).  Fills up to n of
+ * FA_SCHEDULE_FIELDS int32: {forward kernel id (0 none, 1 lock-step fa_fwd_kernel, 2 pipelined fa_fwd_il_kernel,
+ * 3 64-rows-per-wave fa_fwd_w64_kernel), waves per workgroup (16 = 8-wave ping-pong), feature variant, key splits,
+ * varlen work list used, head dim, bf16, dQ-kernel waves, backward work lists used}; returns FA_SCHEDULE_FIELDS. */
+#define FA_SCHEDULE_FIELDS 9
+int fa_last_schedule(int32_t* out, int n);
+/* Name of the forward kernel instantiation of that call, e.g. "fa::fa_fwd_il_kernel<bf16,128,4,3>" ("" if none). */
+const char* fa_last_kernel_name(void);
 
 /* Forward, fixed-length batch.  cu_seqlens_* must be NULL.  `stream` is a hipStream_t. */
 int fa_fwd(const FaFwdParams* params, void* stream);

@@ -14,6 +14,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+class _Knobs:
+    """Set FA_* environment knobs for one test: the library reads its knobs once per process, so every change is
+    followed by fa_knobs_reload(); the previous environment is restored (and reloaded) at teardown."""
+
+    def __init__(self, monkeypatch):
+        self._mp = monkeypatch
+
+    def set(self, name, value):
+        from flash_attn_amd import backend
+        self._mp.setenv(name, str(value))
+        backend.reload_knobs()
+
+    def unset(self, name):
+        from flash_attn_amd import backend
+        self._mp.delenv(name, raising=False)
+        backend.reload_knobs()
+
+
+@pytest.fixture
+def knobs(monkeypatch):
+    from flash_attn_amd import backend
+    yield _Knobs(monkeypatch)
+    monkeypatch.undo()
+    backend.reload_knobs()
+
+
 @pytest.fixture(scope="session")
 def golden_cases():
     import numpy as np

@@ -109,8 +109,8 @@ def _varlen(be, q, k, v, do, cu_q, cu_k, mq, mk, causal):
 
 @pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("causal", [False, True])
-def test_varlen_backward_equals_per_sequence_bit_exact(be, monkeypatch, d, causal):
-    monkeypatch.setenv("FA_FWD_NW", "34")  # pin the forward schedule: out / LSE feed the backward
+def test_varlen_backward_equals_per_sequence_bit_exact(be, knobs, d, causal):
+    knobs.set("FA_FWD_NW", "34")  # pin the forward schedule: out / LSE feed the backward
     torch.manual_seed(5)
     lens_q = [0, 76, 34, 146, 1, 300, 257]
     lens_k = [5, 76, 1, 300, 77, 300, 255]
@@ -200,7 +200,7 @@ def test_softcap_backward_vs_oracle(be, d, alibi):
 
 @pytest.mark.parametrize("causal,window", [(True, (-1, -1)), (False, (-1, -1)), (False, (300, 100))])
 @pytest.mark.parametrize("hk", [8, 2])
-def test_varlen_work_list_equals_dense_grid(be, monkeypatch, hk, causal, window):
+def test_varlen_work_list_equals_dense_grid(be, knobs, hk, causal, window):
     """Uneven packed batch (long-tail lengths, empty sequences included): the scheduled work list (forward, dQ and dK/dV)
     gives bit-for-bit the results of the dense max_seqlen grid, and both match the oracle on sampled sequences."""
     from oracle import attention_oracle as orc
@@ -224,9 +224,9 @@ def test_varlen_work_list_equals_dense_grid(be, monkeypatch, hk, causal, window)
                                       causal, window[0], window[1], 0.0, False, None, None)
         return out, lse, dq, dk, dv
 
-    monkeypatch.setenv("FA_FWD_NW", "34")
+    knobs.set("FA_FWD_NW", "34")
     listed = run()
-    monkeypatch.setenv("FA_VARLEN_LIST", "0")
+    knobs.set("FA_VARLEN_LIST", "0")
     dense = run()
     for a, b_ in zip(listed, dense):
         assert torch.equal(a, b_)

@@ -104,10 +104,10 @@ def test_strided_qkv_packed_views(be):
 @pytest.mark.parametrize("nw", ["4", "8", "16", "34", "38"])
 @pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("causal", [False, True])
-def test_varlen_equals_per_sequence_bit_exact(be, monkeypatch, d, causal, nw):
+def test_varlen_equals_per_sequence_bit_exact(be, knobs, d, causal, nw):
     """cu_seqlens indexing check: with the schedule pinned (the default heuristic picks it from max_seqlen, which
     differs between a packed batch and its single sequences), a varlen call is bit-identical to per-sequence calls."""
-    monkeypatch.setenv("FA_FWD_NW", nw)
+    knobs.set("FA_FWD_NW", nw)
     torch.manual_seed(2)
     lens_q = [0, 76, 34, 146, 1, 300, 257]
     lens_k = [5, 76, 1, 300, 77, 300, 255]
@@ -153,14 +153,14 @@ def test_run_to_run_bitwise_deterministic(be):
 
 @pytest.mark.parametrize("thr", ["0", "8"])
 @pytest.mark.parametrize("nw", ["4", "8", "16"])
-def test_rescale_branch_is_forced_and_exact(be, monkeypatch, thr, nw):
+def test_rescale_branch_is_forced_and_exact(be, knobs, thr, nw):
     """The deferred-rescale branch is rare on random data: force it.  One key per 64-key tile is spiked against
     one query row so that the row's maximum jumps by far more than any threshold at a chosen tile, for every
     schedule and for threshold 0 (reference rule) and 8 (default); checked against the fp64 oracle on the
     FULL tensor (a wrong rescale corrupts whole rows, not the spiked element only)."""
     from oracle import attention_oracle as orc
-    monkeypatch.setenv("FA_RESCALE_THR", thr)
-    monkeypatch.setenv("FA_FWD_NW", nw)
+    knobs.set("FA_RESCALE_THR", thr)
+    knobs.set("FA_FWD_NW", nw)
     torch.manual_seed(11)
     B, S, H, D = 1, 1024, 2, 128
     q = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16)
@@ -176,12 +176,12 @@ def test_rescale_branch_is_forced_and_exact(be, monkeypatch, thr, nw):
     assert max_abs(out.float(), ref) < 2e-2
     assert max_abs(lse, torch.from_numpy(lse_ref).cuda().float()) < 2e-3
     # same inputs, threshold 0 vs this threshold agree to rounding
-    monkeypatch.setenv("FA_RESCALE_THR", "0")
+    knobs.set("FA_RESCALE_THR", "0")
     out0, lse0 = _fwd(be, q, k, v)
     assert max_abs(out.float(), out0.float()) < 1.6e-2 and max_abs(lse, lse0) < 1e-4
 
 
-def test_threshold_accuracy_budget(be, monkeypatch):
+def test_threshold_accuracy_budget(be, knobs):
     """Error against the fp64 oracle with the default threshold stays within 1.5x of threshold 0."""
     from oracle import attention_oracle as orc
     torch.manual_seed(12)
@@ -191,7 +191,7 @@ def test_threshold_accuracy_budget(be, monkeypatch):
     ref = torch.from_numpy(orc.attention_fwd(q, k, v, causal=True)[0]).cuda()
     errs = {}
     for thr in ("0", "8"):
-        monkeypatch.setenv("FA_RESCALE_THR", thr)
+        knobs.set("FA_RESCALE_THR", thr)
         errs[thr] = max_abs(_fwd(be, q, k, v, True)[0].float(), ref)
     assert errs["8"] <= 1.5 * errs["0"] + 1e-3, errs
 

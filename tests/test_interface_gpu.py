@@ -54,8 +54,8 @@ def test_packed_variants_and_return_lse(fi):
     assert max_abs(o2.float(), r2.float()) < 5e-3
 
 
-def test_varlen_func_autograd_matches_padded(fi, monkeypatch):
-    monkeypatch.setenv("FA_FWD_NW", "34")
+def test_varlen_func_autograd_matches_padded(fi, knobs):
+    knobs.set("FA_FWD_NW", "34")
     torch.manual_seed(2)
     lens = [33, 128, 1, 200]
     H, Hk, d = 4, 4, 128

@@ -38,6 +38,7 @@ def main():
                 os.environ["FA_IL_SCHED"] = parts[2]
             else:
                 os.environ.pop("FA_IL_SCHED", None)
+            be.reload_knobs()
         for x in variants:
             setv(x); f()
         for _ in range(5):
@@ -47,7 +48,7 @@ def main():
         line = f"fwd B={B} S={S} H={H} D={D} causal={int(causal)}: " + "  ".join(
             f"[{x}] {statistics.median(res[x]):.3f} ms {fl / statistics.median(res[x]) / 1e9:7.1f} TF" for x in variants)
         print(line, flush=True)
-    os.environ.pop("FA_FWD_NW", None); os.environ.pop("FA_RESCALE_THR", None)
+    os.environ.pop("FA_FWD_NW", None); os.environ.pop("FA_RESCALE_THR", None); be.reload_knobs()
     if "--bwd" in sys.argv:
         for (B, S, H, D, causal) in shapes:
             q = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16); k = torch.randn_like(q); v = torch.randn_like(q)

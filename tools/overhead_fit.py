@@ -18,7 +18,7 @@ def t_ms(fn, reps=20):
 B, H, Sq, D = 4, 32, 4096, 128
 q = torch.randn(B, Sq, H, D, device="cuda", dtype=torch.bfloat16)
 for nw in ("34", "38"):
-    os.environ["FA_FWD_NW"] = nw
+    os.environ["FA_FWD_NW"] = nw; be.reload_knobs()
     xs, ys = [], []
     for Sk in (64, 128, 256, 512, 1024, 2048, 4096):
         k = torch.randn(B, Sk, H, D, device="cuda", dtype=torch.bfloat16); v = torch.randn_like(k)

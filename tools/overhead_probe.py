@@ -13,7 +13,7 @@ def t_ms(fn, reps=20):
     return statistics.median(ts)
 H, D = 16, 128
 for nw in ("34", "38", "4"):
-    os.environ["FA_FWD_NW"] = nw
+    os.environ["FA_FWD_NW"] = nw; be.reload_knobs()
     for S in (256, 512, 1024, 2048, 4096):
         B = 262144 // S  # constant total rows = 256k per head
         B = max(1, B // 16)

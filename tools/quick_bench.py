@@ -50,10 +50,10 @@ def main():
     B, S, H, d = 4, 4096, 32, 128
     q = torch.randn(B, S, H, d, device="cuda", dtype=torch.bfloat16); k = torch.randn_like(q); v = torch.randn_like(q)
     for nw in ("4", "8"):
-        os.environ["FA_FWD_NW"] = nw
+        os.environ["FA_FWD_NW"] = nw; be.reload_knobs()
         ms = bench(lambda: be.fwd(q, k, v, None, None, 0.0, d ** -0.5, True, -1, -1, 0.0, False, None))
         print(f"cfg3 fwd NW={nw}: {ms:.3f} ms {4 * B * H * S * S * d / 2 / ms / 1e9:.1f} TFLOPS", flush=True)
-    os.environ.pop("FA_FWD_NW")
+    os.environ.pop("FA_FWD_NW"); be.reload_knobs()
 
 
 if __name__ == "__main__":
