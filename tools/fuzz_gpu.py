@@ -1,70 +1,104 @@
 """Randomised parity sweep (GPU): random shapes / head dims / masks / features through the public interface mirror,
-forward and backward against the fp64 oracle.  usage: fuzz_gpu.py [seconds] [seed]"""
+forward and backward against the fp64 oracle.  usage: fuzz_gpu.py [seconds] [seed] [--big]
+
+Importable: run(budget_s, seed, big=False, max_cases=None) -> (cases, worst error/tolerance per (tensor, feature), failures);
+tests/test_fuzz_gpu.py runs a seeded slice of it inside `pytest -m gpu`.  --big mixes in long key loops (Sk up to 8192, small
+batch / head counts so that the fp64 oracle stays within seconds per case).
+
+Tolerance: 3e-2 (out) / 8e-2 (gradients) x max(1, |ref|max) / (1 - p_dropout), plus -- for dq / dk only -- the a-priori size of
+the one rounding the kernels (ours and the reference's, flash_bwd_preprocess_kernel.h:40-48) cannot avoid: delta_i = sum_d dO.O
+is formed from the 16-bit ROUNDED output, so dS carries 2^-9-relative noise of |dO.O| per query, which dk sums over the queries
+(dq over the keys): 4 sigma of a random walk = 4 * 2^-9 * sqrt(D * n) * scale * rms(dO) rms(O) rms(q or k).  It only matters when
+the true gradient is ~0 (e.g. a single visible key: softmax over one element has zero gradient).
+"""
 import os, sys, time, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "flash-attention_amd"))
 import numpy as np
 import torch
-from flash_attn_amd import flash_attn_interface as fi
-from oracle import attention_oracle as orc
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t0, n, worst = time.time(), 0, {}
-while time.time() - t0 < budget:
-    n += 1
-    dtype = [torch.bfloat16, torch.float16][rng.integers(2)]
-    d = int(rng.choice([32, 40, 64, 72, 96, 128, 160, 192, 256]))
-    hk = int(rng.choice([1, 2, 3, 4])); h = hk * int(rng.choice([1, 2, 4]))
-    B = int(rng.integers(1, 4))
-    sq = int(rng.choice([1, 7, 33, 64, 65, 127, 128, 129, 200, 256, 300, 513])); sk = int(rng.choice([1, 5, 63, 64, 65, 128, 191, 256, 257, 400, 640]))
-    mode = rng.choice(["full", "causal", "local"])
-    window = (-1, -1) if mode != "local" else (int(rng.integers(0, sk + 10)), int(rng.integers(0, sk + 10)))
-    feat = rng.choice(["none", "none", "alibi", "softcap", "dropout"])
-    varlen = bool(rng.integers(2)) and sq > 1
-    torch.manual_seed(n)
-    kw = dict(causal=(mode == "causal"), window_size=window)
-    alibi = None
-    if feat == "alibi": alibi = torch.rand(h, device="cuda") * 0.3; kw["alibi_slopes"] = alibi
-    if feat == "softcap": kw["softcap"] = float(rng.choice([5.0, 30.0]))
-    pd = 0.0
-    if feat == "dropout": pd = float(rng.choice([0.1, 0.25])); kw["dropout_p"] = pd; kw["return_attn_probs"] = True
-    try:
-        if not varlen:
-            q = torch.randn(B, sq, h, d, device="cuda", dtype=dtype, requires_grad=True)
-            k = torch.randn(B, sk, hk, d, device="cuda", dtype=dtype, requires_grad=True)
-            v = torch.randn(B, sk, hk, d, device="cuda", dtype=dtype, requires_grad=True)
-            res = fi.flash_attn_func(q, k, v, **kw)
-            out = res[0] if pd else res
-            keep = None if not pd else (res[2].to(torch.int32) <= math.floor(255 * (1 - pd))).cpu().numpy()
-            g = torch.randn_like(out)
-            dq, dk, dv = torch.autograd.grad(out, (q, k, v), g)
-            al = None if alibi is None else alibi.cpu().numpy()
-            o_ref, _ = orc.attention_fwd(q, k, v, None, kw["causal"], window, kw.get("softcap", 0.0), al, pd, keep)
-            gr = orc.attention_bwd(g, q, k, v, None, None, None, kw["causal"], window, kw.get("softcap", 0.0), al, pd, keep)
-            pairs = [("out", out, o_ref), ("dq", dq, gr[0]), ("dk", dk, gr[1]), ("dv", dv, gr[2])]
-        else:
-            lq = [int(x) for x in rng.integers(0, sq + 1, size=B + 1)]; lq[0] = sq
-            lk = [max(1, l + int(x)) for l, x in zip(lq, rng.integers(-3, 40, size=B + 1))] if mode != "causal" else lq
-            cu_q = torch.tensor([0] + list(np.cumsum(lq)), dtype=torch.int32, device="cuda"); cu_k = torch.tensor([0] + list(np.cumsum(lk)), dtype=torch.int32, device="cuda")
-            q = torch.randn(sum(lq), h, d, device="cuda", dtype=dtype, requires_grad=True)
-            k = torch.randn(sum(lk), hk, d, device="cuda", dtype=dtype, requires_grad=True)
-            v = torch.randn(sum(lk), hk, d, device="cuda", dtype=dtype, requires_grad=True)
-            kw2 = {a: b_ for a, b_ in kw.items() if a != "return_attn_probs"}; kw2.pop("dropout_p", None)   # varlen fuzz without dropout
-            out = fi.flash_attn_varlen_func(q, k, v, cu_q, cu_k, max(lq), max(lk), **kw2)
-            g = torch.randn_like(out)
-            dq, dk, dv = torch.autograd.grad(out, (q, k, v), g)
-            al = None if alibi is None else np.broadcast_to(alibi.cpu().numpy(), (len(lq), h))
-            o_ref, _ = orc.varlen_fwd(q, k, v, cu_q.cpu().numpy(), cu_k.cpu().numpy(), None, kw["causal"], window, kw.get("softcap", 0.0), al)
-            gr = orc.varlen_bwd(g, q, k, v, cu_q.cpu().numpy(), cu_k.cpu().numpy(), None, kw["causal"], window, kw.get("softcap", 0.0), al)
-            pairs = [("out", out, o_ref), ("dq", dq, gr[0]), ("dk", dk, gr[1]), ("dv", dv, gr[2])]
-        for nm, got, ref in pairs:
-            ref = np.asarray(ref); err = float(np.abs(got.detach().float().cpu().numpy() - ref).max()) if ref.size else 0.0
-            tol = (3e-2 if nm == "out" else 8e-2) * max(1.0, float(np.abs(ref).max()) if ref.size else 1.0) / (1 - pd)
-            key = (nm, feat)
-            worst[key] = max(worst.get(key, 0.0), err / tol)
-            if not (err <= tol):
-                print(f"FAIL case {n}: {nm} err {err:.3e} tol {tol:.3e}  dtype={dtype} d={d} h={h}/{hk} B={B} sq={sq} sk={sk} mode={mode} window={window} feat={feat} varlen={varlen}", flush=True)
-    except Exception as e:
-        print(f"EXC case {n}: {type(e).__name__}: {str(e)[:200]}  dtype={dtype} d={d} h={h}/{hk} B={B} sq={sq} sk={sk} mode={mode} window={window} feat={feat} varlen={varlen}", flush=True)
-print(f"fuzz: {n} cases in {time.time() - t0:.0f} s; worst error/tolerance per (tensor, feature):", {f"{a}/{b}": round(c, 2) for (a, b), c in sorted(worst.items())})
+
+def _rms(x):
+    x = np.asarray(x, dtype=np.float64)
+    return float(np.sqrt((x * x).mean())) if x.size else 0.0
+
+
+def run(budget, seed=0, big=False, max_cases=None, verbose=True):
+  from flash_attn_amd import flash_attn_interface as fi
+  from oracle import attention_oracle as orc
+  rng = np.random.default_rng(seed)
+  t0, n, worst, failures = time.time(), 0, {}, []
+  while time.time() - t0 < budget and (max_cases is None or n < max_cases):
+      n += 1
+      dtype = [torch.bfloat16, torch.float16][rng.integers(2)]
+      d = int(rng.choice([32, 40, 64, 72, 96, 128, 160, 192, 256]))
+      hk = int(rng.choice([1, 2, 3, 4])); h = hk * int(rng.choice([1, 2, 4]))
+      B = int(rng.integers(1, 4))
+      sq = int(rng.choice([1, 7, 33, 64, 65, 127, 128, 129, 200, 256, 300, 513])); sk = int(rng.choice([1, 5, 63, 64, 65, 128, 191, 256, 257, 400, 640]))
+      if big and n % 3 == 0:  # long key loops: every schedule the heuristic picks for S >= 3k, fp64 oracle kept to seconds
+          d = int(rng.choice([64, 128, 96])); hk = int(rng.choice([1, 2])); h = hk * int(rng.choice([1, 2])); B = 1
+          sq = int(rng.choice([513, 1024, 2000, 4096])); sk = int(rng.choice([3000, 4096, 6144, 8192]))
+      mode = rng.choice(["full", "causal", "local"])
+      window = (-1, -1) if mode != "local" else (int(rng.integers(0, sk + 10)), int(rng.integers(0, sk + 10)))
+      feat = rng.choice(["none", "none", "alibi", "softcap", "dropout"])
+      varlen = bool(rng.integers(2)) and sq > 1
+      torch.manual_seed(n)
+      kw = dict(causal=(mode == "causal"), window_size=window)
+      alibi = None
+      if feat == "alibi": alibi = torch.rand(h, device="cuda") * 0.3; kw["alibi_slopes"] = alibi
+      if feat == "softcap": kw["softcap"] = float(rng.choice([5.0, 30.0]))
+      pd = 0.0
+      if feat == "dropout": pd = float(rng.choice([0.1, 0.25])); kw["dropout_p"] = pd; kw["return_attn_probs"] = True
+      try:
+          if not varlen:
+              q = torch.randn(B, sq, h, d, device="cuda", dtype=dtype, requires_grad=True)
+              k = torch.randn(B, sk, hk, d, device="cuda", dtype=dtype, requires_grad=True)
+              v = torch.randn(B, sk, hk, d, device="cuda", dtype=dtype, requires_grad=True)
+              res = fi.flash_attn_func(q, k, v, **kw)
+              out = res[0] if pd else res
+              keep = None if not pd else (res[2].to(torch.int32) <= math.floor(255 * (1 - pd))).cpu().numpy()
+              g = torch.randn_like(out)
+              dq, dk, dv = torch.autograd.grad(out, (q, k, v), g)
+              al = None if alibi is None else alibi.cpu().numpy()
+              o_ref, _ = orc.attention_fwd(q, k, v, None, kw["causal"], window, kw.get("softcap", 0.0), al, pd, keep)
+              gr = orc.attention_bwd(g, q, k, v, None, None, None, kw["causal"], window, kw.get("softcap", 0.0), al, pd, keep)
+              pairs = [("out", out, o_ref), ("dq", dq, gr[0]), ("dk", dk, gr[1]), ("dv", dv, gr[2])]
+          else:
+              lq = [int(x) for x in rng.integers(0, sq + 1, size=B + 1)]; lq[0] = sq
+              lk = [max(1, l + int(x)) for l, x in zip(lq, rng.integers(-3, 40, size=B + 1))] if mode != "causal" else lq
+              cu_q = torch.tensor([0] + list(np.cumsum(lq)), dtype=torch.int32, device="cuda"); cu_k = torch.tensor([0] + list(np.cumsum(lk)), dtype=torch.int32, device="cuda")
+              q = torch.randn(sum(lq), h, d, device="cuda", dtype=dtype, requires_grad=True)
+              k = torch.randn(sum(lk), hk, d, device="cuda", dtype=dtype, requires_grad=True)
+              v = torch.randn(sum(lk), hk, d, device="cuda", dtype=dtype, requires_grad=True)
+              kw2 = {a: b_ for a, b_ in kw.items() if a != "return_attn_probs"}; kw2.pop("dropout_p", None)   # varlen fuzz without dropout
+              out = fi.flash_attn_varlen_func(q, k, v, cu_q, cu_k, max(lq), max(lk), **kw2)
+              g = torch.randn_like(out)
+              dq, dk, dv = torch.autograd.grad(out, (q, k, v), g)
+              al = None if alibi is None else np.broadcast_to(alibi.cpu().numpy(), (len(lq), h))
+              o_ref, _ = orc.varlen_fwd(q, k, v, cu_q.cpu().numpy(), cu_k.cpu().numpy(), None, kw["causal"], window, kw.get("softcap", 0.0), al)
+              gr = orc.varlen_bwd(g, q, k, v, cu_q.cpu().numpy(), cu_k.cpu().numpy(), None, kw["causal"], window, kw.get("softcap", 0.0), al)
+              pairs = [("out", out, o_ref), ("dq", dq, gr[0]), ("dk", dk, gr[1]), ("dv", dv, gr[2])]
+          sc_ = d ** -0.5
+          noise = 4 * 2.0 ** -9 * math.sqrt(d) * sc_ * _rms(g.float().cpu()) * _rms(out.detach().float().cpu())
+          extra = {"dk": noise * math.sqrt(max(sq, 1)) * _rms(q.detach().float().cpu()), "dq": noise * math.sqrt(max(sk, 1)) * _rms(k.detach().float().cpu())}
+          for nm, got, ref in pairs:
+              ref = np.asarray(ref); err = float(np.abs(got.detach().float().cpu().numpy() - ref).max()) if ref.size else 0.0
+              tol = (3e-2 if nm == "out" else 8e-2) * max(1.0, float(np.abs(ref).max()) if ref.size else 1.0) / (1 - pd) + extra.get(nm, 0.0)
+              key = (nm, feat)
+              worst[key] = max(worst.get(key, 0.0), err / tol)
+              if not (err <= tol):
+                  failures.append((n, nm, err, tol))
+                  print(f"FAIL case {n}: {nm} err {err:.3e} tol {tol:.3e}  dtype={dtype} d={d} h={h}/{hk} B={B} sq={sq} sk={sk} mode={mode} window={window} feat={feat} varlen={varlen}", flush=True)
+      except Exception as e:
+          failures.append((n, "exception", str(e)[:200], 0.0))
+          print(f"EXC case {n}: {type(e).__name__}: {str(e)[:200]}  dtype={dtype} d={d} h={h}/{hk} B={B} sq={sq} sk={sk} mode={mode} window={window} feat={feat} varlen={varlen}", flush=True)
+  return n, worst, failures
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    budget = float(args[0]) if len(args) > 0 else 60.0
+    t0 = time.time()
+    n, worst, failures = run(budget, int(args[1]) if len(args) > 1 else 0, big="--big" in sys.argv)
+    print(f"fuzz: {n} cases in {time.time() - t0:.0f} s, {len(failures)} failures; worst error/tolerance per (tensor, feature):",
+          {f"{a}/{b}": round(c, 2) for (a, b), c in sorted(worst.items())})
