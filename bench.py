@@ -1,11 +1,12 @@
 """Headline benchmark: attention forward (and forward+backward) TFLOP/s on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sweep]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-sweep] [--no-cpu] [--no-traffic]
 
 Workload (BASELINE.json): config 3 -- B=4 H=32 S=4096 D=128 bf16 causal, synthetic N(0,1) inputs
 resident in HBM.  One "step" = one forward pass of the hot path (fa_fwd through the C ABI); the
-forward+backward rate on the same config and (with --sweep) the reference's seqlen sweep are
-reported as extra keys.  FLOP convention = the reference's (benchmarks/benchmark_flash_attention.py:
+forward+backward rate on the same config and the reference's seqlen sweep (S = 512 .. 16k, D = 128, causal and not) are
+reported as extra keys, `roofline.kernel` is what fa_last_schedule() says the C ABI launched, `roofline.traffic` comes from
+two rocprofv3 --pmc passes run from here (outside the timed region).  FLOP convention = the reference's (benchmarks/benchmark_flash_attention.py:
 27-30): fwd = 4*B*H*S^2*D (/2 causal), bwd = 2.5x, fwd+bwd = 3.5x.
 N>1: independent replicas, one process per GPU (the path has no exchange step).
 """
@@ -47,7 +48,7 @@ def time_kernel(fn, steps, warmup, sync):
 def cpu_baseline(D, S, causal, heads=8, reps=2):
     """Reference CPU SDPA (torch F.scaled_dot_product_attention, bf16) on a bounded sample of the same
     workload: `heads` (batch, head) units of config 3 (units are independent, so the rate is per-unit
-    exact); all host cores."""
+    exact); all host cores.  Forward, and forward+backward through autograd (one rep)."""
     import torch.nn.functional as F
     n = os.cpu_count() or 1
     torch.set_num_threads(n)
@@ -60,8 +61,53 @@ def cpu_baseline(D, S, causal, heads=8, reps=2):
     for _ in range(reps):
         F.scaled_dot_product_attention(q, k, v, is_causal=causal)
     dt = (time.perf_counter() - t0) / reps
-    return {"value": fwd_flops(1, heads, S, D, causal) / dt / 1e12, "unit": "TFLOP/s", "cores": n, "kind": "reference",
-            "sample": f"torch CPU SDPA bf16 fwd, {heads} of 128 (batch,head) units of config 3 (S={S}, D={D}, causal), {reps} reps"}
+    qg, kg, vg = (t.clone().requires_grad_() for t in (q, k, v))
+    t0 = time.perf_counter()
+    o = F.scaled_dot_product_attention(qg, kg, vg, is_causal=causal)
+    o.backward(torch.ones_like(o))
+    dt_fb = time.perf_counter() - t0
+    fl = fwd_flops(1, heads, S, D, causal)
+    return {"value": fl / dt / 1e12, "unit": "TFLOP/s", "cores": n, "kind": "reference",
+            "fwd_bwd_value": 3.5 * fl / dt_fb / 1e12,
+            "sample": f"torch CPU SDPA bf16, {heads} of 128 (batch,head) units of config 3 (S={S}, D={D}, causal): fwd {reps} reps, "
+                      f"fwd+bwd (autograd) 1 rep"}
+
+
+def measure_traffic(kernel_substr, timeout=240):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+    WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (kernel-trace only) over `bench.py --one-launch`; FETCH_SIZE is doubled
+    (gfx950 reports half the bytes of wide coalesced reads), both are KiB.  Returns (bytes, detail) or (None, reason)."""
+    import shutil, sqlite3, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fa_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--one-launch"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=timeout, check=True)
+            db = None
+            for root, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith(".db"):
+                        db = os.path.join(root, f)
+            if db is None:
+                return None, "no rocpd database written"
+            c = sqlite3.connect(db)
+            ccols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+            kn = "kernel_name" if "kernel_name" in ccols else "name"
+            rows = c.execute(f"select {kn}, avg(value), count(*) from counters_collection where counter_name = ? group by {kn}", (ctr,)).fetchall()
+            rows = [r for r in rows if kernel_substr in r[0]]
+            if not rows:
+                return None, f"kernel {kernel_substr} not in the {ctr} pass"
+            vals[ctr] = max(rows, key=lambda r: r[2])[1]
+        except Exception as e:  # profiler missing / refused / format change: report, never fail the bench
+            return None, f"{ctr} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    nbytes = int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+    return nbytes, {"fetch_size_kib_raw": vals["FETCH_SIZE"], "fetch_correction": 2.0, "write_size_kib_raw": vals["WRITE_SIZE"]}
 
 
 def dist_setup(backend=None, device=None):
@@ -86,31 +132,67 @@ def replica_aggregate(wall_seconds, units_per_rank, world, device="cpu"):
     return world * units_per_rank / wall_max, wall_max
 
 
+def sweep(be, dev, sync):
+    """The reference's headline sweep (benchmarks/benchmark_flash_attention.py:70-78): hidden dim 2048 (H = 16 at D = 128),
+    B = 16384 / S, bf16, dropout 0; TFLOP/s forward and forward+backward, non-causal and causal."""
+    rows = []
+    D, H = 128, 16
+    for causal in (False, True):
+        for S in (512, 1024, 2048, 4096, 8192, 16384):
+            B = 16384 // S
+            q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
+            k, v = torch.randn_like(q), torch.randn_like(q)
+            sc = D ** -0.5
+            f = lambda: be.fwd(q, k, v, None, None, 0.0, sc, causal, -1, -1, 0.0, False, None)
+            _, ms = time_kernel(f, 20, 5, sync)
+            name = be.last_schedule()["name"]
+            o, l, _, _ = f()
+            g = torch.randn_like(o)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            h = lambda: be.bwd(g, q, k, v, o, l, dq, dk, dv, None, 0.0, sc, causal, -1, -1, 0.0, False, None, None)
+            _, mb = time_kernel(h, 8, 2, sync)
+            fl = fwd_flops(B, H, S, D, causal)
+            rows.append({"seqlen": S, "batch": B, "causal": causal, "fwd_tflops": round(fl / ms / 1e9, 1),
+                         "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name})
+    return {"head_dim": D, "heads": H, "dtype": "bf16", "rows": rows}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--sweep", action="store_true", help="also print the reference's seqlen sweep (stderr)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the seqlen sweep (extra key `sweep`)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
+    ap.add_argument("--one-launch", action="store_true", help="(internal) a few forward launches of the workload, for the PMC passes")
     a = ap.parse_args()
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    from flash_attn_amd import backend as be
+
+    B, H, S, D, causal = 4, 32, 4096, 128, True
+    scale = D ** -0.5
+    if a.one_launch:
+        torch.manual_seed(0)
+        q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
+        k, v = torch.randn_like(q), torch.randn_like(q)
+        for _ in range(3):
+            be.fwd(q, k, v, None, None, 0.0, scale, causal, -1, -1, 0.0, False, None)
+        torch.cuda.synchronize(dev)
+        return
+
     rank, world = dist_setup("nccl", dev)
     dist_on = world > 1
     if dist_on:
         import torch.distributed as dist
 
-    from flash_attn_amd import backend as be
-
-    B, H, S, D, causal = 4, 32, 4096, 128, True
     torch.manual_seed(rank)
     q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
     k = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
     v = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
-    scale = D ** -0.5
     fwd = lambda: be.fwd(q, k, v, None, None, 0.0, scale, causal, -1, -1, 0.0, False, None)
 
     def sync():
@@ -119,8 +201,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    local_sync = lambda: torch.cuda.synchronize(dev)
     sync()
     wall, ms = time_kernel(fwd, a.steps, a.warmup, sync)
+    sched = be.last_schedule()   # which kernel instantiation the C ABI enqueued (fa_last_schedule / fa_last_kernel_name)
     flops = fwd_flops(B, H, S, D, causal)
     rate, wall_max = replica_aggregate(wall, flops * a.steps, world, dev)
     value = rate / 1e12  # whole-job aggregate over replicas, host-clocked
@@ -133,6 +217,7 @@ def main():
     _, ms_bwd = time_kernel(bwd, max(5, a.steps // 5), 3, sync)
 
     if rank == 0:
+        algo_bytes = 2 * (q.numel() + k.numel() + v.numel() + out.numel()) + 4 * lse.numel()
         res = {
             "metric": "attention_fwd_tflops", "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall_max / a.steps * 1e3, 4),
@@ -141,36 +226,26 @@ def main():
                        "batch": B, "heads": H, "seqlen": S, "head_dim": D, "causal": causal, "parallelism": f"replicas x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(flops / ms / 1e9, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "fa::fa_fwd_il_kernel<bf16,128,4,3> (software-pipelined forward, 4-wave workgroups; schedule chosen in fa_api.cpp)", "algorithmic_flops_per_launch": flops, "kernel_ms": round(ms, 4)},
+                         "kernel": sched["name"], "kernel_waves_per_workgroup": sched["fwd_nw"],
+                         "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": round(ms, 4)},
             "fwd_bwd": {"tflops": round(3.5 * flops / (ms + ms_bwd) / 1e9, 2), "bwd_tflops": round(2.5 * flops / ms_bwd / 1e9, 2),
                         "bwd_ms": round(ms_bwd, 4), "frac_of_peak": round(3.5 * flops / (ms + ms_bwd) / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)},
         }
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the committed
-        # rocprofv3 measurement of the same kernel/config (separate --pmc passes, gfx950 FETCH_SIZE x2 correction)
-        # is reported when present.
-        tpath = os.path.join(ROOT, "profiles", "r01_fwd_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                res["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+        # HBM traffic of the dominant kernel, measured now (two rocprofv3 --pmc passes over `bench.py --one-launch`, outside
+        # the timed region); if the profiler is unavailable the committed measurement is reported under its own key.
+        if world == 1 and not a.no_traffic:
+            nbytes, detail = measure_traffic(sched["name"].split("::")[-1].split("<")[0])
+            res["roofline"]["traffic"] = nbytes
+            res["roofline"]["traffic_detail"] = detail
+        if res["roofline"]["traffic"] is None:
+            tpath = os.path.join(ROOT, "profiles", "r02_fwd_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    res["roofline"]["traffic_profiled"] = {"hbm_bytes_per_launch": json.load(f)["hbm_bytes_per_launch"], "source": "profiles/r02_fwd_traffic.json"}
+        if world == 1 and not a.no_sweep:
+            res["sweep"] = sweep(be, dev, local_sync)
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(D, S, causal)
-        if a.sweep:
-            for d_, H_ in ((128, 16), (64, 32)):
-                for c_ in (False, True):
-                    for S_ in (512, 1024, 2048, 4096, 8192, 16384):
-                        B_ = 16384 // S_
-                        q_ = torch.randn(B_, S_, H_, d_, device=dev, dtype=torch.bfloat16)
-                        k_, v_ = torch.randn_like(q_), torch.randn_like(q_)
-                        f_ = lambda: be.fwd(q_, k_, v_, None, None, 0.0, d_ ** -0.5, c_, -1, -1, 0.0, False, None)
-                        _, m_ = time_kernel(f_, 20, 5, lambda: torch.cuda.synchronize(dev))
-                        o_, l_, _, _ = f_()
-                        g_ = torch.randn_like(o_)
-                        a_, b_, c2 = torch.empty_like(q_), torch.empty_like(k_), torch.empty_like(v_)
-                        h_ = lambda: be.bwd(g_, q_, k_, v_, o_, l_, a_, b_, c2, None, 0.0, d_ ** -0.5, c_, -1, -1, 0.0, False, None, None)
-                        _, mb_ = time_kernel(h_, 10, 3, lambda: torch.cuda.synchronize(dev))
-                        fl = fwd_flops(B_, H_, S_, d_, c_)
-                        print(f"sweep d={d_} causal={int(c_)} S={S_:6d} B={B_:3d}: fwd {fl / m_ / 1e9:7.1f} TF  bwd {2.5 * fl / mb_ / 1e9:7.1f} TF  "
-                              f"fwd+bwd {3.5 * fl / (m_ + mb_) / 1e9:7.1f} TF", file=sys.stderr, flush=True)
         print(json.dumps(res), flush=True)
     if dist_on:
         dist.barrier()

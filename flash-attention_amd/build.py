@@ -52,13 +52,15 @@ def _sources(names):
 
 def build_lib(force=False):
     hdrs = _sources(["fa_device.h", "fa_kernel_params.h", "fa_launch.h"]) + [os.path.join(ROOT, "include", "fa_gfx950.h")]
-    units = ["fa_fwd.hip", "fa_fwd_il.hip", "fa_bwd.hip", "fa_api.cpp"]
+    units = ["fa_fwd.hip", "fa_fwd_il.hip", "fa_fwd_w64.hip", "fa_bwd.hip", "fa_api.cpp"]
+    # per-file flags: fa_fwd_w64.hip places its row-sum adds by hand (see the note on asm helpers there)
+    extra = {"fa_fwd_w64.hip": ["-fno-slp-vectorize"]}
     objs, cmds = [], []
     for u in units:
         src = os.path.join(CSRC, u)
         obj = os.path.join(CSRC, os.path.splitext(u)[0] + ".o")
         if force or not _newer(obj, [src] + hdrs):
-            cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("FA_EXTRA_HIPCC_FLAGS", "").split() + ["-c", src, "-o", obj]
+            cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("FA_EXTRA_HIPCC_FLAGS", "").split() + extra.get(u, []) + ["-c", src, "-o", obj]
             if u.endswith(".cpp"):
                 cmd.insert(1, "-x")
                 cmd.insert(2, "hip")

@@ -123,23 +123,23 @@ int64_t splitkv_bytes(const FaFwdParams* a, int n_splits) {
   return (int64_t)n_splits * a->b * a->h * a->seqlen_q * (a->d + 1) * (int64_t)sizeof(float);
 }
 
-// Forward schedule code: 34 / 38 = software-pipelined kernel (fa_fwd_il.hip) with 4 / 8 waves per workgroup,
-// 4 / 8 = lock-step kernel with 4 / 8 waves, 16 = 8-wave ping-pong (fa_fwd.hip).  wl / wr = normalised window.
+// Forward schedule code: 64 = 64-rows-per-wave kernel (fa_fwd_w64.hip, 4 waves, 256-row blocks), 34 / 38 = software-pipelined
+// kernel (fa_fwd_il.hip) with 4 / 8 waves per workgroup, 4 / 8 = lock-step kernel with 4 / 8 waves, 16 = 8-wave ping-pong
+// (fa_fwd.hip).  wl / wr = normalised window.
 int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
-  // Schedule (measured on MI355X, tools/ab_bench.py; FA_FWD_NW overrides):
-  //   34 / 38 = software-pipelined kernel (fa_fwd_il.hip) with 4 / 8 waves per workgroup,
-  //   4 / 8   = lock-step kernel with 4 / 8 waves, 16 = 8-wave ping-pong (fa_fwd.hip).
-  // 8-wave pipelined workgroups (Q block in LDS, one workgroup per CU) win on long key loops (>= ~48 tiles per
-  // query block); 4-wave pipelined workgroups (Q fragments in registers, two workgroups per CU hide each other's
-  // prologue/epilogue) win on shorter loops and under causal masks at S <= 8k.  D = 64 has half the MFMA work
-  // per softmax element and prefers 4-wave workgroups throughout.
+  // Schedule (measured on MI355X, tools/ab_bench.py, profiles/r02_fwd_schedules.txt; FA_FWD_NW overrides):
+  //   head dim 128, long key loops (>= ~48 tiles of 64 keys per query block): the 64-rows-per-wave kernel -- its steady state
+  //   is 15-20 % faster than the pipelined kernels (1.19-1.26 vs 1.02-1.05 PFLOP/s at S = 16k), but with one 256-row
+  //   workgroup per CU nothing hides a block's prologue / epilogue, so shorter loops (config 3: 32 tiles on average) stay on
+  //   the 4-wave pipelined kernel (Q fragments in registers, two workgroups per CU hide each other's prologue / epilogue).
+  //   D = 64 has half the MFMA work per softmax element and prefers 4-wave pipelined workgroups throughout.
   int nw = fa::knobs().fwd_nw;
-  if (nw != 4 && nw != 8 && nw != 16 && nw != 34 && nw != 38) {
+  if (nw != 4 && nw != 8 && nw != 16 && nw != 34 && nw != 38 && nw != 64) {
     const bool right_bounded = (wr >= 0);
     const long avg_keys = right_bounded ? (a->seqlen_k + 1) / 2 : a->seqlen_k;
     const long span = (wl >= 0) ? std::min<long>(avg_keys, wl + (wr >= 0 ? wr : a->seqlen_k) + 256) : avg_keys;
     const long tiles = span / 64;
-    if (a->d == 128) nw = (tiles >= 48 && a->seqlen_q >= 512) ? 38 : (a->seqlen_q > 128 ? 34 : 4);
+    if (a->d == 128) nw = (tiles >= 48 && a->seqlen_q >= 512) ? 64 : (a->seqlen_q > 128 ? 34 : 4);
     else nw = (a->seqlen_q > 128) ? 34 : 4;
   }
   return nw;
@@ -148,6 +148,7 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
 // head dim 256 / split keys)
 int fwd_block_rows(const FaFwdParams* a, int nw, bool split) {
   if (a->d > 128 || split) return 128;
+  if (nw == 64) return 256;
   if (nw == 34 || nw == 38) return 32 * (nw - 30);  // (the lock-step fallback of a pipelined schedule keeps the wave count)
   return nw == 16 ? 256 : 32 * nw;
 }
@@ -249,9 +250,11 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   }
   // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
   const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && k.n_splits == 1;
+  const bool w64 = nw == 64 && plain && !a->block_table;
+  if (nw == 64 && !w64) nw = 8;   // features / paged KV: 8-wave lock-step kernel (same 256-row blocks)
   const bool il = (nw == 34 || nw == 38) && plain;
   if ((nw == 34 || nw == 38) && !il) nw -= 30;
-  const int bm = il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
+  const int bm = w64 ? 256 : il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
   k.nmb = (a->seqlen_q + bm - 1) / bm;
   if (varlen && !kvcache) {  // uneven packed batch: enumerate the non-empty query blocks, heaviest first
     const int64_t entries = varlen_list_entries(a, bm);
@@ -266,8 +269,9 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     }
   }
   fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb * k.n_splits, k.n_units, k.unit_size, k.unit_hpx);
-  int rc = il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, a->d, nw - 30, (hipStream_t)stream)
-                    : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
+  int rc = w64  ? fa::launch_fwd_w64(k, a->dtype == FA_DTYPE_BF16, a->d, (hipStream_t)stream)
+           : il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, a->d, nw - 30, (hipStream_t)stream)
+                : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
   if (rc == 0 && k.n_splits > 1) rc = fa::launch_splitkv_combine(k, a->dtype == FA_DTYPE_BF16, a->d, (hipStream_t)stream);
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
   if (rc == -3)

@@ -93,6 +93,8 @@ int launch_rotary(const RotaryK& p, int dtype_bf16, hipStream_t stream);
 int launch_splitkv_combine(const FwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_set_rng(uint64_t seed, uint64_t offset, uint64_t* dst, hipStream_t stream);
 int launch_fwd_il(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream);
+// 64-rows-per-wave forward (fa_fwd_w64.hip): 4 waves, 256 query rows per workgroup, one workgroup per CU.
+int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream);
 
 // Backward: delta = rowsum(dO*O) pre-pass, dK/dV kernel (loops over query blocks),
 // dQ kernel (loops over key blocks).  Same return convention.
