@@ -16,6 +16,8 @@ struct Knobs {
   int bwd_dq_nw;       // FA_BWD_DQ_NW: waves per dQ workgroup (4 or 8)
   int bwd_mode;        // FA_BWD_MODE: 0 = heuristic
   int lds_pad;         // FA_IL_LDS_PAD (occupancy experiments, FA_IL_EXPERIMENTS builds only)
+  int strict;          // FA_STRICT=1: the reference's numerics contract -- rescale on any growth of a row maximum (threshold 0) and
+                       // softmax_scale applied in fp32 to every score (never the bf16 pre-scaled Q of the 64-rows-per-wave kernel)
 };
 const Knobs& knobs();
 

@@ -114,13 +114,24 @@ std::vector<Tensor> mha_fwd(Tensor& q, const Tensor& k, const Tensor& v, OptTens
   CHECK_SHAPE(k, B, Sk, Hk, D);
   CHECK_SHAPE(v, B, Sk, Hk, D);
   c10::DeviceGuard guard(q.device());
-  const int64_t Dn = native_head_dim(D);
-  const Tensor qp = pad_d(q, Dn), kp = pad_d(k, Dn), vp = pad_d(v, Dn);
-  Tensor out;
   if (out_.has_value()) {
     TORCH_CHECK(out_->dtype() == q.dtype(), "Output must have the same dtype as inputs");
     CHECK_DEVICE(*out_); CHECK_LAST_CONTIG(*out_); CHECK_SHAPE(*out_, B, Sq, H, D);
   }
+  // One query row and grouped heads: the query heads of a KV group become the rows of one block, K/V are streamed once
+  // per KV head (seqlenq_ngroups_swapped, flash_api.cpp:429-437 and :531-535)
+  if (Sq == 1 && H > Hk && window_size_left < 0 && window_size_right < 0 && p_dropout == 0.0 && !alibi_slopes_.has_value() && Sk > 0) {
+    const int64_t ng = H / Hk;
+    Tensor q2 = q.reshape({B, Hk, ng, D}).transpose(1, 2);
+    OptTensor none;
+    std::vector<Tensor> r = mha_fwd(q2, k, v, none, none, 0.0, softmax_scale, false, -1, -1, softcap, false, std::nullopt);
+    Tensor o = r[0].transpose(1, 2).reshape({B, 1, H, D});
+    if (out_.has_value()) { out_->copy_(o); o = *out_; }
+    return {o, r[1].reshape({B, H, 1}), r[2], r[3]};
+  }
+  const int64_t Dn = native_head_dim(D);
+  const Tensor qp = pad_d(q, Dn), kp = pad_d(k, Dn), vp = pad_d(v, Dn);
+  Tensor out;
   out = (out_.has_value() && Dn == D) ? *out_ : at::empty({B, Sq, H, Dn}, q.options());
   Tensor lse = at::empty({B, H, Sq}, q.options().dtype(at::kFloat));
   Tensor rng_state = make_rng_state(q, p_dropout, B, H);
@@ -211,6 +222,25 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
     CHECK_SHAPE(*seqused_k, B);
   }
   c10::DeviceGuard guard(q.device());
+  // One query row per sequence and grouped heads (decode over a packed batch): the query heads of a KV group become the
+  // rows of one block (seqlenq_ngroups_swapped, flash_api.cpp:620-629 and :776-782); q is then ngroups rows per sequence
+  if (max_seqlen_q == 1 && total_q == B && H > Hk && window_size_left < 0 && window_size_right < 0 && p_dropout == 0.0 &&
+      !alibi_slopes_.has_value() && max_seqlen_k > 0 && total_k > 0) {
+    const int64_t ng = H / Hk;
+    Tensor q2 = q.reshape({B, Hk, ng, D}).transpose(1, 2).reshape({B * ng, Hk, D});
+    Tensor cu_q2 = at::arange(0, (B + 1) * ng, ng, cu_seqlens_q.options());
+    OptTensor none;
+    std::vector<Tensor> r = mha_varlen_fwd(q2, k, v, none, cu_q2, cu_seqlens_k, seqused_k, leftpad_k_, block_table_, none, ng, max_seqlen_k, 0.0,
+                                           softmax_scale, zero_tensors, false, -1, -1, softcap, false, std::nullopt, num_splits);
+    Tensor o = r[0].reshape({B, ng, Hk, D}).transpose(1, 2).reshape({B, H, D});
+    if (out_.has_value()) {
+      TORCH_CHECK(out_->dtype() == q.dtype(), "Output must have the same dtype as inputs");
+      CHECK_DEVICE(*out_); CHECK_LAST_CONTIG(*out_); CHECK_SHAPE(*out_, total_q, H, D);
+      out_->copy_(o); o = *out_;
+    }
+    // lse (Hk, B*ng) -> (H, B): head hk*ng + g of sequence b sits at [hk][b*ng + g]
+    return {o, r[1].reshape({Hk, B, ng}).permute({0, 2, 1}).reshape({H, B}), r[2], r[3]};
+  }
   const int64_t Dn = native_head_dim(D);
   const Tensor qp = pad_d(q, Dn), kp = pad_d(k, Dn), vp = pad_d(v, Dn);
   if (out_.has_value()) {

@@ -133,11 +133,23 @@ def fwd(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, windo
         raise RuntimeError("Number of heads in key/value must divide number of heads in query")
     if tuple(k.shape) != (B, Sk, Hk, D) or tuple(v.shape) != (B, Sk, Hk, D):
         raise RuntimeError("key/value shape mismatch")
-    Dn = _native_d(D)
-    qp, kp, vp = _pad_d(q, Dn), _pad_d(k, Dn), _pad_d(v, Dn)
     if out_ is not None:
         if out_.dtype != q.dtype or tuple(out_.shape) != (B, Sq, H, D) or out_.stride(-1) != 1:
             raise RuntimeError("out_ must have the same dtype/shape as q and a contiguous last dimension")
+    # One query row and grouped heads: the query heads of a KV group become the rows of one block, K/V are streamed once
+    # per KV head (seqlenq_ngroups_swapped, flash_api.cpp:429-437 and :531-535)
+    if (Sq == 1 and H > Hk and window_size_left < 0 and window_size_right < 0 and p_dropout == 0.0 and alibi_slopes_ is None
+            and Sk > 0):
+        ng = H // Hk
+        o2, l2, p2, r2 = fwd(q.reshape(B, Hk, ng, D).transpose(1, 2), k, v, None, None, 0.0, softmax_scale, False, -1, -1,
+                             softcap, False, None)
+        out = o2.transpose(1, 2).reshape(B, 1, H, D)
+        if out_ is not None:
+            out_.copy_(out)
+            out = out_
+        return [out, l2.reshape(B, H, 1), p2, r2]
+    Dn = _native_d(D)
+    qp, kp, vp = _pad_d(q, Dn), _pad_d(k, Dn), _pad_d(v, Dn)
     out = out_ if (out_ is not None and Dn == D) else torch.empty((B, Sq, H, Dn), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     rng_state = _new_rng_state(q.device, p_dropout, B, H)
@@ -218,6 +230,21 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
         raise RuntimeError("head_size must be a multiple of 8 and at most 256")
     if H % Hk != 0:
         raise RuntimeError("Number of heads in key/value must divide number of heads in query")
+    # One query row per sequence and grouped heads (decode over a packed batch): the query heads of a KV group become the
+    # rows of one block (seqlenq_ngroups_swapped, flash_api.cpp:620-629 and :776-782); q is then ngroups rows per sequence
+    if (max_seqlen_q == 1 and total_q == B and H > Hk and window_size_left < 0 and window_size_right < 0 and p_dropout == 0.0
+            and alibi_slopes_ is None and max_seqlen_k > 0 and total_k > 0):
+        ng = H // Hk
+        q2 = q.reshape(B, Hk, ng, D).transpose(1, 2).reshape(B * ng, Hk, D)
+        cu_q2 = torch.arange(0, (B + 1) * ng, ng, dtype=torch.int32, device=q.device)
+        o2, l2, p2, r2 = varlen_fwd(q2, k, v, None, cu_q2, cu_seqlens_k, seqused_k, leftpad_k_, block_table_, None, ng,
+                                    max_seqlen_k, 0.0, softmax_scale, zero_tensors, False, -1, -1, softcap, False, None, num_splits)
+        out = o2.reshape(B, ng, Hk, D).transpose(1, 2).reshape(B, H, D)
+        if out_ is not None:
+            out_.copy_(out)
+            out = out_
+        # lse (Hk, B*ng) -> (H, B): head hk*ng + g of sequence b sits at [hk][b*ng + g]
+        return [out, l2.reshape(Hk, B, ng).permute(0, 2, 1).reshape(H, B), p2, r2]
     if seqused_k is not None and (seqused_k.dtype != torch.int32 or seqused_k.numel() != B or not seqused_k.is_contiguous()):
         raise RuntimeError("seqused_k must be a contiguous int32 tensor of shape (batch_size)")
     Dn = _native_d(D)

@@ -132,3 +132,38 @@ def test_torch_compile_fullgraph_and_opcheck(fi):
     torch.library.opcheck(torch.ops.flash_attn_amd._flash_attn_forward.default,
                           (q.detach(), k.detach(), v.detach(), 0.0, 0.125, True, -1, -1, 0.0, None, False),
                           test_utils=("test_schema", "test_faketensor"))
+
+
+@pytest.mark.parametrize("varlen", [False, True])
+def test_single_query_row_grouped_heads_swap(varlen):
+    """seqlen_q == 1 with grouped heads takes the head-packing path of mha_fwd / mha_varlen_fwd (flash_api.cpp:431, :622):
+    results (out, LSE shapes and values) equal the per-head computation, through both binders."""
+    import flash_attn_2_cuda as ext
+    from flash_attn_amd import backend as be
+    from oracle import attention_oracle as orc
+    torch.manual_seed(5)
+    B, H, Hk, D = 3, 8, 2, 128
+    lens = [300, 77, 513]
+    q = torch.randn(B, 1, H, D, device="cuda", dtype=torch.bfloat16)
+    if not varlen:
+        Sk = 333
+        k = torch.randn(B, Sk, Hk, D, device="cuda", dtype=torch.bfloat16); v = torch.randn_like(k)
+        for mod in (be, ext):
+            out, lse = mod.fwd(q, k, v, None, None, 0.0, D ** -0.5, True, -1, -1, 0.0, False, None)[:2]
+            assert out.shape == (B, 1, H, D) and lse.shape == (B, H, 1)
+            ref, lse_ref = orc.attention_fwd(q, k, v, None, False)
+            assert float((out.float().cpu() - torch.from_numpy(ref)).abs().max()) < 2e-2
+            assert float((lse.cpu() - torch.from_numpy(lse_ref)).abs().max()) < 2e-3
+    else:
+        cu_k = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+        cu_q = torch.arange(0, B + 1, dtype=torch.int32, device="cuda")
+        k = torch.randn(sum(lens), Hk, D, device="cuda", dtype=torch.bfloat16); v = torch.randn_like(k)
+        for mod in (be, ext):
+            out, lse = mod.varlen_fwd(q[:, 0], k, v, None, cu_q, cu_k, None, None, None, None, 1, max(lens), 0.0, D ** -0.5, False, False,
+                                      -1, -1, 0.0, False, None)[:2]
+            assert out.shape == (B, H, D) and lse.shape == (H, B)
+            for b in range(B):
+                ks = k[None, int(cu_k[b]):int(cu_k[b + 1])]; vs = v[None, int(cu_k[b]):int(cu_k[b + 1])]
+                ref, lse_ref = orc.attention_fwd(q[b:b + 1], ks, vs, None, False)
+                assert float((out[b].float().cpu() - torch.from_numpy(ref)[0, 0]).abs().max()) < 2e-2
+                assert float((lse[:, b].cpu() - torch.from_numpy(lse_ref)[0, :, 0]).abs().max()) < 2e-3
