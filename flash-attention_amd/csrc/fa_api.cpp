@@ -50,6 +50,7 @@ const fa::Knobs* read_knobs() {
   k->bwd_dq_nw = env_int("FA_BWD_DQ_NW", 4);
   k->bwd_mode = env_int("FA_BWD_MODE", 0);
   k->lds_pad = env_int("FA_IL_LDS_PAD", 0);
+  k->w64_persist = env_int("FA_W64_PERSIST", 1);
   k->strict = env_int("FA_STRICT", 0);
   if (k->strict) k->rescale_thr = 0.f;
   return k;
@@ -141,7 +142,7 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
     const long avg_keys = right_bounded ? (a->seqlen_k + 1) / 2 : a->seqlen_k;
     const long span = (wl >= 0) ? std::min<long>(avg_keys, wl + (wr >= 0 ? wr : a->seqlen_k) + 256) : avg_keys;
     const long tiles = span / 64;
-    if (a->d == 128) nw = (tiles >= 48 && a->seqlen_q >= 512) ? (fa::knobs().strict ? 38 : 64) : (a->seqlen_q > 128 ? 34 : 4);
+    if (a->d == 128) nw = (tiles >= 32 && a->seqlen_q >= 512) ? (fa::knobs().strict ? (tiles >= 48 ? 38 : 34) : 64) : (a->seqlen_q > 128 ? 34 : 4);
     else nw = (a->seqlen_q > 128) ? 34 : 4;
   }
   return nw;

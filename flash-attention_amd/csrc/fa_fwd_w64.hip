@@ -127,47 +127,85 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   constexpr float kLn2 = 0.6931471805599453f;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char FA_LDS* lds = (char FA_LDS*)smem;  // K0 | K1 | V0 | V1 | Q (BM rows, K-style swizzle)
-  constexpr int Q_OFF = 4 * TILE_BYTES;
+  // LDS: K0 | K1 | V0 | V1 (the O tile of the epilogue is staged over them, 256 padded rows) | Q block (K-style swizzle; each
+  // wave loads and reads only its own 64 rows, so the NEXT block's Q can be prefetched here as soon as this block's
+  // fragments sit in their registers)
+  char FA_LDS* lds = (char FA_LDS*)smem;
+  constexpr int STAGE_BYTES = BM * (ROW_BYTES + 16);
+  constexpr int Q_OFF = (4 * TILE_BYTES > STAGE_BYTES ? 4 * TILE_BYTES : STAGE_BYTES + 1023) / 1024 * 1024;
 
-#if FA_W64_ABL & 256
-  const long long abl_tk = clock64();
-#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, qi = lane & 31;
 
-  int b, h, m_block;
-  if (p.work_list) {  // varlen: non-empty blocks only, heaviest first (fa_varlen_schedule_kernel)
-    if (!work_list_item(p.work_list, blockIdx.x, p.h, p.h_k, b, h, m_block)) return;
-  } else {
-    const int w = xcd_interleave(blockIdx.x, p.n_units, p.unit_size, p.unit_hpx);
-    if (w < 0) return;
-    const int bh = w / p.nmb;
-    const int mbr = w - bh * p.nmb;
-    m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
-    b = bh / p.h;
-    h = bh - b * p.h;
-  }
+  const int d_row = lane / CPR, d_pc = lane % CPR;   // row inside a 1-KiB DMA piece, physical 16-byte chunk
+  constexpr int RPD = 1024 / ROW_BYTES;              // tile rows per DMA instruction
+
+  // ---- persistent workgroup: blocks vb = blockIdx.x, + gridDim.x, ...  (grid = one workgroup per CU when the dense grid is
+  // larger; a grid as large as the block count degenerates to one block per workgroup).  vb -> (batch, head, query block) is
+  // the XCD-aware, heavy-first order of xcd_interleave; under a right-bounded mask every other round walks the blocks of its
+  // units lightest-first instead, so that a CU's rounds add up to the same work (the hardware dispatcher balanced this
+  // dynamically; a static walk has to do it by construction).
+  struct Blk { int b, h, m_block, sq, sk; int64_t q_row0, k_row0, q_boff, k_boff, v_boff, o_boff; };
+  const int n_virtual = p.persist_total > 0 ? p.persist_total : (int)gridDim.x;
+  const bool snake = p.persist_total > 0 && p.wr >= 0 && p.unit_size > 1 && ((int)(gridDim.x / 8) % p.unit_size) == 0;
+  auto decode = [&](int vb, int round, Blk& k) __attribute__((always_inline)) -> bool {
+    if (vb >= n_virtual) return false;
+    if (p.work_list) {  // varlen: non-empty blocks only, heaviest first (fa_varlen_schedule_kernel)
+      if (!work_list_item(p.work_list, vb, p.h, p.h_k, k.b, k.h, k.m_block)) return false;
+    } else {
+      int bid = vb;
+      if (snake && (round & 1)) {   // same unit, mirrored item
+        const int slot = vb / 8, item = slot % p.unit_size;
+        bid = vb + 8 * (p.unit_size - 1 - 2 * item);
+      }
+      const int w = xcd_interleave(bid, p.n_units, p.unit_size, p.unit_hpx);
+      if (w < 0) return false;
+      const int bh = w / p.nmb;
+      const int mbr = w - bh * p.nmb;
+      k.m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
+      k.b = bh / p.h;
+      k.h = bh - k.b * p.h;
+    }
+    k.sq = p.sq; k.sk = p.sk; k.q_row0 = 0; k.k_row0 = 0;
+    const int bkv = p.kv_batch_idx ? p.kv_batch_idx[k.b] : k.b;
+    k.q_boff = (int64_t)k.b * p.q_bs; k.k_boff = (int64_t)bkv * p.k_bs; k.v_boff = (int64_t)bkv * p.v_bs; k.o_boff = (int64_t)k.b * p.o_bs;
+    if (p.cu_q) { const int c0 = p.cu_q[k.b]; k.sq = p.cu_q[k.b + 1] - c0; k.q_row0 = c0; k.q_boff = 0; k.o_boff = 0; }
+    if (p.cu_k) { const int c0 = p.cu_k[k.b]; k.sk = p.cu_k[k.b + 1] - c0; k.k_row0 = c0; k.k_boff = 0; k.v_boff = 0; }
+    if (p.seqused_k) k.sk = min(p.seqused_k[k.b] + p.seqused_add, p.sk);
+    if (p.leftpad_k) {
+      const int lp = p.leftpad_k[k.b];
+      k.sk = max(0, k.sk - lp);
+      k.k_row0 += lp;
+    }
+    return k.m_block * BM < k.sq;
+  };
+  // this wave's 64 rows of a block's Q -> its rows of the LDS Q region (coalesced DMA, K-style swizzle on the source chunk)
+  auto dma_q = [&](const Blk& k) __attribute__((always_inline)) {
+    const E* qsrc = (const E*)p.q + k.q_boff + k.q_row0 * p.q_rs + (int64_t)k.h * p.q_hs;
+    constexpr int QDMA = (BM * ROW_BYTES) / 1024 / NW;
+#pragma unroll
+    for (int i = 0; i < QDMA; ++i) {
+      const int row = (wave * QDMA + i) * RPD + d_row;
+      const int grow = min(k.m_block * BM + row, k.sq - 1);
+      const int c = d_pc ^ k_swz_w<D>(row);
+      lds_dma_16B(qsrc + (int64_t)grow * p.q_rs + c * 8, lds + Q_OFF + (wave * QDMA + i) * 1024);
+    }
+  };
+  int q_in_lds = -1;   // virtual block whose Q this wave has prefetched into the LDS Q region
+
+  for (int vb = blockIdx.x, round = 0; vb < n_virtual; vb += gridDim.x, ++round) {
+#if FA_W64_ABL & 256
+  const long long abl_tk = clock64();
+#endif
+  Blk blk;
+  if (!decode(vb, round, blk)) continue;   // (uniform over the workgroup: no barrier is skipped by part of it)
+  const int b = blk.b, h = blk.h, m_block = blk.m_block, sq = blk.sq, sk = blk.sk;
   const int hk = h / p.hk_ratio;
-
-  int sq = p.sq, sk = p.sk;
-  int64_t q_row0 = 0, k_row0 = 0;
-  const int bkv = p.kv_batch_idx ? p.kv_batch_idx[b] : b;
-  int64_t q_boff = (int64_t)b * p.q_bs, k_boff = (int64_t)bkv * p.k_bs, v_boff = (int64_t)bkv * p.v_bs, o_boff = (int64_t)b * p.o_bs;
-  if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; o_boff = 0; }
-  if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
-  if (p.seqused_k) sk = min(p.seqused_k[b] + p.seqused_add, p.sk);
-  if (p.leftpad_k) {
-    const int lp = p.leftpad_k[b];
-    sk = max(0, sk - lp);
-    k_row0 += lp;
-  }
+  const int64_t q_row0 = blk.q_row0, k_row0 = blk.k_row0, q_boff = blk.q_boff, k_boff = blk.k_boff, v_boff = blk.v_boff, o_boff = blk.o_boff;
   const int m0 = m_block * BM;
-  if (m0 >= sq) return;
 
-  const E* __restrict__ qp = (const E*)p.q + q_boff + q_row0 * p.q_rs + (int64_t)h * p.q_hs;
   const E* __restrict__ kp = (const E*)p.k + k_boff + k_row0 * p.k_rs + (int64_t)hk * p.k_hs;
   const E* __restrict__ vp = (const E*)p.v + v_boff + k_row0 * p.v_rs + (int64_t)hk * p.v_hs;
   E* __restrict__ op = (E*)p.o + o_boff + q_row0 * p.o_rs + (int64_t)h * p.o_hs;
@@ -213,10 +251,8 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // are applied to the per-lane SOURCE chunk.  A wave issues its DPW pieces of a tile from ONE statement: M0 = LDS base
   // of piece 0, pieces 1.. by the instruction offset (added to the LDS AND the memory address, hence the -1024*i folded
   // into each piece's lane offset).  Rows past the last key are clamped to the last key (finite data, masked to -inf).
-  constexpr int RPD = 1024 / ROW_BYTES;            // tile rows per DMA instruction
   constexpr int NDMA = TILE_BYTES / 1024;          // DMA instructions per tile
   constexpr int DPW = NDMA / NW;                   // per wave: 4 (D = 128) or 2 (D = 64)
-  const int d_row = lane / CPR, d_pc = lane % CPR;
   unsigned koff_l[DPW], voff_l[DPW];
 #pragma unroll
   for (int i = 0; i < DPW; ++i) {
@@ -277,23 +313,18 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     dma_pieces(ISV ? v_srd : k_srd, vo, lds_dst);
   };
 
-  // ---- Q block -> LDS (coalesced DMA), then this wave's B-operand fragments, pre-multiplied by softmax_scale*log2(e)
-  // and rounded once to the input dtype, into accumulator registers for the whole block.
-  {
-    const int64_t rs = p.q_rs;
-    constexpr int QDMA = (BM * ROW_BYTES) / 1024 / NW;
-#pragma unroll
-    for (int i = 0; i < QDMA; ++i) {
-      const int row = (wave * QDMA + i) * RPD + d_row;
-      const int grow = min(m0 + row, sq - 1);
-      const int c = d_pc ^ k_swz_w<D>(row);
-      lds_dma_16B(qp + (int64_t)grow * rs + c * 8, lds + Q_OFF + (wave * QDMA + i) * 1024);
-    }
-  }
-  if (n_tiles > 0) dma_tile(ICw<0>{}, 0, 0);
-  lds_dma_wait_all();
+  // ---- prologue.  The previous block's epilogue staged its O tile over the K/V buffers: nobody may refill them before every
+  // wave is through with it.  Q: already prefetched by this wave during the previous block (its own rows, so its own
+  // vmcnt wait at the tile barriers made them visible), else loaded now.  K_0 rides under the Q conversion.
   __syncthreads();
-
+  if (q_in_lds != vb) dma_q(blk);
+  if (n_tiles > 0) dma_tile(ICw<0>{}, 0, 0);
+  if (q_in_lds != vb) {
+    if (n_tiles > 0) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else lds_dma_wait_all();
+  }
+  // this wave's B-operand fragments of Q, pre-multiplied by softmax_scale*log2(e) and rounded once to the input dtype, into
+  // accumulator registers for the whole block
   {
     const float cq = p.scale_log2;
     auto load_q = [&](auto qbc, auto ksc) __attribute__((always_inline)) {
@@ -311,6 +342,18 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     };
     load_q_all(ICw<0>{});
     load_q_all(ICw<1>{});
+  }
+  lds_dma_wait_all();   // K_0 (issued before the conversion)
+  __syncthreads();
+  {  // next block's Q rows of this wave -> LDS, under this block's tile loop (its first tile barrier waits for them)
+    Blk nxt;
+    q_in_lds = -1;
+    if (p.persist_total > 0 && decode(vb + (int)gridDim.x, round + 1, nxt)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the Q region have returned
+      dma_q(nxt);
+      if (n_tiles == 0) lds_dma_wait_all();                // no tile barrier will wait for it
+      q_in_lds = vb + (int)gridDim.x;
+    }
   }
 
   // per-lane LDS read bases: K fragment of k-step ks at ka[ks] (+ buffer / half offsets as immediates), V d-block db at va[db]
@@ -625,6 +668,10 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 
   // iteration u (0..n_tiles): steps 2u-1 and 2u read K_u (kbuf[u&1]) and V_{u-1} (vbuf[(u-1)&1]); K_{u+1} and V_u are
   // DMA'd during the iteration into the buffers it does not read.  Head / steady-state / tail split as in fa_fwd_il.hip.
+  // (A wave's two drain steps after its last scored step -- {exp2 + P.V}, {P.V} -- stay on the generic path.  Tried and
+  // measured slower or wrong: running them as MASKED steady-state steps, whose discarded score chains cost more than the
+  // generic step saves (config 3: 949 -> 858 TFLOP/s); compile-time variants of the steady-state step without the score
+  // chain, which were right one at a time and wrong -- rows without any visible key -- when both were instantiated.)
   int uf_lo = 1, uf_hi = 0;
   if (wave_valid && n_tiles > 0) {
     const int a_lo = max(0, (w_kmin - key_base) >> 5);
@@ -671,8 +718,8 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       const unsigned toff_v = (unsigned)(n_min + uu) * (unsigned)(BN * 2) * (unsigned)p.v_rs;
       fast_step(parc, ICw<0>{}, maskc, 2 * uu, sA, sB, pfA, pfB, k_srd, koff_l, toff_k, __builtin_amdgcn_readfirstlane((unsigned)((par ^ 1) * TILE_BYTES) + wave_dst));
       fast_step(parc, ICw<1>{}, maskc, 2 * uu + 1, sB, sA, pfB, pfA, v_srd, voff_l, toff_v, __builtin_amdgcn_readfirstlane((unsigned)((2 + par) * TILE_BYTES) + wave_dst));
-      have_prev = true;  // P_{2u} is packed and S_{2u+1} is pending (what the tail's generic steps expect)
-      have_cur = true;
+      have_prev = step_active(2 * uu);      // P_{2u} is packed and S_{2u+1} is pending -- what the generic steps that follow
+      have_cur = step_active(2 * uu + 1);   // expect; past the wave's last scored step they are 0 / -inf and simply dropped
       iter_tail();
     };
     int um_lo = uf_lo, um_hi = uf_hi;
@@ -700,9 +747,10 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   const long long abl_t1 = clock64();
   const float abl_ticks = (float)(abl_t1 - abl_t0) / (float)(n_tiles > 0 ? n_tiles * 16 * DB : 1);
 #endif
-  if (!wave_valid) return;
+  if (wave_valid) {
   mfma_drain_acc();
-  // O tile through LDS (the K/V buffers and the Q block are free after the last barrier): whole-row stores
+  // O tile through LDS (the K/V buffers are free after the last tile barrier; the Q region may already hold the next block's
+  // rows and is not touched): whole-row stores
   static_for<QB>([&](auto qbc) __attribute__((always_inline)) {
     constexpr int qb = decltype(qbc)::value;
     f32x16 o_v[DB];
@@ -729,17 +777,32 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #endif
     }
   });
+  }  // wave_valid
+  }  // persistent block loop
 }
 
 template <typename E, int D>
 static int launch_fwd_w64_t(const FwdK& p, hipStream_t stream) {
-  constexpr int smem = 4 * 64 * D * 2 + 256 * D * 2 + 4096;  // K/V double buffers + Q block (+ row padding of the staged O epilogue)
+  constexpr int STAGE = 256 * (D * 2 + 16);
+  constexpr int smem = ((4 * 64 * D * 2 > STAGE ? 4 * 64 * D * 2 : STAGE + 1023) / 1024 * 1024) + 256 * D * 2;  // K/V buffers | O staging, then the Q block
   auto kern = fa_fwd_w64_kernel<E, D>;
   static std::atomic<unsigned long long> attr_mask{0};  // the kernel addresses LDS by byte offset: the dynamic segment must start at 0
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
   const long long total = p.work_list ? (long long)p.work_bound * p.h : units_grid(p.n_units, p.unit_size);
   if (total <= 0) return 0;
-  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), smem, stream, p);
+  // dense grids larger than the chip: one persistent workgroup per CU walks the blocks (multiple of 8 keeps vb % 8 = XCD);
+  // work lists keep one workgroup per block (their order is already heavy-first, the dispatcher balances the tail)
+  FwdK pp = p;
+  long long grid = total;
+  const int cus = device_cu_count();
+  // (under a right-bounded mask the static walk is balanced by mirroring every other round inside its units: needs rounds
+  // made of whole units)
+  const bool balanced = p.wr < 0 || (p.unit_size > 1 && (cus / 8) % p.unit_size == 0);
+  if (!p.work_list && cus >= 8 && total > cus && balanced && knobs().w64_persist != 0) {
+    grid = cus / 8 * 8;
+    pp.persist_total = (int)total;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, stream, pp);
   if (hipGetLastError() != hipSuccess) return -1;
   LastSchedule& ls = last_schedule();
   ls.fwd_kernel = 3; ls.fwd_nw = 4; ls.fwd_feat = 0; ls.fwd_splits = 1; ls.fwd_list = p.work_list != nullptr; ls.d = D;

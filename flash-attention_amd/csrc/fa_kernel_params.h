@@ -37,6 +37,7 @@ struct FwdK {
   float scale_log2;          // softmax_scale * log2(e)
   float softcap;             // 0 = off
   float rescale_thr;         // O rescale deferred until a row max grows by more than this (log2 units)
+  int32_t persist_total;     // fa_fwd_w64: > 0 => persistent launch, blocks 0 .. persist_total-1 are walked by gridDim.x workgroups
   int32_t work_bound;        // entries the list can hold (grid = work_bound * h)
   const int2* work_list;     // varlen: {count,0}, then {batch, query block} pairs, heaviest first (nullptr => dense grid)
   // split-KV (decode): n_splits > 1 => workgroup (.., split) scans key tiles [split*split_tiles, (split+1)*split_tiles) and

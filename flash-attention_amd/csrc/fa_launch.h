@@ -16,6 +16,7 @@ struct Knobs {
   int bwd_dq_nw;       // FA_BWD_DQ_NW: waves per dQ workgroup (4 or 8)
   int bwd_mode;        // FA_BWD_MODE: 0 = heuristic
   int lds_pad;         // FA_IL_LDS_PAD (occupancy experiments, FA_IL_EXPERIMENTS builds only)
+  int w64_persist;     // FA_W64_PERSIST: 0 = one workgroup per block (no persistent walk) in the 64-rows-per-wave forward
   int strict;          // FA_STRICT=1: the reference's numerics contract -- rescale on any growth of a row maximum (threshold 0) and
                        // softmax_scale applied in fp32 to every score (never the bf16 pre-scaled Q of the 64-rows-per-wave kernel)
 };
@@ -33,6 +34,19 @@ struct LastSchedule {
   char name[96];
 };
 LastSchedule& last_schedule();
+
+// CUs of the current device (cached per device id)
+inline int device_cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int v = dev < 64 ? cache[dev].load(std::memory_order_relaxed) : 0;
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (dev < 64) cache[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is per device: `mask` (one per kernel instantiation) records the devices
 // it has been set on.  Concurrent first calls may both set it (idempotent).  Also checks that the kernel has no static

@@ -17,9 +17,14 @@ def t_ms(fn, reps=10):
 
 
 def main():
-    variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["4", "8", "16"]
+    variants = sys.argv[1].split(",") if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else ["4", "8", "16"]
+    if "--sweep-shapes" in sys.argv:
+        shapes_override = [(16384 // S, S, 16, 128, c) for c in (False, True) for S in (512, 1024, 2048, 4096, 8192)] + [(8, 2048, 32, 128, True), (4, 4096, 32, 128, True), (2, 8192, 32, 128, True)]
+    else:
+        shapes_override = None
     shapes = [(4, 4096, 32, 128, True), (4, 4096, 32, 128, False), (1, 16384, 16, 128, True), (1, 16384, 16, 128, False),
               (8, 2048, 16, 64, False), (4, 4096, 32, 64, True), (16, 1024, 16, 128, True), (2, 8192, 32, 128, True)]
+    if shapes_override: shapes = shapes_override
     torch.manual_seed(0)
     for (B, S, H, D, causal) in shapes:
         q = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16); k = torch.randn_like(q); v = torch.randn_like(q)
