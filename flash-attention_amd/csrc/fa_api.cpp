@@ -98,7 +98,6 @@ template <typename K> void fill_dropout(K& k, float p_dropout, const uint64_t* r
     k.rng = rng_state;
     const float p_keep = 1.0f - p_dropout;  // single precision throughout, as csrc/flash_attn_ck/mha_fwd.cpp derives its uint8 threshold
     k.drop_thr8 = (uint32_t)std::floor(p_keep * 255.0f);
-    k.drop_groups = (seqlen_k + 3) / 4;
     k.rp_keep = 1.f / (1.f - p_dropout);
   }
 }

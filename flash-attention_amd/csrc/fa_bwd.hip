@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
     const float slope = use_alibi ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
     const bool drop = F_DROP && (FEAT != FEAT_ALL || p.rng != nullptr);
     // stream key of this (batch, query head) plus this lane's key group; rows are added per 4-query group below
-    const uint32_t drop_col = drop ? (drop_bh_key(p.rng, b * p.h + item_head(it)) + (uint32_t)(my_key >> 2)) : 0u;
+    const uint32_t drop_key = drop ? drop_bh_key(p.rng, b * p.h + item_head(it)) : 0u;
     constexpr int QB_OFF = OFF_Q + cur * QT_BYTES, DOB_OFF = OFF_DO + cur * QT_BYTES;
 
 #pragma unroll
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
         // group (4 bytes = those 4 keys) and the quad exchanges words, so each lane reads its key's byte of every row.
         uint32_t hq = 0u;
         if constexpr (F_DROP) {
-          if (drop) hq = hash32(drop_col + (uint32_t)(q0 + 8 * g + 4 * hi + (ki & 3)) * (uint32_t)p.drop_groups);
+          if (drop) hq = drop_bytes(drop_key, q0 + 8 * g + 4 * hi + (ki & 3), my_key >> 2);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   const bool use_cap = F_CAP && (FEAT != FEAT_ALL || p.softcap > 0.f);
   const float slope = use_alibi ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
   const bool drop = F_DROP && (FEAT != FEAT_ALL || p.rng != nullptr);
-  const uint32_t drop_row = drop ? (drop_bh_key(p.rng, b * p.h + h) + (uint32_t)my_row * (uint32_t)p.drop_groups) : 0u;
+  const uint32_t drop_key = drop ? drop_bh_key(p.rng, b * p.h + h) : 0u;
 
   // Q and dO fragments (B operands), LSE and delta (lane-local scalars).  The fragments are staged through the (still
   // idle) LDS by coalesced DMA -- each wave its own 32 rows -- instead of 16-byte loads at row stride.
@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
           if constexpr (F_DROP) {
             if (drop) {  // acc rows 4g..4g+3 are keys key0..key0+3: one hash per group, byte r&3
               const int key0 = kv0 + 32 * kb + 8 * (r >> 2) + 4 * hi;
-              const uint32_t bytes = hash32(drop_row + (uint32_t)(key0 >> 2));
+              const uint32_t bytes = drop_bytes(drop_key, my_row, key0 >> 2);
               dpe = (((bytes >> (8 * (r & 3))) & 0xffu) <= p.drop_thr8) ? dp[r] * p.rp_keep : 0.f;
             }
           }

@@ -191,10 +191,14 @@ FA_DEVINL bool work_list_item(const int2* __restrict__ list, int bid, int h, int
 }
 
 // ---- dropout random stream --------------------------------------------------------------------------
-// Counter-based: the random byte of element (batch b, query head h, query i, key j) is a pure function of
-// (seed, offset, b, h, i, j), so the forward and both backward kernels regenerate the same mask in their own
-// tilings (the reference does the same with Philox keyed on its tile coordinates, dropout.h:31-90).  One
-// 32-bit integer hash (two multiply/xorshift rounds) yields the 4 bytes of keys 4g .. 4g+3 of one query row.
+// Counter-based and keyed: the 4 random bytes of keys 4g .. 4g+3 of (batch b, query head h, query row i) are word 0 of
+// Philox2x32-7 with counter (g, i) under the 32-bit key K(seed, offset) ^ (b*H + h) * odd.  For a fixed key the block
+// cipher is a bijection of the 64-bit counter, and the key is injective in (b*H + h), so no (batch, head) stream can be a
+// shifted copy of another one (the first version -- one multiply/xorshift hash over an ADDITIVE 32-bit counter, streams
+// distinguished only by a start offset -- overlapped by construction once B*H*Sq*Sk/4 approached 2^32).  A pure function of
+// the element, so the forward and both backward kernels regenerate the same mask in their own tilings; the reference does
+// the same with Philox4x32-7 keyed on its tile coordinates (csrc/flash_attn/src/dropout.h:31-90, philox.cuh).
+// Cost: 7 x (v_mul_hi, v_mul_lo, 3-input xor) = 21 VALU per 4 elements.
 FA_DEVINL uint32_t hash32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
@@ -205,16 +209,25 @@ FA_DEVINL uint32_t drop_bh_key(const uint64_t* rng, int bh) {
   k = hash32(k ^ (uint32_t)(seed >> 32));
   k = hash32(k ^ (uint32_t)off);
   k = hash32(k ^ (uint32_t)(off >> 32));
-  return hash32(k ^ ((uint32_t)bh * 0x9E3779B1u));
+  return k ^ ((uint32_t)bh * 0x9E3779B1u);   // odd multiplier: distinct (batch, head) -> distinct key
+}
+// bytes of keys 4g..4g+3 (byte c <-> key 4g+c) of query row i
+FA_DEVINL uint32_t drop_bytes(uint32_t bh_key, int i, int g) {
+  constexpr uint32_t M = 0xD256D193u, W = 0x9E3779B9u;   // Philox2x32 multiplier / Weyl key increment (Random123)
+  uint32_t c0 = (uint32_t)g, c1 = (uint32_t)i, key = bh_key;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const uint32_t hi = __umulhi(M, c0), lo = M * c0;
+    c0 = hi ^ key ^ c1;
+    c1 = lo;
+    key += W;
+  }
+  return c0;
 }
 // value held by lane j of the caller's quad (4 adjacent lanes); j must fold to a constant
 template <int J> FA_DEVINL uint32_t quad_bcast_c(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, J * 0x55, 0xf, 0xf, true); }
 FA_DEVINL uint32_t quad_bcast(uint32_t x, int j) {
   return j == 0 ? quad_bcast_c<0>(x) : j == 1 ? quad_bcast_c<1>(x) : j == 2 ? quad_bcast_c<2>(x) : quad_bcast_c<3>(x);
-}
-// bytes of keys 4g..4g+3 (byte c <-> key 4g+c) of query row i; groups = key groups per row in the stream index
-FA_DEVINL uint32_t drop_bytes(uint32_t bh_key, int i, int groups, int g) {
-  return hash32(bh_key + (uint32_t)i * (uint32_t)groups + (uint32_t)g);
 }
 
 }  // namespace fa

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   const float slope = use_alibi ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
   // dropout: per-(batch, head) stream key and this lane's row base
   const bool drop = F_DROP && (FEAT != FEAT_ALL || p.rng != nullptr);
-  const uint32_t drop_row = drop ? (drop_bh_key(p.rng, b * p.h + h) + (uint32_t)my_row * (uint32_t)p.drop_groups) : 0u;
+  const uint32_t drop_key = drop ? drop_bh_key(p.rng, b * p.h + h) : 0u;
   uint8_t* rv_row = (drop && p.randval) ? (p.randval + (int64_t)b * p.rv_bs + (int64_t)h * p.rv_hs + (q_row0 + my_row) * p.rv_rs) : nullptr;
   const float thr = p.rescale_thr;
 
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const int key0 = kv0 + 32 * kb + 8 * g4 + 4 * hi;  // acc rows 4*g4 .. 4*g4+3 are keys key0 .. key0+3
-            const uint32_t bytes = hash32(drop_row + (uint32_t)(key0 >> 2));
+            const uint32_t bytes = drop_bytes(drop_key, my_row, key0 >> 2);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const uint32_t byte = (bytes >> (8 * c)) & 0xffu;

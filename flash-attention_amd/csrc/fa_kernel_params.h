@@ -45,12 +45,11 @@ struct FwdK {
   int32_t n_splits, split_tiles;
   float* o_accum;            // (n_splits, b, h, sq, d) fp32
   float* lse_accum;          // (n_splits, b, h, sq) fp32, -inf for an empty partial
-  // dropout (rng == nullptr => off): element (b, h, i, j) is kept iff its random byte <= drop_thr8 (fa_device.h drop_bytes)
+  // dropout (rng == nullptr => off): element (b, h, i, j) is kept iff its random byte <= drop_thr8 (fa_device.h drop_bytes: Philox2x32-7 keyed per (batch, head))
   const uint64_t* rng;       // device {seed, offset}
   uint8_t* randval;          // optional: random bytes out
   int64_t rv_bs, rv_hs, rv_rs;
   uint32_t drop_thr8;        // floor(255 * (1 - p_dropout))
-  int32_t drop_groups;       // key groups (of 4) per query row in the stream index
   float rp_keep;             // 1 / (1 - p_dropout)
 };
 
@@ -92,7 +91,6 @@ struct BwdK {
   const int2* k_list;
   const uint64_t* rng;       // dropout, as in FwdK
   uint32_t drop_thr8;
-  int32_t drop_groups;
   float rp_keep;
 };
 

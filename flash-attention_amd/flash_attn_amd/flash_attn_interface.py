@@ -141,6 +141,49 @@ _flash_attn_backward = _register("_flash_attn_backward", _bwd_impl, _bwd_fake, (
 _flash_attn_varlen_backward = _register("_flash_attn_varlen_backward", _varlen_bwd_impl, _varlen_bwd_fake, ("dq", "dk", "dv"))
 
 
+# An exported program (torch.export) holds the raw ops, not the autograd.Function wrappers below; with an autograd formula on
+# the two forward ops such a graph can still be differentiated (the reference registers one for its FA3 ops, the precedent
+# hopper/test_torch_compile_and_export.py exercises; its FA2 ops have none).  Inside the Function wrappers the ops run
+# without grad mode, so this never double-counts.
+def _fwd_setup(ctx, inputs, output):
+    q, k, v, dropout_p, softmax_scale, causal, wl, wr, softcap, alibi_slopes, _ = inputs
+    out, lse, _, rng_state = output
+    ctx.save_for_backward(q, k, v, out, lse, rng_state, *([alibi_slopes] if alibi_slopes is not None else []))
+    ctx.args = (dropout_p, softmax_scale, causal, wl, wr, softcap, alibi_slopes is not None)
+
+
+def _fwd_backward(ctx, dout, dlse, dp, drng):
+    q, k, v, out, lse, rng_state, *rest = ctx.saved_tensors
+    dropout_p, softmax_scale, causal, wl, wr, softcap, has_alibi = ctx.args
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _flash_attn_backward(dout.contiguous(), q, k, v, out, lse, dq, dk, dv, dropout_p, softmax_scale, causal, wl, wr, softcap,
+                         rest[0] if has_alibi else None, False, rng_state)
+    return dq, dk, dv, None, None, None, None, None, None, None, None
+
+
+def _varlen_fwd_setup(ctx, inputs, output):
+    (q, k, v, cu_q, cu_k, max_q, max_k, dropout_p, softmax_scale, causal, wl, wr, softcap, alibi_slopes, _, block_table,
+     leftpad_k, seqused_k, zero_tensors) = inputs
+    if block_table is not None or leftpad_k is not None or seqused_k is not None:
+        raise RuntimeError("flash_attn_amd::_flash_attn_varlen_forward: no backward with block_table / leftpad_k / seqused_k")
+    out, lse, _, rng_state = output
+    ctx.save_for_backward(q, k, v, out, lse, rng_state, cu_q, cu_k, *([alibi_slopes] if alibi_slopes is not None else []))
+    ctx.args = (max_q, max_k, dropout_p, softmax_scale, causal, wl, wr, softcap, alibi_slopes is not None)
+
+
+def _varlen_fwd_backward(ctx, dout, dlse, dp, drng):
+    q, k, v, out, lse, rng_state, cu_q, cu_k, *rest = ctx.saved_tensors
+    max_q, max_k, dropout_p, softmax_scale, causal, wl, wr, softcap, has_alibi = ctx.args
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _flash_attn_varlen_backward(dout.contiguous(), q, k, v, out, lse, dq, dk, dv, cu_q, cu_k, max_q, max_k, dropout_p, softmax_scale,
+                                causal, wl, wr, softcap, rest[0] if has_alibi else None, False, rng_state)
+    return (dq, dk, dv) + (None,) * 16
+
+
+torch.library.register_autograd("flash_attn_amd::_flash_attn_forward", _fwd_backward, setup_context=_fwd_setup)
+torch.library.register_autograd("flash_attn_amd::_flash_attn_varlen_forward", _varlen_fwd_backward, setup_context=_varlen_fwd_setup)
+
+
 class _AttnFn(torch.autograd.Function):
     """Fixed-length attention with separate q, k, v (reference FlashAttnFunc :828-911)."""
 

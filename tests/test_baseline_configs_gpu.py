@@ -241,7 +241,8 @@ def test_sampled_block_against_fp64_oracle_config3(be):
     q = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16)
     k, v = torch.randn_like(q), torch.randn_like(q)
     out, lse, _, _ = be.fwd(q, k, v, None, None, 0.0, D ** -0.5, True, -1, -1, 0.0, False, None)
+    sched = be.last_schedule()
     for (b, h) in ((0, 0), (3, 31), (1, 17)):
         ref, lse_ref = orc.attention_fwd(q[b:b + 1, :, h:h + 1], k[b:b + 1, :, h:h + 1], v[b:b + 1, :, h:h + 1], None, True)
         assert max_abs(out[b:b + 1, :, h:h + 1].float(), torch.from_numpy(ref).cuda()) < 2e-2
-        assert max_abs(lse[b, h], torch.from_numpy(lse_ref[0, 0]).cuda().float()) < 2e-3
+        assert max_abs(lse[b, h], torch.from_numpy(lse_ref[0, 0]).cuda().float()) < lse_tolerance(sched, q.dtype)

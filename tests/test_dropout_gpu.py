@@ -123,6 +123,34 @@ def test_dropout_random_bytes_are_uniform_and_uncorrelated(be):
         assert abs((a * b).mean()) < 5 / math.sqrt(a.size)                       # neighbours along keys / queries / heads / batch
 
 
+def test_dropout_streams_of_different_heads_do_not_alias(be):
+    """Every (batch, head) pair against every other one: the random-byte planes (Sq x Sk) must be uncorrelated at equal
+    position AND at any small shift along queries / key groups -- the failure mode of a single additive counter, where one
+    head's stream is a shifted copy of another's (reference: Philox keyed per (batch, head), dropout.h:31-90).  B*H = 48
+    streams of 256 x 512 bytes: 1128 pairs x 9 shifts, each tested at 6 sigma; and no 4-byte word plane may be EQUAL."""
+    torch.manual_seed(10)
+    B, S, Sk, H, d = 3, 256, 512, 16, 64
+    q = torch.randn(B, S, H, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, Sk, H, d, device="cuda", dtype=torch.bfloat16)
+    _, _, rv, _ = be.fwd(q, k, k, None, None, 0.2, d ** -0.5, False, -1, -1, 0.0, True, None)
+    x = rv.reshape(B * H, S, Sk).float().cuda()
+    xf = (x - 127.5) / 73.9
+    n = S * Sk
+    worst = 0.0
+    for dr, dg in ((0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (0, 2), (3, 1), (1, 3), (0, 8)):
+        a = xf[:, : S - dr, : Sk - 4 * dg].reshape(B * H, -1)
+        b_ = xf[:, dr:, 4 * dg:].reshape(B * H, -1)
+        c = (a @ b_.T) / a.shape[1]                      # correlation of stream i with stream j shifted by (dr rows, dg groups)
+        if dr == 0 and dg == 0:
+            c = c - torch.diag(torch.diag(c))            # a stream is of course equal to itself at shift 0
+        worst = max(worst, float(c.abs().max()) * math.sqrt(a.shape[1]))
+    assert worst < 6.0, worst
+    words = rv.reshape(B * H, S, Sk // 4, 4).to(torch.int32)
+    w = (words[..., 0] | (words[..., 1] << 8) | (words[..., 2] << 16) | (words[..., 3] << 24)).reshape(B * H, -1)
+    eq = (w[:, None, :] == w[None, :, :]).float().mean(-1)
+    assert float((eq - torch.eye(B * H, device=eq.device)).max()) < 1e-4   # chance level 2^-32
+
+
 def test_dropout_through_the_public_interface():
     from flash_attn_amd import flash_attn_interface as fi
     from oracle import attention_oracle as orc
