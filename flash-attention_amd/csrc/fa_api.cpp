@@ -47,8 +47,9 @@ const fa::Knobs* read_knobs() {
   if (!(k->rescale_thr >= 0.f) || k->rescale_thr > 16.f) k->rescale_thr = 0.f;
   k->varlen_list = env_int("FA_VARLEN_LIST", 1);
   k->il_sched = env_int("FA_IL_SCHED", 3);
-  k->bwd_dq_nw = env_int("FA_BWD_DQ_NW", 4);
+  k->bwd_dq_nw = env_int("FA_BWD_DQ_NW", 0);
   k->bwd_mode = env_int("FA_BWD_MODE", 0);
+  k->bwd_ds_cap_mb = env_int("FA_BWD_DS_CAP_MB", 8192);
   k->lds_pad = env_int("FA_IL_LDS_PAD", 0);
   k->w64_persist = env_int("FA_W64_PERSIST", 1);
   k->strict = env_int("FA_STRICT", 0);
@@ -283,6 +284,16 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   return FA_OK;
 }
 
+// dQ schedule (fa_launch.h Knobs::bwd_dq_nw).  Measured on MI355X (profiles/r02_bwd_schedules.txt): the 64-rows-per-wave
+// kernel wins from ~2k keys at head dim 128 (config 3: dQ 955 vs 997 us, S = 16k non-causal 1383 vs 1584 us) and loses on
+// short sequences, where its 256-row blocks leave CUs idle.
+int bwd_dq_schedule(const FaBwdParams* a) {
+  const int knob = fa::knobs().bwd_dq_nw;
+  if (knob == 4 || knob == 8 || knob == 64) return knob;
+  const bool plain = a->softcap <= 0.f && !a->alibi_slopes && a->p_dropout <= 0.f;
+  return (a->d == 128 && plain && a->seqlen_k >= 2048 && a->seqlen_q >= 512) ? 64 : 4;
+}
+
 int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
   g_err[0] = 0;
@@ -315,7 +326,8 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   k.softcap = a->softcap;
   if (int rc = check_dropout(a->p_dropout, a->rng_state)) return rc;
   fill_dropout(k, a->p_dropout, a->rng_state, a->seqlen_k);
-  const int bwd_bm = a->d > 128 ? 128 : fa::bwd_block_m();
+  k.dq_nw = bwd_dq_schedule(a);
+  const int bwd_bm = a->d > 128 ? 128 : fa::bwd_block_m(k.dq_nw);
   k.nmb = (a->seqlen_q + bwd_bm - 1) / bwd_bm;
   k.nnb = (a->seqlen_k + fa::bwd_block_n(a->d) - 1) / fa::bwd_block_n(a->d);
   fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb, k.q_units, k.q_unit_size, k.q_unit_hpx);
@@ -327,17 +339,36 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
 void bwd_list_entries(const FaBwdParams* a, int64_t& q_entries, int64_t& k_entries) {
   q_entries = k_entries = 0;
   if (!a->cu_seqlens_q || !a->cu_seqlens_k || fa::knobs().varlen_list == 0) return;
-  const int bm = a->d > 128 ? 128 : fa::bwd_block_m(), bn = fa::bwd_block_n(a->d);
+  const int bm = a->d > 128 ? 128 : fa::bwd_block_m(bwd_dq_schedule(a)), bn = fa::bwd_block_n(a->d);
   const int64_t dq_dense = (int64_t)a->b * ((a->seqlen_q + bm - 1) / bm), dq_bound = (int64_t)a->total_q / bm + a->b;
   const int64_t dk_dense = (int64_t)a->b * ((a->seqlen_k + bn - 1) / bn), dk_bound = (int64_t)a->total_k / bn + a->b;
   if (dq_dense * 4 > dq_bound * 5 && dq_dense >= 64) q_entries = dq_bound;
   if (dk_dense * 4 > dk_bound * 5 && dk_dense >= 64) k_entries = dk_bound;
 }
 
+// dS spill (5-contraction backward, fa_kernel_params.h BwdK::ds_ws): bytes of the dS workspace, 0 = the dQ kernel recomputes.
+// Opt-in (FA_BWD_MODE=2): measured on MI355X it ties with the recomputing pair -- the spilled dS is B*H*Sq*Sk*2 bytes written
+// and read once (4.3 GB at config 3), which costs the HBM about what the two saved contractions cost the matrix pipe
+// (profiles/r02_bwd_5_vs_7_contractions.txt) -- and it needs O(S^2) scratch, so the default keeps the scratch-free 7.
+int64_t bwd_ds_bytes(const FaBwdParams* a) {
+  if (fa::knobs().bwd_mode != 2 || a->cu_seqlens_q || a->cu_seqlens_k || (a->d != 128 && a->d != 64)) return 0;
+  if (a->seqlen_q <= 0 || a->seqlen_k <= 0) return 0;
+  const int64_t bytes = (int64_t)a->b * a->h * ((a->seqlen_q + 31) / 32) * ((a->seqlen_k + 31) / 32) * 2048;
+  return bytes > ((int64_t)fa::knobs().bwd_ds_cap_mb << 20) ? 0 : bytes;
+}
+
 int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   fa::BwdK k;
   if (int rc = fill_bwd(a, varlen, k)) return rc;
   hipStream_t s = (hipStream_t)stream;
+  const int64_t ds_bytes = varlen ? 0 : bwd_ds_bytes(a);
+  if (ds_bytes > 0 && a->workspace && a->workspace_bytes >= ds_bytes) {
+    k.ds_ws = a->workspace;
+    k.ds_nq32 = (a->seqlen_q + 31) / 32;
+    k.ds_nk32 = (a->seqlen_k + 31) / 32;
+    k.nmb = (a->seqlen_q + 255) / 256;   // the dS.K pass works on 256-row blocks
+    fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb, k.q_units, k.q_unit_size, k.q_unit_hpx);
+  }
   if (varlen) {
     int64_t qe, ke;
     bwd_list_entries(a, qe, ke);
@@ -348,7 +379,7 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
       sk.nb = a->b; sk.wl = k.wl; sk.wr = k.wr;
       if (qe) {
         sk.cu_a = a->cu_seqlens_q; sk.cu_o = a->cu_seqlens_k; sk.list = (int2*)ws; sk.bound = (int)qe; sk.keys_blocked = 0;
-        sk.blk = a->d > 128 ? 128 : fa::bwd_block_m();
+        sk.blk = a->d > 128 ? 128 : fa::bwd_block_m(k.dq_nw);
         if (fa::launch_varlen_schedule(sk, s) != 0) return fail(FA_ERR_LAUNCH, "schedule kernel launch failed");
         k.q_list = (const int2*)ws; k.q_bound = (int)qe;
         ws += (qe + 1) * 8;
@@ -367,8 +398,8 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   if (a->seqlen_q == 0 || a->seqlen_k == 0 || a->total_q == 0 || a->total_k == 0) return FA_OK;
   int rc = fa::launch_bwd_delta(k, bf, a->d, s);
   if (rc == 0) rc = fa::launch_bwd_dkdv(k, bf, a->d, s);
-  if (rc == 0) rc = fa::launch_bwd_dq(k, bf, a->d, s);
-  if (rc == 0) { fa::last_schedule().bwd_dq_nw = fa::bwd_block_m() / 32; fa::last_schedule().bwd_list = (k.q_list != nullptr) + 2 * (k.k_list != nullptr); }
+  if (rc == 0) rc = k.ds_ws ? fa::launch_bwd_dq_ds(k, bf, a->d, s) : fa::launch_bwd_dq(k, bf, a->d, s);
+  if (rc == 0) { fa::last_schedule().bwd_spill = k.ds_ws != nullptr; fa::last_schedule().bwd_list = (k.q_list != nullptr) + 2 * (k.k_list != nullptr); }
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no backward kernel for head dim %d", a->d);
   if (rc != 0) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   return FA_OK;
@@ -387,7 +418,7 @@ const char* fa_last_error(void) { return g_err; }
 void fa_knobs_reload(void) { g_knobs.store(read_knobs(), std::memory_order_release); }
 int fa_last_schedule(int32_t* out, int n) {
   const fa::LastSchedule& ls = fa::last_schedule();
-  const int32_t v[FA_SCHEDULE_FIELDS] = {ls.fwd_kernel, ls.fwd_nw, ls.fwd_feat, ls.fwd_splits, ls.fwd_list, ls.d, ls.bf16, ls.bwd_dq_nw, ls.bwd_list};
+  const int32_t v[FA_SCHEDULE_FIELDS] = {ls.fwd_kernel, ls.fwd_nw, ls.fwd_feat, ls.fwd_splits, ls.fwd_list, ls.d, ls.bf16, ls.bwd_dq_nw, ls.bwd_list, ls.bwd_spill};
   for (int i = 0; i < n && i < FA_SCHEDULE_FIELDS; ++i) out[i] = v[i];
   return FA_SCHEDULE_FIELDS;
 }
@@ -461,11 +492,11 @@ int64_t fa_fwd_workspace_bytes(const FaFwdParams* params) {
 }
 
 int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {
-  // the two-pass backward (dK/dV kernel + dQ kernel) needs no fp32 dq accumulator; an uneven packed batch gets work lists
+  // no fp32 dq accumulator; an uneven packed batch gets work lists, a fixed-length batch the dS workspace of the 5-contraction path
   if (!params) return 0;
   int64_t qe, ke;
   bwd_list_entries(params, qe, ke);
-  return (qe ? (qe + 1) * 8 : 0) + (ke ? (ke + 1) * 8 : 0);
+  return (qe ? (qe + 1) * 8 : 0) + (ke ? (ke + 1) * 8 : 0) + bwd_ds_bytes(params);   // (work lists: varlen only; dS: fixed-length only)
 }
 int fa_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, false); }
 int fa_varlen_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, true); }

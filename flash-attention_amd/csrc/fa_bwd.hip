@@ -33,17 +33,15 @@
 #ifndef FA_BWD_PFT
 #define FA_BWD_PFT 3   // same for the transposed operands of the dV / dK products
 #endif
+#ifndef FA_DKDV_SPLIT
+#define FA_DKDV_SPLIT 0  // experiment: 1 = head dims <= 128 also run 4-wave workgroups of 128 keys with 32-query tiles, two per CU
+#endif
+#ifndef FA_DKDV_ABL
+#define FA_DKDV_ABL 0  // timing ablations of the dK/dV kernel (results become wrong; tools/ablate_dkdv.sh): 1 no exp2, 2 row-major LDS
+#endif                 // operands read once per sub-tile, 4 transposed operands read once, 8 no DMA wait / barrier per item,
+                       // 16 no S/dP MFMAs, 32 no dV/dK MFMAs, 64 no Q/dO DMA after the first item
 
 namespace fa {
-
-// Unified LDS tile layout (rows of D 16-bit elements, 16-B chunks XOR-swizzled) that is
-// conflict-free for both access patterns used on the same tile:
-//   - ds_read_b128 operand rows (16 distinct rows per lane group, same logical chunk),
-//   - ds_read_b64_tr_b16 (a half-wave reads 4 consecutive rows x 64 contiguous logical bytes).
-template <int D> FA_DEVINL int swz16(int row) {
-  return D >= 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
-}
-template <int D> FA_DEVINL int tile_off(int row, int chunk) { return row * (D * 2) + ((chunk ^ swz16<D>(row)) << 4); }
 
 constexpr float kLog2e = 1.4426950408889634f;
 
@@ -88,7 +86,7 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
 // dK / dV
 // ------------------------------------------------------------------------------------------------
 template <typename E, int D, int FEAT>
-__global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_dkdv_kernel(const BwdK p) {
+__global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_dkdv_kernel(const BwdK p) {
   constexpr bool XFORM = (FEAT & (FEAT_CAP | FEAT_ALIBI)) != 0;  // scores pass through the scaled domain
   constexpr bool F_CAP = (FEAT & FEAT_CAP) != 0, F_ALIBI = (FEAT & FEAT_ALIBI) != 0, F_DROP = (FEAT & FEAT_DROP) != 0;
   using T = ElemTraits<E>;
@@ -96,9 +94,9 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   using V4 = typename T::v4;
   // D <= 128: 8 waves (two per SIMD, 256 registers each); D = 256: 4 waves, one per SIMD, with the 512-register budget
   // the two 32 x 256 accumulators need, and 32-query tiles so that V block + Q/dO double buffers fit 160 KB of LDS
-  constexpr int NW = D > 128 ? 4 : 8, NT = NW * 64;
+  constexpr int NW = (D > 128 || FA_DKDV_SPLIT) ? 4 : 8, NT = NW * 64;
   constexpr int BNK = NW * 32;   // keys per workgroup
-  constexpr int BMQ = D > 128 ? 32 : 64;  // queries per streamed tile (32-row sub-blocks)
+  constexpr int BMQ = (D > 128 || FA_DKDV_SPLIT) ? 32 : 64;  // queries per streamed tile (32-row sub-blocks)
   constexpr int CPR = D / 8, ROW_BYTES = D * 2;
   constexpr int KS = D / 16, DB = D / 32;
   constexpr int VBLK_BYTES = BNK * ROW_BYTES;
@@ -258,7 +256,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   auto item = [&](auto curc, int it) __attribute__((always_inline)) {
     constexpr int cur = decltype(curc)::value;
     const bool has_next = it + 1 < n_items;
-    if (has_next) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
+    if (has_next && !((FA_DKDV_ABL & 64) && it > 0)) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
     const int m0 = item_m0(it);
     const bool use_alibi = F_ALIBI && (FEAT != FEAT_ALL || p.alibi != nullptr);
     const bool use_cap = F_CAP && (FEAT != FEAT_ALL || p.softcap > 0.f);
@@ -268,13 +266,11 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
     const uint32_t drop_key = drop ? drop_bh_key(p.rng, b * p.h + item_head(it)) : 0u;
     constexpr int QB_OFF = OFF_Q + cur * QT_BYTES, DOB_OFF = OFF_DO + cur * QT_BYTES;
 
+    int ds_stores = 0;   // dS spill stores issued by this wave in this item (wave-uniform)
 #pragma unroll
     for (int qb = 0; qb < BMQ / 32; ++qb) {
       const int q0 = m0 + 32 * qb;
-      bool active = wave_valid && q0 < sq;
-      if (p.wr >= 0) active = active && (wk0 <= q0 + 31 + shift + p.wr);
-      if (p.wl >= 0) active = active && (wk1 >= q0 + shift - p.wl);
-      if (!active) continue;
+      if (!ds_tile_active(q0, wk0, sq, sk, shift, p.wl, p.wr)) continue;
       const int sub = qb * 32 * ROW_BYTES;
 
       // S[query][key] = Q.K^T ; dP[query][key] = dO.V^T   (column = key = lane).  The two accumulation chains alternate
@@ -286,6 +282,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
         const int k0p = opaque(k0), kv0p = opaque(kv0);
         auto rd = [&](int j) __attribute__((always_inline)) {
           const int ks = j >> 1;
+          if ((FA_DKDV_ABL & 2) && j >= 2) { ra[j % PF] = ra[(j & 1) % PF]; if (j & 1) rb[ks & 1] = rb[0]; return; }
           if ((j & 1) == 0) {
             ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (QB_OFF + sub) + (k0p ^ (ks << 5)));
           } else {
@@ -305,6 +302,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[r] = 0.f;
           }
+          if ((FA_DKDV_ABL & 16) && j >= 2) { if ((j & 1) == 0) s = c; else dp = c; continue; }
           if ((j & 1) == 0) s = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), kf[ks], c);
           else dp = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), bitcast_u32x4<V8>(rb[ks & 1]), c);
         }
@@ -360,7 +358,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
-          const float pv = fast_exp2(__builtin_fmaf(s[r], cs, -l4[j]));
+          const float pv = (FA_DKDV_ABL & 1) ? __builtin_fmaf(s[r], cs, -l4[j]) : fast_exp2(__builtin_fmaf(s[r], cs, -l4[j]));
           float pkeep = pv, dpe = dp[r];
           if constexpr (F_DROP) {
             if (drop) {  // Z = keep / (1 - p): dV uses P*Z (the 1/(1-p) is applied to dV at the end), dS = P*(dP*Z - delta)
@@ -377,6 +375,17 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
         }
       }
 
+      if (p.ds_ws) {  // dS spill: this sub-tile's fragments, one 16-byte slot per lane (fa_device.h ds_slot), for the dQ contraction
+        if (!key_valid) {  // keys past the end (their K rows are clamped copies over there): no contribution
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { dsfrag[0][j] = (E)0.f; dsfrag[1][j] = (E)0.f; }
+        }
+        E* dst = (E*)p.ds_ws + (((((int64_t)b * p.h + item_head(it)) * p.ds_nq32 + (q0 >> 5)) * p.ds_nk32 + (wk0 >> 5)) << 10) + ds_slot(ki, hi) * 8;
+        *(u32x4*)dst = __builtin_bit_cast(u32x4, dsfrag[0]);
+        *(u32x4*)(dst + 512) = __builtin_bit_cast(u32x4, dsfrag[1]);
+        ds_stores += 2;
+      }
+
       // dV^T[d][key] += dO^T[d][query] . P[query][key] ;  dK^T[d][key] += Q^T[d][query] . dS[query][key]
       // op i: source = dO (even) / Q (odd), d-block (i>>1) % DB, query half t = i / (2*DB); transpose reads PFT-1 ops ahead
       {
@@ -385,6 +394,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
         const int t0p = opaque(tr_base[0]), t1p = opaque(tr_base[1]);
         auto rd = [&](int i) __attribute__((always_inline)) {
           const int db = (i >> 1) % DB, t = i / (2 * DB);
+          if ((FA_DKDV_ABL & 4) && i >= 2) { tlo[i % PFT] = tlo[(i & 1) % PFT]; thi[i % PFT] = thi[(i & 1) % PFT]; return; }
           const int base = ((i & 1) ? QB_OFF : DOB_OFF) + sub + 16 * t * ROW_BYTES;
           tlo[i % PFT] = lds_read_tr16(lds + base + (t0p ^ (db << 6)));
           thi[i % PFT] = lds_read_tr16(lds + base + (t1p ^ (db << 6)));
@@ -396,6 +406,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
           if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
           __builtin_amdgcn_sched_barrier(0);
           const int db = (i >> 1) % DB, t = i / (2 * DB);
+          if ((FA_DKDV_ABL & 32) && i >= 2) continue;
           if ((i & 1) == 0) dv_acc[db] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), pfrag[t], dv_acc[db]);
           else dk_acc[db] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), dsfrag[t], dk_acc[db]);
         }
@@ -403,7 +414,12 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
     }
 
     if (has_next) store_item(cur ^ 1);
-    lds_dma_wait_all();
+    // the next item's DMA loads were issued before this item's dS stores, and vmcnt retires in issue order: wait for the
+    // loads only, the (0, 2 or 4) stores stay in flight under the next item
+    if (FA_DKDV_ABL & 8) return;
+    if (ds_stores == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (ds_stores == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else lds_dma_wait_all();
     __syncthreads();
   };
   for (int it = 0; it < n_items; it += 2) {
@@ -700,10 +716,9 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-int bwd_block_m() {
-  return 32 * (knobs().bwd_dq_nw == 8 ? 8 : 4);
-}
-int bwd_block_n(int d) { return d > 128 ? 128 : 256; }
+// query rows per dQ workgroup for the schedule BwdK::dq_nw: 4 | 8 waves x 32 rows, or 64 = 4 waves x 64 rows (fa_bwd_w64.hip)
+int bwd_block_m(int nw) { return (nw == 8 || nw == 64) ? 256 : 128; }
+int bwd_block_n(int d) { return (d > 128 || FA_DKDV_SPLIT) ? 128 : 256; }
 
 template <typename E, int D>
 static int launch_delta_t(const BwdK& p, hipStream_t stream) {
@@ -715,7 +730,7 @@ static int launch_delta_t(const BwdK& p, hipStream_t stream) {
 
 template <typename E, int D, int FEAT>
 static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
-  constexpr int NWK = D > 128 ? 4 : 8, BMQ = D > 128 ? 32 : 64;
+  constexpr int NWK = (D > 128 || FA_DKDV_SPLIT) ? 4 : 8, BMQ = (D > 128 || FA_DKDV_SPLIT) ? 32 : 64;
   constexpr int smem = NWK * 32 * D * 2 + 4 * BMQ * D * 2 + 4 * BMQ * 4;
   auto kern = fa_bwd_dkdv_kernel<E, D, FEAT>;
   static std::atomic<unsigned long long> attr_mask{0};
@@ -751,7 +766,7 @@ static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
 template <typename E, int D, int FEAT>
 static int launch_dq_f(const BwdK& p, hipStream_t stream) {
   if constexpr (D > 128) return launch_dq_nw<E, D, 4, FEAT>(p, stream);
-  else return bwd_block_m() == 256 ? launch_dq_nw<E, D, 8, FEAT>(p, stream) : launch_dq_nw<E, D, 4, FEAT>(p, stream);
+  else return bwd_block_m(p.dq_nw) == 256 ? launch_dq_nw<E, D, 8, FEAT>(p, stream) : launch_dq_nw<E, D, 4, FEAT>(p, stream);
 }
 template <typename E, int D>
 static int launch_dq_t(const BwdK& p, hipStream_t stream) {
@@ -780,6 +795,14 @@ static int launch_dq_t(const BwdK& p, hipStream_t stream) {
 
 int launch_bwd_delta(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_delta_t) }
 int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_dkdv_t) }
-int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_dq_t) }
+int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
+  LastSchedule& ls = last_schedule();
+  ls.bwd_dq_nw = d > 128 ? 4 : bwd_block_m(p.dq_nw) / 32;
+  if (p.dq_nw == 64) {   // 64-rows-per-wave schedule where it applies, else the 8-wave kernel on the same 256-row blocks
+    const int rc = launch_bwd_dq_w64(p, dtype_bf16, d, stream);
+    if (rc != -2) { ls.bwd_dq_nw = 64; return rc; }
+  }
+  FA_BWD_DISPATCH(launch_dq_t)
+}
 
 }  // namespace fa

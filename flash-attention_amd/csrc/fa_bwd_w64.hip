@@ -1,0 +1,729 @@
+// dQ kernel of the backward pass for gfx950, "64 query rows per wave, one wave per SIMD" schedule (the forward's
+// fa_fwd_w64.hip shape applied to fa_bwd.hip's dQ kernel; reference: the dQ half of compute_dq_dk_dv_1colblock,
+// csrc/flash_attn/src/flash_bwd_kernel.h:457-724).
+//
+// A wave owns two 32-row query blocks.  Their Q and dO fragments (B operands, 64 + 64 registers) and the dQ^T accumulators
+// (128 registers) fill the accumulator half of the 512-entry register file for the whole block and are named literally in
+// the inline asm; scores come out of the matrix pipe in arch VGPRs.  K/V tiles of 64 keys stream through LDS by DMA, every
+// fragment read from LDS feeds TWO MFMAs (one per query block):
+//   S^T[key][query]  = K . Q^T        A = K row fragment (LDS),     B = Q fragment (AGPR)
+//   dP^T[key][query] = V . dO^T       A = V row fragment (LDS),     B = dO fragment (AGPR)
+//   dQ^T[d][query]  += K^T . dS^T     A = K^T (LDS transpose read), B = dS^T = P*(dP^T - delta) packed from the VGPR tuples
+// column = query = lane, so LSE and delta are lane-local scalars.  Unlike the forward there is no running maximum and no
+// rescale: the steady-state step is branch-free.  Step i (32 keys) = 16 MFMAs S_{i+1}, 16 MFMAs dP_{i+1}, 16 MFMAs
+// dQ += K_{i-1}^T.dS_{i-1}, with the VALU work of dS_i (fma, exp2, sub, mul, pack: ~5 per element) hand-assigned to the 48
+// MFMA gaps.  K is read twice per tile -- row fragments when its scores are computed, transposed one tile later -- so K
+// (and, slot for slot, V) sit in a ring of three tiles: tile u+1 arrives while tiles u and u-1 are read.
+// Arithmetic as in fa_bwd.hip: P = exp2(S*scale*log2e - LSE*log2e), dS = P*(dP - delta), dS rounded to the input dtype,
+// softmax_scale applied once in the epilogue.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "fa_device.h"
+#include "fa_kernel_params.h"
+#include "fa_launch.h"
+#include "fa_fwd_w64_regs.h"
+#define FA_W64_CLOB FA_W64_ACC_CLOBBERS_256
+#include "fa_w64_asm.h"
+
+#ifndef FA_BW64_ABL
+#define FA_BW64_ABL 0  // timing ablations (results become wrong): 1 no exp2, 2 no LDS operand reads, 4 no K/V DMA after the
+#endif                 // first tiles, 8 no DMA wait / barrier per tile, 16 no packing
+
+namespace fa {
+namespace {
+
+constexpr int BW_Q_BASE = 128;    // Q fragments: fragment F at a[128+4F : 131+4F], F = qb*KS + ks
+constexpr int BW_DO_BASE = 192;   // dO fragments, same indexing
+constexpr float kLog2eW = 1.4426950408889634f;
+
+// d(VGPR) = a(VGPR) . frag(AGPR a[BASE:BASE+3])            first k-step of a chain (C = inline constant 0)
+template <typename E, int BASE> FA_DEVINL void mfma_v_first(f32x16& d, u32x4 a) {
+  if constexpr (std::is_same<E, __bf16>::value)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "i"(BASE), "i"(BASE + 3) : FA_W64_CLOB);
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "i"(BASE), "i"(BASE + 3) : FA_W64_CLOB);
+}
+// d(VGPR) += a(VGPR) . frag(AGPR)
+template <typename E, int BASE> FA_DEVINL void mfma_v_acc(f32x16& d, u32x4 a) {
+  if constexpr (std::is_same<E, __bf16>::value)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(BASE), "i"(BASE + 3) : FA_W64_CLOB);
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(BASE), "i"(BASE + 3) : FA_W64_CLOB);
+}
+// dQ tuple T (AGPR a[16T:16T+15]) += a(VGPR) . b(VGPR)
+template <typename E, int T> FA_DEVINL void mfma_q_acc(u32x4 a, u32x4 b) {
+  if constexpr (std::is_same<E, __bf16>::value)
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(16 * T), "i"(16 * T + 15) : FA_W64_CLOB);
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(16 * T), "i"(16 * T + 15) : FA_W64_CLOB);
+}
+
+}  // namespace
+
+template <typename E, int D>
+__global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
+  using T = ElemTraits<E>;
+  using V8 = typename T::v8;
+  constexpr int NW = 4, QB = 2, BM = NW * 64, BN = 64, CPR = D / 8;
+  constexpr int ROW_BYTES = D * 2, TILE_BYTES = BN * ROW_BYTES;
+  constexpr int KS = D / 16, DB = D / 32;
+  constexpr int RING = 3;                         // K tiles u-1 (transposed), u (rows), u+1 (arriving); V shares the slot index
+  constexpr int V_RING = RING * TILE_BYTES;       // V ring behind the K ring
+  constexpr int DO_OFF = BM * ROW_BYTES;          // prologue staging: Q rows at 0, dO rows behind (both under the rings)
+  static_assert(D == 128 || D == 64, "head dims of this schedule: 64, 128");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char FA_LDS* lds = (char FA_LDS*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, qi = lane & 31;
+  const int d_row = lane / CPR, d_pc = lane % CPR;   // row inside a 1-KiB DMA piece, physical 16-byte chunk
+  constexpr int RPD = 1024 / ROW_BYTES;
+
+  int b, h, m_block;
+  if (p.q_list) {
+    if (!work_list_item(p.q_list, blockIdx.x, p.h, p.h_k, b, h, m_block)) return;
+  } else {
+    const int w = xcd_interleave(blockIdx.x, p.q_units, p.q_unit_size, p.q_unit_hpx);
+    if (w < 0) return;
+    const int bh = w / p.nmb;
+    const int mbr = w - bh * p.nmb;
+    m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
+    b = bh / p.h;
+    h = bh - b * p.h;
+  }
+  const int hk = h / p.hk_ratio;
+  int sq = p.sq, sk = p.sk;
+  int64_t q_row0 = 0, k_row0 = 0;
+  int64_t q_boff = (int64_t)b * p.q_bs, do_boff = (int64_t)b * p.do_bs, dq_boff = (int64_t)b * p.dq_bs;
+  int64_t k_boff = (int64_t)b * p.k_bs, v_boff = (int64_t)b * p.v_bs;
+  if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; dq_boff = 0; }
+  if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
+  const int m0 = m_block * BM;
+  if (m0 >= sq) return;
+
+  const E* __restrict__ kp = (const E*)p.k + k_boff + k_row0 * p.k_rs + (int64_t)hk * p.k_hs;
+  const E* __restrict__ vp = (const E*)p.v + v_boff + k_row0 * p.v_rs + (int64_t)hk * p.v_hs;
+
+  const int shift = sk - sq;
+  const int blk_last = min(m0 + BM, sq) - 1;
+  int kmax = sk - 1, kmin = 0;
+  if (p.wr >= 0) kmax = min(kmax, blk_last + shift + p.wr);
+  if (p.wl >= 0) kmin = max(0, m0 + shift - p.wl);
+  const int n_min = kmin / BN;
+  const int n_max = (kmax >= kmin) ? (kmax / BN + 1) : n_min;
+  const int n_tiles = n_max - n_min;
+  const int n_steps = 2 * n_tiles;
+  const int key_base = n_min * BN;
+
+  const int w_row0 = m0 + wave * 64;
+  const int w_row1 = min(w_row0 + 63, sq - 1);
+  const bool wave_valid = w_row0 < sq;
+  const int w_kmax = (p.wr >= 0) ? min(sk - 1, w_row1 + shift + p.wr) : sk - 1;
+  const int w_kmin = (p.wl >= 0) ? max(0, w_row0 + shift - p.wl) : 0;
+  const int w_full_hi = (p.wr >= 0) ? min(sk - 1, w_row0 + shift + p.wr) : sk - 1;
+  const int w_full_lo = (p.wl >= 0) ? (w_row1 + shift - p.wl) : 0;
+  int lim_hi[QB], lim_lo[QB];
+  float lse_l[QB], delta_l[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int my_row = w_row0 + 32 * qb + qi;
+    lim_hi[qb] = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
+    lim_lo[qb] = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
+    lse_l[qb] = INFINITY;   // rows past the end: P = 0
+    delta_l[qb] = 0.f;
+    if (my_row < sq) {
+      const int64_t base = p.cu_q ? ((int64_t)h * p.total_q + q_row0) : (((int64_t)b * p.h + h) * p.sq);
+      lse_l[qb] = p.lse[base + my_row] * kLog2eW;
+      delta_l[qb] = p.delta[base + my_row];
+    }
+  }
+  const float cs = p.scale_log2;
+
+  auto step_active = [&](int i) __attribute__((always_inline)) {
+    const int k0 = key_base + 32 * i;
+    return wave_valid && (i >= 0) && (i < n_steps) && (k0 <= w_kmax) && (k0 + 31 >= w_kmin);
+  };
+  auto step_needs_mask = [&](int i) __attribute__((always_inline)) {
+    const int k0 = key_base + 32 * i;
+    return (k0 + 31 > w_full_hi) || (k0 < w_full_lo);
+  };
+
+  // ---- prologue: this wave's 64 rows of Q and dO -> LDS (coalesced DMA, swizzled source chunk) -> B-operand fragments in
+  // accumulator registers.  Only the wave's own rows are touched, so its own vmcnt wait publishes them.
+  {
+    const E* qsrc = (const E*)p.q + q_boff + q_row0 * p.q_rs + (int64_t)h * p.q_hs;
+    const E* dosrc = (const E*)p.dout + do_boff + q_row0 * p.do_rs + (int64_t)h * p.do_hs;
+    constexpr int QDMA = (64 * ROW_BYTES) / 1024;   // pieces per wave and operand
+#pragma unroll
+    for (int i = 0; i < QDMA; ++i) {
+      const int row = wave * 64 + i * RPD + d_row;
+      const int grow = min(m0 + row, sq - 1);
+      const int c = d_pc ^ swz16<D>(row);
+      lds_dma_16B(qsrc + (int64_t)grow * p.q_rs + c * 8, lds + (wave * QDMA + i) * 1024);
+      lds_dma_16B(dosrc + (int64_t)grow * p.do_rs + c * 8, lds + DO_OFF + (wave * QDMA + i) * 1024);
+    }
+    lds_dma_wait_all();
+    const int fbase = (wave * 64 + qi) * ROW_BYTES + ((hi ^ swz16<D>(qi)) << 4);
+    static_for<QB * KS>([&](auto fc) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value, qb = f / KS, ks = f % KS;
+      const int a = (fbase + qb * 32 * ROW_BYTES) ^ (ks << 5);
+      const u32x4 xq = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)a;
+      const u32x4 xd = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(a + DO_OFF);
+      acc_write_frag<BW_Q_BASE + 4 * f>(xq);
+      acc_write_frag<BW_DO_BASE + 4 * f>(xd);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();   // the K/V rings reuse this LDS
+  }
+
+  // ---- K/V tiles: global -> LDS by DMA through a buffer descriptor (see fa_fwd_w64.hip), swz16 on the source chunk -----
+  constexpr int NDMA = TILE_BYTES / 1024, DPW = NDMA / NW;
+  unsigned koff_l[DPW], voff_l[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int row = (wave * DPW + i) * RPD + d_row;
+    const int c = d_pc ^ swz16<D>(row);
+    koff_l[i] = (unsigned)(row * (int)p.k_rs + c * 8) * 2u - (unsigned)(i * 1024);
+    voff_l[i] = (unsigned)(row * (int)p.v_rs + c * 8) * 2u - (unsigned)(i * 1024);
+  }
+  auto make_srd = [&](const void* base, int64_t row_stride) __attribute__((always_inline)) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi16 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;
+    const unsigned long long bytes = sk > 0 ? ((unsigned long long)(sk - 1) * (unsigned long long)row_stride + D) * 2ull : 0ull;
+    const unsigned nrec = __builtin_amdgcn_readfirstlane((unsigned)(bytes > 0xffffffffull ? 0xffffffffull : bytes));
+    u32x4 s = {lo, hi16, nrec, 0x00020000u};
+    return s;
+  };
+  const u32x4 k_srd = make_srd(kp, p.k_rs), v_srd = make_srd(vp, p.v_rs);
+  auto dma_pieces = [&](const u32x4& srd, const unsigned (&vo)[DPW], unsigned lds_dst) __attribute__((always_inline)) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    if constexpr (DPW == 4) {
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                   "buffer_load_dwordx4 %1, %6, 0 offen lds\n\t"
+                   "buffer_load_dwordx4 %2, %6, 0 offen offset:1024 lds\n\t"
+                   "buffer_load_dwordx4 %3, %6, 0 offen offset:2048 lds\n\t"
+                   "buffer_load_dwordx4 %4, %6, 0 offen offset:3072 lds\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "s"(dst), "s"(srd) : "memory");
+    } else {
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                   "buffer_load_dwordx4 %1, %4, 0 offen lds\n\t"
+                   "buffer_load_dwordx4 %2, %4, 0 offen offset:1024 lds\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(vo[0]), "v"(vo[DPW - 1]), "s"(dst), "s"(srd) : "memory");
+    }
+  };
+  auto dma_tile = [&](auto isvc, int slot, int t) __attribute__((always_inline)) {  // t relative to n_min
+    constexpr bool ISV = decltype(isvc)::value != 0;
+    const int n = n_min + t;
+    const int64_t rs = ISV ? p.v_rs : p.k_rs;
+    const unsigned lds_dst = (unsigned)((ISV ? V_RING : 0) + slot * TILE_BYTES + wave * DPW * 1024);
+    unsigned vo[DPW];
+    if (n * BN + BN <= sk) {
+      const unsigned toff = (unsigned)n * (unsigned)(BN * 2) * (unsigned)rs;
+#pragma unroll
+      for (int i = 0; i < DPW; ++i) vo[i] = (ISV ? voff_l[i] : koff_l[i]) + toff;
+    } else {  // last, partial tile: rows past the last key are clamped to it (finite data, masked to P = 0)
+#pragma unroll
+      for (int i = 0; i < DPW; ++i) {
+        const int row = (wave * DPW + i) * RPD + d_row;
+        const int grow = min(n * BN + row, sk - 1);
+        const int c = d_pc ^ swz16<D>(row);
+        vo[i] = ((unsigned)grow * (unsigned)rs + (unsigned)(c * 8)) * 2u - (unsigned)(i * 1024);
+      }
+    }
+    dma_pieces(ISV ? v_srd : k_srd, vo, lds_dst);
+  };
+
+  if (n_tiles > 0) {
+    dma_tile(ICw<0>{}, 0, 0);
+    dma_tile(ICw<1>{}, 0, 0);
+  }
+
+  // per-lane LDS read addresses, ring slot included: ka = row fragments of the tile being scored (V at + V_RING),
+  // ta = transposed fragments of the tile before it.  Advanced by one slot per iteration.
+  int ka[KS], ta0[DB], ta1[DB];
+  {
+    const int kbase = qi * ROW_BYTES + ((hi ^ swz16<D>(qi)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ka[ks] = kbase ^ (ks << 5);
+    const int tr_i = lane & 15, tr_half = (lane >> 4) & 1, tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
+    const int tb0 = tile_off<D>(4 * hi + tr_rr, 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
+    const int tb1 = tile_off<D>(8 + 4 * hi + tr_rr, 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      ta0[db] = (tb0 ^ (db << 6)) + (RING - 1) * TILE_BYTES;   // "tile -1" sits in the last slot
+      ta1[db] = (tb1 ^ (db << 6)) + (RING - 1) * TILE_BYTES;
+    }
+  }
+  int slot_k = 0;   // ring slot of the tile being scored (wave-uniform)
+
+  acc_zero_range<0>(std::make_integer_sequence<int, 32 * DB>{});   // dQ^T: tuple qb*DB + db
+  f32x16 sA[QB], sB[QB], dpA[QB], dpB[QB];
+  u32x4 fA[QB][2], fB[QB][2];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sA[qb][r] = 0.f; sB[qb][r] = 0.f; dpA[qb][r] = 0.f; dpB[qb][r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { fA[qb][t] = u32x4{0u, 0u, 0u, 0u}; fB[qb][t] = u32x4{0u, 0u, 0u, 0u}; }
+  }
+  bool have_cur = false, have_prev = false;
+
+  lds_dma_wait_all();
+  __syncthreads();
+
+  auto rd_tr = [&](int a0, int a1) __attribute__((always_inline)) {
+    const s16x4 lo = lds_read_tr16((const char FA_LDS*)(unsigned long)(unsigned)a0);
+    const s16x4 hi4 = lds_read_tr16((const char FA_LDS*)(unsigned long)(unsigned)a1);
+    return __builtin_bit_cast(u32x4, combine_tr<V8>(lo, hi4));
+  };
+  // dS_i of one element
+  auto ds_elem = [&](float sv, float dpv, int qb) __attribute__((always_inline)) {
+    const float e = __builtin_fmaf(sv, cs, -lse_l[qb]);
+    const float pv = (FA_BW64_ABL & 1) ? e : fast_exp2(e);
+    return pv * (dpv - delta_l[qb]);
+  };
+  auto pack2 = [&](float x0, float x1) __attribute__((always_inline)) {
+    using V2 = __attribute__((ext_vector_type(2))) E;
+    V2 pr;
+    pr[0] = (E)x0;
+    pr[1] = (E)x1;
+    return __builtin_bit_cast(unsigned, pr);
+  };
+
+  // ---- generic (head / tail) step: compiler-ordered, drains the matrix pipe before the VALU touches MFMA results ------
+  auto generic_step = [&](auto halfc, int i, f32x16 (&s_cur)[QB], f32x16 (&dp_cur)[QB], f32x16 (&s_nxt)[QB], f32x16 (&dp_nxt)[QB],
+                          const u32x4 (&f_prev)[QB][2], u32x4 (&f_cur)[QB][2]) __attribute__((always_inline)) {
+    constexpr int half = decltype(halfc)::value;
+    constexpr int HOFF = half * 32 * ROW_BYTES;
+    const bool do_qk = step_active(i + 1);
+    const bool do_sm = have_cur;
+    const bool do_pv = have_prev;
+    if (do_qk) {
+      static_for<KS>([&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value;
+        const u32x4 kf = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[ks] + HOFF);
+        const u32x4 vf = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[ks] + HOFF + V_RING);
+        if constexpr (ks == 0) {
+          mfma_v_first<E, BW_Q_BASE>(s_nxt[0], kf);
+          mfma_v_first<E, BW_Q_BASE + 4 * KS>(s_nxt[1], kf);
+          mfma_v_first<E, BW_DO_BASE>(dp_nxt[0], vf);
+          mfma_v_first<E, BW_DO_BASE + 4 * KS>(dp_nxt[1], vf);
+        } else {
+          mfma_v_acc<E, BW_Q_BASE + 4 * ks>(s_nxt[0], kf);
+          mfma_v_acc<E, BW_Q_BASE + 4 * (KS + ks)>(s_nxt[1], kf);
+          mfma_v_acc<E, BW_DO_BASE + 4 * ks>(dp_nxt[0], vf);
+          mfma_v_acc<E, BW_DO_BASE + 4 * (KS + ks)>(dp_nxt[1], vf);
+        }
+      });
+    }
+    if (do_sm) {
+      mfma_drain_v(s_cur[0], s_cur[1]);
+      mfma_drain_v(dp_cur[0], dp_cur[1]);
+      const bool mask = step_needs_mask(i);
+      const int k0 = key_base + 32 * i;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const int rel_hi = lim_hi[qb] - k0 - 4 * hi, rel_lo = lim_lo[qb] - k0 - 4 * hi;
+        float dsv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int off = acc_row(r, 0);
+          float sv = s_cur[qb][r];
+          if (mask) sv = ((off <= rel_hi) && (off >= rel_lo)) ? sv : -INFINITY;
+          dsv[r] = ds_elem(sv, dp_cur[qb][r], qb);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f_cur[qb][c >> 2][c & 3] = pack2(dsv[2 * c], dsv[2 * c + 1]);
+      }
+    }
+    if (do_pv) {
+      static_for<2 * DB>([&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value, db = g % DB, t = g / DB;
+        constexpr int off = HOFF + 16 * t * ROW_BYTES;
+        const u32x4 kt = rd_tr(ta0[db] + off, ta1[db] + off);
+        mfma_q_acc<E, db>(kt, f_prev[0][t]);
+        mfma_q_acc<E, DB + db>(kt, f_prev[1][t]);
+      });
+    }
+    if (do_qk) {
+      mfma_drain_v(s_nxt[0], s_nxt[1]);
+      mfma_drain_v(dp_nxt[0], dp_nxt[1]);
+    }
+    have_prev = do_sm;
+    have_cur = do_qk;
+  };
+
+  // ---- steady-state step: NG MFMA gaps -----------------------------------------------------------------------------------
+  //   gaps [0, 2KS)        : S_{i+1}[qb] chain, k-step g/2          (K row fragment read once, used by both query blocks)
+  //   gaps [2KS, 4KS)      : dP_{i+1}[qb] chain                     (V row fragment)
+  //   gaps [4KS, 4KS+4DB)  : dQ[qb][db] += K_{i-1}^T . dS_{i-1}[qb] (transposed K fragment)
+  //   VALU: the 32 elements of dS_i spread over the gaps, each pair packed one gap after it is complete; the step's DMA
+  //   pieces in the odd gaps 1, 3, ...  The score chains end 16 MFMAs before the next step reads them.
+  auto fast_step = [&](auto halfc, auto maskc, int i_cur, f32x16 (&s_cur)[QB], f32x16 (&dp_cur)[QB], f32x16 (&s_nxt)[QB],
+                       f32x16 (&dp_nxt)[QB], const u32x4 (&f_prev)[QB][2], u32x4 (&f_cur)[QB][2], const u32x4& dma_srd,
+                       const unsigned (&dma_off)[DPW], unsigned dma_toff, unsigned dma_dst) __attribute__((always_inline)) {
+    constexpr int half = decltype(halfc)::value;
+    constexpr bool MASK = decltype(maskc)::value != 0;
+    constexpr int HOFF = half * 32 * ROW_BYTES;
+    constexpr int QKG = 2 * KS, DQG = 4 * DB, NG = 2 * QKG + DQG;
+    constexpr int AH = 2, RNG = AH + 1;     // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
+    constexpr int NF = 2 * KS + 2 * DB;     // fragment slots: KS K rows, KS V rows, 2*DB transposed K
+    u32x4 fr[RNG];
+    if (FA_BW64_ABL & 2) {
+#pragma unroll
+      for (int f = 0; f < RNG; ++f) fr[f] = f_prev[0][0];
+    }
+    auto rd_frag = [&](int f) __attribute__((always_inline)) {
+      if (FA_BW64_ABL & 2) return;
+      if (f < KS) {
+        fr[f % RNG] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[f] + HOFF);
+      } else if (f < 2 * KS) {
+        fr[f % RNG] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[f - KS] + HOFF + V_RING);
+      } else if (f < NF) {
+        const int op = f - 2 * KS, db = op % DB, t = op / DB;
+        fr[f % RNG] = rd_tr(ta0[db] + HOFF + 16 * t * ROW_BYTES, ta1[db] + HOFF + 16 * t * ROW_BYTES);
+      }
+    };
+    // elements of dS_i done before gap x (e = 16*qb + r), all 32 before the last gap; pairs are packed one gap later
+    auto el_end = [](int x) constexpr { return x <= 0 ? 0 : ((32 * x + NG - 2) / (NG - 1) > 32 ? 32 : (32 * x + NG - 2) / (NG - 1)); };
+    float dsv[QB][16];
+    int rel_hi[QB] = {0, 0}, rel_lo[QB] = {0, 0};
+    if constexpr (MASK) {
+      const int k0 = key_base + 32 * i_cur;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) { rel_hi[qb] = lim_hi[qb] - k0 - 4 * hi; rel_lo[qb] = lim_lo[qb] - k0 - 4 * hi; }
+    }
+#pragma unroll
+    for (int f = 0; f < AH; ++f) rd_frag(f);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NG>([&](auto xc) __attribute__((always_inline)) {
+      constexpr int x = decltype(xc)::value;
+      constexpr int f = x / 2, qb = x & 1;
+      if constexpr (qb == 0) rd_frag(f + AH);
+      if constexpr (x < QKG) {
+        if constexpr (f == 0) mfma_v_first<E, BW_Q_BASE + 4 * (qb * KS)>(s_nxt[qb], fr[f % RNG]);
+        else mfma_v_acc<E, BW_Q_BASE + 4 * (qb * KS + f)>(s_nxt[qb], fr[f % RNG]);
+      } else if constexpr (x < 2 * QKG) {
+        constexpr int ks = f - KS;
+        if constexpr (ks == 0) mfma_v_first<E, BW_DO_BASE + 4 * (qb * KS)>(dp_nxt[qb], fr[f % RNG]);
+        else mfma_v_acc<E, BW_DO_BASE + 4 * (qb * KS + ks)>(dp_nxt[qb], fr[f % RNG]);
+      } else {
+        constexpr int op = f - 2 * KS;
+        mfma_q_acc<E, qb * DB + op % DB>(fr[f % RNG], f_prev[qb][op / DB]);
+      }
+      if constexpr ((x & 1) && (x / 2) < DPW && !(FA_BW64_ABL & 4)) {
+        constexpr int pc = x / 2;
+        const unsigned vo = dma_off[pc] + dma_toff;
+        if constexpr (pc == 0)
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(vo), "s"(dma_dst), "s"(dma_srd) : "memory");
+        else
+          asm volatile("buffer_load_dwordx4 %0, %1, 0 offen offset:%c2 lds" : : "v"(vo), "s"(dma_srd), "i"(1024 * pc) : "memory");
+      }
+#pragma unroll
+      for (int e = el_end(x); e < el_end(x + 1); ++e) {
+        const int eq = e >> 4, r = e & 15;
+        float sv = s_cur[eq][r];
+        if constexpr (MASK) {
+          const int off = acc_row(r, 0);
+          sv = ((off <= rel_hi[eq]) && (off >= rel_lo[eq])) ? sv : -INFINITY;
+        }
+        dsv[eq][r] = ds_elem(sv, dp_cur[eq][r], eq);
+      }
+      if (!(FA_BW64_ABL & 16)) {
+#pragma unroll
+        for (int c = el_end(x - 1) / 2; c < el_end(x) / 2; ++c) {
+          const int cq = c >> 3, r = 2 * (c & 7);
+          unsigned pw = pack2(dsv[cq][r], dsv[cq][r + 1]);
+          asm volatile("" : "+v"(pw));   // pinned to this gap
+          f_cur[cq][r >> 3][(r & 7) >> 1] = pw;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // iteration u (0..n_tiles): steps 2u-1 and 2u score tile u (K_u, V_u row fragments) and accumulate tile u-1 (K_{u-1}
+  // transposed); K_{u+1}, V_{u+1} are DMA'd during the iteration into the third ring slot.
+  int uf_lo = 1, uf_hi = 0;
+  if (wave_valid && n_tiles > 0) {
+    const int a_lo = max(0, (w_kmin - key_base) >> 5);
+    const int a_hi = min(n_steps - 1, (w_kmax - key_base) >> 5);
+    uf_lo = (a_lo + 3) >> 1;
+    uf_hi = (a_hi - 1) >> 1;
+    if (sk % BN != 0) uf_hi = min(uf_hi, sk / BN - n_min - 2);   // the steady-state DMA does not clamp rows: full tiles only
+  }
+#ifdef FA_BW64_NOFAST
+  uf_lo = 1; uf_hi = 0;
+#endif
+  auto iter_head = [&](int u) __attribute__((always_inline)) {
+    if ((FA_BW64_ABL & 4) && u > 1) return;
+    if (u + 1 < n_tiles) {
+      const int nslot = slot_k == RING - 1 ? 0 : slot_k + 1;
+      dma_tile(ICw<0>{}, nslot, u + 1);
+      dma_tile(ICw<1>{}, nslot, u + 1);
+    }
+  };
+  auto iter_tail = [&]() __attribute__((always_inline)) {
+    // advance the read addresses by one ring slot (ka: slot_k -> slot_k + 1; ta: slot_k - 1 -> slot_k)
+    const int dk = slot_k == RING - 1 ? -(RING - 1) * TILE_BYTES : TILE_BYTES;
+    const int dt = slot_k == 0 ? -(RING - 1) * TILE_BYTES : TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ka[ks] += dk;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { ta0[db] += dt; ta1[db] += dt; }
+    slot_k = slot_k == RING - 1 ? 0 : slot_k + 1;
+    if (FA_BW64_ABL & 8) return;
+    lds_dma_wait_all();
+    __syncthreads();
+  };
+  auto generic_iter = [&](int u) __attribute__((always_inline)) {
+    iter_head(u);
+    generic_step(ICw<0>{}, 2 * u - 1, sA, dpA, sB, dpB, fA, fB);
+    generic_step(ICw<1>{}, 2 * u, sB, dpB, sA, dpA, fB, fA);
+    iter_tail();
+  };
+  if (n_tiles > 0) {
+    int u = 0;
+    const int head_end = min(max(uf_lo, 0), n_tiles + 1);
+    for (; u < head_end; ++u) generic_iter(u);
+    const unsigned wave_dst = (unsigned)(wave * DPW * 1024);
+    auto fast_iter = [&](auto maskc, int uu) __attribute__((always_inline)) {
+      const int nslot = slot_k == RING - 1 ? 0 : slot_k + 1;
+      const unsigned toff_k = (unsigned)(n_min + uu + 1) * (unsigned)(BN * 2) * (unsigned)p.k_rs;
+      const unsigned toff_v = (unsigned)(n_min + uu + 1) * (unsigned)(BN * 2) * (unsigned)p.v_rs;
+      // (a tile past the last one lands in the slot nobody reads again; rows past the descriptor's range are never a fault)
+      fast_step(ICw<0>{}, maskc, 2 * uu - 1, sA, dpA, sB, dpB, fA, fB, k_srd, koff_l, toff_k,
+                __builtin_amdgcn_readfirstlane((unsigned)(nslot * TILE_BYTES) + wave_dst));
+      fast_step(ICw<1>{}, maskc, 2 * uu, sB, dpB, sA, dpA, fB, fA, v_srd, voff_l, toff_v,
+                __builtin_amdgcn_readfirstlane((unsigned)(V_RING + nslot * TILE_BYTES) + wave_dst));
+      have_prev = step_active(2 * uu);
+      have_cur = step_active(2 * uu + 1);
+      iter_tail();
+    };
+    int um_lo = uf_lo, um_hi = uf_hi;
+    {
+      const int f_lo = (w_full_lo - key_base + 31) >> 5;   // first step with no left-masked key
+      const int f_hi = (w_full_hi - 31 - key_base) >> 5;   // last step with no right-masked key
+      um_lo = max(uf_lo, (f_lo + 2) >> 1);                 // steps 2u-1 and 2u both unmasked
+      um_hi = min(uf_hi, f_hi >> 1);
+    }
+    auto fast_range = [&](auto maskc, int hi_incl) __attribute__((always_inline)) {
+      for (; u <= hi_incl; ++u) fast_iter(maskc, u);
+    };
+    fast_range(ICw<1>{}, min(uf_hi, um_lo - 1));
+    fast_range(ICw<0>{}, um_hi);
+    fast_range(ICw<1>{}, uf_hi);
+    for (; u <= n_tiles; ++u) generic_iter(u);
+  }
+
+  if (!wave_valid) return;
+  mfma_drain_acc();
+  // dQ tile through LDS (the rings are free after the last tile barrier): whole-row stores, softmax_scale applied here
+  E* dqtile = (E*)p.dq + dq_boff + (q_row0 + w_row0) * p.dq_rs + (int64_t)h * p.dq_hs;
+  static_for<QB>([&](auto qbc) __attribute__((always_inline)) {
+    constexpr int qb = decltype(qbc)::value;
+    f32x16 o_v[DB];
+    static_for<DB>([&](auto dbc) __attribute__((always_inline)) {
+      constexpr int db = decltype(dbc)::value;
+      acc_read_tuple<16 * (qb * DB + db)>(o_v[db]);
+    });
+    const int row0 = w_row0 + 32 * qb;
+    if (row0 < sq)
+      store_tile_via_lds<E, D>(lds + (wave * 64 + qb * 32) * (ROW_BYTES + 16), o_v, p.scale, dqtile + (int64_t)(32 * qb) * p.dq_rs, p.dq_rs,
+                               sq - row0, lane);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dQ from spilled dS (BwdK::ds_ws): dQ^T[d][query] = sum_key K^T[d][key] . dS^T[key][query] -- ONE contraction instead of the
+// three of the recomputing kernels.  8 waves x 32 query rows; K tiles (64 keys) shared through LDS, each wave's dS
+// sub-tiles DMA'd into its private LDS rows and read back transposed (ds_read_b64_tr_b16 turns the writer's lane = key image
+// into the lane = query B operand; fa_device.h ds_slot).  No score arithmetic at all, so this kernel also serves softcap,
+// ALiBi and dropout: they are folded into dS by the dK/dV kernel.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename E, int D>
+__global__ void __launch_bounds__(512, 1) fa_bwd_dq_ds_kernel(const BwdK p) {
+  using T = ElemTraits<E>;
+  using V8 = typename T::v8;
+  // 8 waves x 32 rows, two waves per SIMD: the operands are all 8-byte transpose reads, which need several waves per SIMD in
+  // flight to reach the LDS rate (MI355X_MICROARCH.md, LDS); per tile a wave reads the K tile (16 KB) + its dS (4 KB) for 16 MFMAs
+  constexpr int NW = 8, BM = NW * 32, BN = 64, CPR = D / 8;
+  constexpr int ROW_BYTES = D * 2, TILE_BYTES = BN * ROW_BYTES, DB = D / 32;
+  constexpr int DS_WAVE = 2 * 2048;        // per wave and tile: the two 32-key sub-tiles of its 32 rows (contiguous in the workspace)
+  constexpr int DS_BUF = NW * DS_WAVE;
+  constexpr int OFF_DS = 2 * TILE_BYTES;   // LDS: K0 | K1 | dS0 | dS1
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char FA_LDS* lds = (char FA_LDS*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+
+  int b, h, m_block;
+  {
+    const int w = xcd_interleave(blockIdx.x, p.q_units, p.q_unit_size, p.q_unit_hpx);
+    if (w < 0) return;
+    const int bh = w / p.nmb;
+    const int mbr = w - bh * p.nmb;
+    m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
+    b = bh / p.h;
+    h = bh - b * p.h;
+  }
+  const int hk = h / p.hk_ratio;
+  const int sq = p.sq, sk = p.sk;
+  const int m0 = m_block * BM;
+  if (m0 >= sq) return;
+  const E* __restrict__ kp = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
+  const int shift = sk - sq;
+  const int blk_last = min(m0 + BM, sq) - 1;
+  int kmax = sk - 1, kmin = 0;
+  if (p.wr >= 0) kmax = min(kmax, blk_last + shift + p.wr);
+  if (p.wl >= 0) kmin = max(0, m0 + shift - p.wl);
+  const int n_min = kmin / BN;
+  const int n_max = (kmax >= kmin) ? (kmax / BN + 1) : n_min;
+  const int w_row0 = m0 + wave * 32;
+  const bool wave_valid = w_row0 < sq;
+  const E* __restrict__ ds_row = (const E*)p.ds_ws + (((((int64_t)b * p.h + h) * p.ds_nq32) + (w_row0 >> 5)) * p.ds_nk32 << 10) + lane * 8;
+
+  constexpr int RPD = 1024 / ROW_BYTES, NDMA = TILE_BYTES / 1024, DPW = NDMA / NW;
+  static_assert(NDMA % NW == 0 && DPW >= 1, "tile does not divide over the waves");
+  auto load_tile = [&](int n, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int idx = wave * DPW + i;
+      const int row = idx * RPD + lane / CPR;
+      const int c = (lane % CPR) ^ swz16<D>(row);
+      const int key = min(n * BN + row, sk - 1);   // rows past the last key: clamped copies, their dS is zero
+      lds_dma_16B(kp + (int64_t)key * p.k_rs + c * 8, lds + buf * TILE_BYTES + idx * 1024);
+    }
+    if (wave_valid) {
+      const E* src = ds_row + ((int64_t)(2 * n) << 10);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (2 * n + (j >> 1) < p.ds_nk32) lds_dma_16B(src + j * 512, lds + OFF_DS + buf * DS_BUF + wave * DS_WAVE + j * 1024);
+    }
+  };
+
+  // transposed K fragments (as fa_bwd_dq_kernel) and transposed dS fragments
+  const int tr_i = lane & 15, tr_half = (lane >> 4) & 1, tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
+  int tr_base[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int row = 8 * s2 + 4 * hi + tr_rr;
+    tr_base[s2] = tile_off<D>(row, 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
+  }
+  // dS sub-tile image: half (queries 16*tr_half ..) * 1024 + slot(key = 16t + 8s + 4hi + rr, writer half = cc & 1) * 16 + (cc >> 1) * 8
+  const int ds_lane = tr_half * 1024 + hi * 128 + (tr_cc & 1) * 64 + tr_rr * 16 + (tr_cc >> 1) * 8 + OFF_DS + wave * DS_WAVE;
+
+  f32x16 dq_acc[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq_acc[i][r] = 0.f;
+
+  if (n_min < n_max) {
+    load_tile(n_min, 0);
+    lds_dma_wait_all();
+    __syncthreads();
+  }
+  auto tile = [&](auto curc, int n) __attribute__((always_inline)) {
+    constexpr int cur = decltype(curc)::value;
+    if (n + 1 < n_max) load_tile(n + 1, cur ^ 1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int k0 = n * BN + 32 * kb;
+      if (!(wave_valid && ds_tile_active(w_row0, k0, sq, sk, shift, p.wl, p.wr))) continue;
+      V8 f[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int a = ds_lane + cur * DS_BUF + kb * 2048 + t * 512;
+        const s16x4 lo = lds_read_tr16(lds + a), hi4 = lds_read_tr16(lds + a + 256);
+        f[t] = combine_tr<V8>(lo, hi4);
+      }
+      constexpr int NOPS = 2 * DB, PFT = 3;
+      s16x4 tlo[PFT], thi[PFT];
+      auto rd = [&](int i) __attribute__((always_inline)) {
+        const int db = i % DB, t = i / DB;
+        const int base = cur * TILE_BYTES + kb * 32 * ROW_BYTES + 16 * t * ROW_BYTES;
+        tlo[i % PFT] = lds_read_tr16(lds + base + (tr_base[0] ^ (db << 6)));
+        thi[i % PFT] = lds_read_tr16(lds + base + (tr_base[1] ^ (db << 6)));
+      };
+#pragma unroll
+      for (int i = 0; i < PFT - 1; ++i) rd(i);
+#pragma unroll
+      for (int i = 0; i < NOPS; ++i) {
+        if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
+        dq_acc[i % DB] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), f[i / DB], dq_acc[i % DB]);
+      }
+    }
+    lds_dma_wait_all();
+    __syncthreads();
+  };
+  for (int n = n_min; n < n_max; n += 2) {
+    tile(ICw<0>{}, n);
+    if (n + 1 < n_max) tile(ICw<1>{}, n + 1);
+  }
+
+  if (!wave_valid) return;
+  E* dqtile = (E*)p.dq + (int64_t)b * p.dq_bs + (int64_t)w_row0 * p.dq_rs + (int64_t)h * p.dq_hs;
+  store_tile_via_lds<E, D>(lds + wave * 32 * (ROW_BYTES + 16), dq_acc, p.scale, dqtile, p.dq_rs, sq - w_row0, lane);
+}
+
+template <typename E, int D>
+static int launch_bwd_dq_ds_t(const BwdK& p, hipStream_t stream) {
+  constexpr int LOOP = 2 * 64 * D * 2 + 2 * 8 * 4096, STAGE_OUT = 256 * (D * 2 + 16);
+  constexpr int smem = LOOP > STAGE_OUT ? LOOP : STAGE_OUT;
+  auto kern = fa_bwd_dq_ds_kernel<E, D>;
+  static std::atomic<unsigned long long> attr_mask{0};
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem) != 0) return -1;
+  const long long total = units_grid(p.q_units, p.q_unit_size);
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), smem, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// dQ pass of the 5-contraction backward (fixed-length batches, p.ds_ws filled by the dK/dV kernel, nmb sized for 256 rows)
+int launch_bwd_dq_ds(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
+  if (!p.ds_ws || p.cu_q || p.cu_k) return -2;
+  if (dtype_bf16) {
+    if (d == 128) return launch_bwd_dq_ds_t<__bf16, 128>(p, stream);
+    if (d == 64) return launch_bwd_dq_ds_t<__bf16, 64>(p, stream);
+  } else {
+    if (d == 128) return launch_bwd_dq_ds_t<_Float16, 128>(p, stream);
+    if (d == 64) return launch_bwd_dq_ds_t<_Float16, 64>(p, stream);
+  }
+  return -2;
+}
+
+template <typename E, int D>
+static int launch_bwd_dq_w64_t(const BwdK& p, hipStream_t stream) {
+  constexpr int TILE = 64 * D * 2, RINGS = 2 * 3 * TILE, STAGE_IN = 2 * 256 * D * 2, STAGE_OUT = 256 * (D * 2 + 16);
+  constexpr int smem = (RINGS > STAGE_IN ? (RINGS > STAGE_OUT ? RINGS : STAGE_OUT) : (STAGE_IN > STAGE_OUT ? STAGE_IN : STAGE_OUT));
+  auto kern = fa_bwd_dq_w64_kernel<E, D>;
+  static std::atomic<unsigned long long> attr_mask{0};
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
+  const long long total = p.q_list ? (long long)p.q_bound * p.h : units_grid(p.q_units, p.q_unit_size);
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), smem, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// 4 waves x 64 query rows per workgroup (the caller sized nmb / the work list for 256-row blocks).  Plain attention only;
+// -2 = not covered, the caller falls back to fa_bwd_dq_kernel<.., 8, ..> on the same blocks.
+int launch_bwd_dq_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
+  if (p.softcap > 0.f || p.alibi != nullptr || p.rng != nullptr) return -2;
+  const uint64_t span = ((uint64_t)(p.sk > 0 ? p.sk : 1) + 128) * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u;
+  if (span >= (1ull << 32)) return -2;   // buffer addressing: 32-bit byte offsets from the (batch, kv-head) base
+  if (d != 128) return -2;
+  return dtype_bf16 ? launch_bwd_dq_w64_t<__bf16, 128>(p, stream) : launch_bwd_dq_w64_t<_Float16, 128>(p, stream);
+}
+
+}  // namespace fa

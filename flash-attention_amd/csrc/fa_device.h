@@ -150,6 +150,31 @@ FA_DEVINL void store_tile_via_lds(char FA_LDS* stage, const f32x16 (&acc)[D / 32
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging rows may be rewritten by the caller's next tile
 }
 
+// Unified LDS tile layout (rows of D 16-bit elements, 16-B chunks XOR-swizzled) that is
+// conflict-free for both access patterns used on the same tile:
+//   - ds_read_b128 operand rows (16 distinct rows per lane group, same logical chunk),
+//   - ds_read_b64_tr_b16 (a half-wave reads 4 consecutive rows x 64 contiguous logical bytes).
+template <int D> FA_DEVINL int swz16(int row) {
+  return D >= 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+}
+template <int D> FA_DEVINL int tile_off(int row, int chunk) { return row * (D * 2) + ((chunk ^ swz16<D>(row)) << 4); }
+
+// ---- dS spill (BwdK::ds_ws) ------------------------------------------------------------------------------------------
+// Does the dK/dV kernel compute (and write) the dS sub-tile of queries [q0, q0+32) x keys [k0, k0+32)?  The dQ contraction
+// reads exactly the sub-tiles for which this holds -- anything else in the workspace is uninitialised.
+FA_DEVINL bool ds_tile_active(int q0, int k0, int sq, int sk, int shift, int wl, int wr) {
+  if (q0 >= sq || k0 >= sk) return false;
+  const int k1 = min(k0 + 31, sk - 1);
+  if (wr >= 0 && k0 > q0 + 31 + shift + wr) return false;
+  if (wl >= 0 && k1 < q0 + shift - wl) return false;
+  return true;
+}
+// Image of a sub-tile: two 1-KiB halves (queries 0-15 / 16-31), each the dK/dV kernel's B-operand fragment (lane = key,
+// lane half hi, 8 queries acc_row(j, hi)) stored one 16-byte slot per lane.  The slot order is chosen for the reader, which
+// pulls the transposed fragment (lane = query) out of LDS with ds_read_b64_tr_b16: the 16 lanes of one transpose group vary
+// key bits 0-1, hi and the 8-byte half of the slot -- with those in address bits 3-6 the group covers all 32 banks once.
+FA_DEVINL int ds_slot(int key, int hi) { return (key & 3) | (hi << 2) | ((key >> 2) << 3); }
+
 // Score-transform features of the non-plain kernel variants (template int FEAT): softcap, ALiBi, dropout.  A variant
 // with exactly one feature carries only that feature's code and registers; FEAT_ALL checks the parameters at run time.
 enum { FEAT_NONE = 0, FEAT_CAP = 1, FEAT_ALIBI = 2, FEAT_DROP = 4, FEAT_ALL = 7 };

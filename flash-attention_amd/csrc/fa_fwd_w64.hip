@@ -26,7 +26,8 @@
 #include "fa_kernel_params.h"
 #include "fa_launch.h"
 #include "fa_fwd_w64_regs.h"
-#include <utility>
+#define FA_W64_CLOB FA_W64_ACC_CLOBBERS
+#include "fa_w64_asm.h"
 
 #ifndef FA_W64_ABL
 #define FA_W64_ABL 0  // timing ablations of the steady-state step, bit mask (results become wrong): tools/ablate_w64.sh
@@ -39,10 +40,6 @@ namespace fa {
 
 template <int D> FA_DEVINL constexpr int k_swz_w(int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); }
 template <int D> FA_DEVINL constexpr int v_swz_w(int row) { return D == 128 ? (row & 3) : ((row >> 1) & 1); }
-
-template <int N> using ICw = std::integral_constant<int, N>;
-template <int... I, class F> FA_DEVINL void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(ICw<I>{}), ...); }
-template <int N, class F> FA_DEVINL void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // ---- MFMA in inline asm: operand register classes are part of the design (see header) ----------------------------
 // O and the Q fragments are NOT C++ values: they live in accumulator registers named literally in the asm (fa_fwd_w64_regs.h).
@@ -71,49 +68,6 @@ template <typename E, int T> FA_DEVINL void mfma_o_acc(u32x4 a, u32x4 b) {
   else
     asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(16 * T), "i"(16 * T + 15) : FA_W64_ACC_CLOBBERS);
 }
-// hipcc neither sees the asm MFMAs' latency nor pads their hazards: an MFMA result may be read by a non-MFMA instruction
-// only 12+ wait states after issue.  The hand-placed step keeps that distance by construction; every other reader drains.
-// The drained VGPR tuples are tied operands of the drain: a "memory" clobber does not order register-only instructions, so
-// without the data dependence hipcc may schedule a reader above the nops.
-FA_DEVINL void mfma_drain_v(f32x16& a, f32x16& b) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b)); }
-FA_DEVINL void mfma_drain_acc() { asm volatile("s_nop 15\n\ts_nop 3" ::: FA_W64_ACC_CLOBBERS); }   // volatile asm keeps its order among the asm accessors
-// accumulator register N: write / read / multiply by a per-lane factor (N is a compile-time constant)
-template <int N> FA_DEVINL void acc_write(float x) { asm volatile("v_accvgpr_write_b32 a[%c1], %0" : : "v"(x), "i"(N) : FA_W64_ACC_CLOBBERS); }
-template <int N> FA_DEVINL float acc_read() { float x; asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "i"(N) : FA_W64_ACC_CLOBBERS); return x; }
-template <int N> FA_DEVINL void acc_scale(float f) {
-  float t;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a[%c2], %0" : "=&v"(t) : "v"(f), "i"(N) : FA_W64_ACC_CLOBBERS);
-}
-template <int N0, int... I> FA_DEVINL void acc_scale_range(float f, std::integer_sequence<int, I...>) { (acc_scale<N0 + I>(f), ...); }
-template <int N0, int... I> FA_DEVINL void acc_zero_range(std::integer_sequence<int, I...>) { (acc_write<N0 + I>(0.f), ...); }
-// (elements are copied to scalars first: __builtin_bit_cast applied directly to an ext_vector element lvalue reads element 0)
-template <int N0> FA_DEVINL void acc_read_tuple(f32x16& x) {
-  x[0] = acc_read<N0 + 0>(); x[1] = acc_read<N0 + 1>(); x[2] = acc_read<N0 + 2>(); x[3] = acc_read<N0 + 3>();
-  x[4] = acc_read<N0 + 4>(); x[5] = acc_read<N0 + 5>(); x[6] = acc_read<N0 + 6>(); x[7] = acc_read<N0 + 7>();
-  x[8] = acc_read<N0 + 8>(); x[9] = acc_read<N0 + 9>(); x[10] = acc_read<N0 + 10>(); x[11] = acc_read<N0 + 11>();
-  x[12] = acc_read<N0 + 12>(); x[13] = acc_read<N0 + 13>(); x[14] = acc_read<N0 + 14>(); x[15] = acc_read<N0 + 15>();
-}
-template <int N0> FA_DEVINL void acc_write_frag(u32x4 w) {
-  const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-  acc_write<N0 + 0>(__builtin_bit_cast(float, w0)); acc_write<N0 + 1>(__builtin_bit_cast(float, w1));
-  acc_write<N0 + 2>(__builtin_bit_cast(float, w2)); acc_write<N0 + 3>(__builtin_bit_cast(float, w3));
-}
-// single-instruction float helpers (clang would canonicalise the asm MFMA outputs in front of fmaxf)
-FA_DEVINL float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-FA_DEVINL float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// max of a value with the one held by lane (l ^ 32): copy, swap halves, max -- one statement so that the permlane hazard pad
-// (2 wait states between a VALU write of an operand and v_permlane32_swap) sits inside it; no canonicalising v_max
-FA_DEVINL float vhalf_max(float x) {
-  float t;
-  asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(x), "=&v"(t));
-  return x;
-}
-// NOTE on asm helpers: hipcc's hazard recogniser does not look inside an asm statement.  gfx950 needs one wait state between
-// a transcendental (v_exp_f32) and a non-transcendental VALU that consumes its result; an asm v_add_f32 placed right behind
-// the v_exp that feeds it reads a stale register (seen as run-to-run different row sums).  So nothing that consumes a v_exp
-// result is asm: the row sums are plain C++ adds, and this translation unit is built with -fno-slp-vectorize (build.py) --
-// the SLP vectoriser otherwise packs them into v_pk_add_f32 (slower beside MFMAs) and moves them out of their gaps.
-
 template <typename E, int D>
 __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   using T = ElemTraits<E>;

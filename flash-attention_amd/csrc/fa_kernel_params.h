@@ -92,6 +92,11 @@ struct BwdK {
   const uint64_t* rng;       // dropout, as in FwdK
   uint32_t drop_thr8;
   float rp_keep;
+  // dS spill (5-contraction backward): the dK/dV kernel writes every dS sub-tile (32 queries x 32 keys, 2 KB, rounded to the
+  // input dtype) here and the dQ pass is one contraction dS.K; NULL = the dQ kernel recomputes S, dP and dS (7 contractions)
+  void* ds_ws;               // [b][h][ds_nq32][ds_nk32][2 KB]
+  int32_t ds_nq32, ds_nk32;  // 32-row / 32-key blocks per sequence
+  int32_t dq_nw;             // dQ schedule: 4 / 8 waves x 32 rows, 64 = 4 waves x 64 rows (nmb and the query work list are sized for it)
 };
 
 }  // namespace fa

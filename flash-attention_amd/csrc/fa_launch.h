@@ -13,8 +13,10 @@ struct Knobs {
   float rescale_thr;   // FA_RESCALE_THR: deferred-rescale threshold in log2 units (default 8; 0 = the reference's rule)
   int varlen_list;     // FA_VARLEN_LIST: 0 = always the dense varlen grid
   int il_sched;        // FA_IL_SCHED: 0 = compiler-ordered pipelined step, else hand-placed slots
-  int bwd_dq_nw;       // FA_BWD_DQ_NW: waves per dQ workgroup (4 or 8)
-  int bwd_mode;        // FA_BWD_MODE: 0 = heuristic
+  int bwd_dq_nw;       // FA_BWD_DQ_NW: 0 = heuristic; recomputing dQ kernel of 4 or 8 waves x 32 rows, 64 = 4 waves x 64 rows (fa_bwd_w64.hip)
+  int bwd_mode;        // FA_BWD_MODE: 0 / 1 = the dQ kernel recomputes S, dP, dS (7 contractions, no O(S^2) scratch); 2 = the dK/dV kernel spills
+                       // dS and dQ is one contraction (5), fixed-length batches whose dS workspace fits FA_BWD_DS_CAP_MB
+  int bwd_ds_cap_mb;   // FA_BWD_DS_CAP_MB: largest dS workspace FA_BWD_MODE=2 asks for (default 8192)
   int lds_pad;         // FA_IL_LDS_PAD (occupancy experiments, FA_IL_EXPERIMENTS builds only)
   int w64_persist;     // FA_W64_PERSIST: 0 = one workgroup per block (no persistent walk) in the 64-rows-per-wave forward
   int strict;          // FA_STRICT=1: the reference's numerics contract -- rescale on any growth of a row maximum (threshold 0) and
@@ -30,7 +32,7 @@ struct LastSchedule {
   int fwd_splits;   // split-KV factor
   int fwd_list;     // 1 = varlen work list
   int d, bf16;
-  int bwd_dq_nw, bwd_list;
+  int bwd_dq_nw, bwd_list, bwd_spill;
   char name[96];
 };
 LastSchedule& last_schedule();
@@ -117,7 +119,9 @@ int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_delta(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
-int bwd_block_m();   // query rows per dQ workgroup
+int launch_bwd_dq_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
+int launch_bwd_dq_ds(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);    // fa_bwd_w64.hip: dQ = dS.K from the spilled dS   // fa_bwd_w64.hip; -2 = shape / feature not covered
+int bwd_block_m(int dq_nw);   // query rows per dQ workgroup of schedule dq_nw (BwdK::dq_nw)
 int bwd_block_n(int d);   // key rows per dK/dV workgroup (256; 128 for head dim 256)
 
 }  // namespace fa
