@@ -36,6 +36,9 @@
 #ifndef FA_DKDV_SPLIT
 #define FA_DKDV_SPLIT 0  // experiment: 1 = head dims <= 128 also run 4-wave workgroups of 128 keys with 32-query tiles, two per CU
 #endif
+#ifndef FA_DKDV_ROT
+#define FA_DKDV_ROT 0  // experiment: 1 = waves 4-7 of the plain D <= 128 dK/dV kernel run their phases rotated by one (see the kernel);
+#endif                 // measured no faster than lock step (profiles/r02_bwd_schedules.txt), so off
 #ifndef FA_DKDV_ABL
 #define FA_DKDV_ABL 0  // timing ablations of the dK/dV kernel (results become wrong; tools/ablate_dkdv.sh): 1 no exp2, 2 row-major LDS
 #endif                 // operands read once per sub-tile, 4 transposed operands read once, 8 no DMA wait / barrier per item,
@@ -253,178 +256,231 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   const int aux_lane = OFF_AUX + 4 * hi * 4;
   auto opaque = [](int x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); return x; };
 
-  auto item = [&](auto curc, int it) __attribute__((always_inline)) {
-    constexpr int cur = decltype(curc)::value;
-    const bool has_next = it + 1 < n_items;
-    if (has_next && !((FA_DKDV_ABL & 64) && it > 0)) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
-    const int m0 = item_m0(it);
+  // A sub-block (32 queries x this wave's 32 keys) goes through three phases: P1 = the S / dP contractions (16 MFMAs), SM = the
+  // softmax arithmetic (VALU: P, dS, packing), P2 = the dV / dK contractions (16 MFMAs).  The two waves that share a SIMD
+  // (waves w and w + 4) start every item together and sit in the same phase all the time; timing ablations give
+  // time = MFMA time + everything else (profiles/r02_bwd_schedules.txt).  FA_DKDV_ROT=1 makes the upper four waves run the
+  // ROTATED loop SM, P2, P1(next sub-block), one phase ahead, with two barriers per item ("next tile landed" before the last
+  // phase, "this tile is free" after it).  Measured: 1494 | 2394 us against 1431 | 2278 us in lock step (causal | full,
+  // config 3) -- the vector phase of one wave does not hide under the matrix phase of its partner, so the default is lock step.
+  f32x16 s, dp;              // S / dP of a sub-block between P1 and SM (the rotated waves carry them across the barriers)
+  V8 pfrag[2], dsfrag[2];    // P / dS between SM and P2
+  constexpr int NQB = BMQ / 32;
+  constexpr bool ROT_OK = (NW == 8 && NQB == 2 && FEAT == 0) && FA_DKDV_ROT;  // the feature variants have no registers to carry S / dP across the barriers
+  const bool rot = ROT_OK && wave >= NW / 2;
+  auto sub_active = [&](int it, int qb) __attribute__((always_inline)) {
+    return it < n_items && ds_tile_active(item_m0(it) + 32 * qb, wk0, sq, sk, shift, p.wl, p.wr);
+  };
+
+  // P1: S[query][key] = Q.K^T ; dP[query][key] = dO.V^T   (column = key = lane).  The two accumulation chains alternate
+  // (op j = k-step j/2 of S for even j, of dP for odd j) and the LDS operands are read PF-1 ops ahead.
+  auto p1 = [&](auto bufc, auto qbc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value, qb = decltype(qbc)::value;
+    constexpr int QB_OFF = OFF_Q + buf * QT_BYTES, DOB_OFF = OFF_DO + buf * QT_BYTES, sub = qb * 32 * ROW_BYTES;
+    constexpr int NOPS = 2 * KS, PF = FA_BWD_PF;
+    u32x4 ra[PF], rb[2];
+    const int k0p = opaque(k0), kv0p = opaque(kv0);
+    auto rd = [&](int j) __attribute__((always_inline)) {
+      const int ks = j >> 1;
+      if ((FA_DKDV_ABL & 2) && j >= 2) { ra[j % PF] = ra[(j & 1) % PF]; if (j & 1) rb[ks & 1] = rb[0]; return; }
+      if ((j & 1) == 0) {
+        ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (QB_OFF + sub) + (k0p ^ (ks << 5)));
+      } else {
+        ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (DOB_OFF + sub) + (k0p ^ (ks << 5)));
+        rb[ks & 1] = *(const u32x4 FA_LDS*)(lds + (kv0p ^ (ks << 5)));
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < PF - 1; ++j) rd(j);
+#pragma unroll
+    for (int j = 0; j < NOPS; ++j) {
+      if (j + PF - 1 < NOPS) rd(j + PF - 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this op's MFMA
+      const int ks = j >> 1;
+      f32x16 c = (j & 1) ? dp : s;
+      if (j < 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+      }
+      if ((FA_DKDV_ABL & 16) && j >= 2) { if ((j & 1) == 0) s = c; else dp = c; continue; }
+      if ((j & 1) == 0) s = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), kf[ks], c);
+      else dp = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), bitcast_u32x4<V8>(rb[ks & 1]), c);
+    }
+  };
+
+  // SM: score transform, mask, P = exp2(S*c - LSE*log2e), dS = P * (dP - delta); rows are queries acc_row(r,hi)
+  auto sm = [&](auto bufc, auto qbc, int it) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value, qb = decltype(qbc)::value;
+    const int q0 = item_m0(it) + 32 * qb;
     const bool use_alibi = F_ALIBI && (FEAT != FEAT_ALL || p.alibi != nullptr);
     const bool use_cap = F_CAP && (FEAT != FEAT_ALL || p.softcap > 0.f);
     const float slope = use_alibi ? p.alibi[(int64_t)b * p.alibi_bs + item_head(it)] : 0.f;
     const bool drop = F_DROP && (FEAT != FEAT_ALL || p.rng != nullptr);
     // stream key of this (batch, query head) plus this lane's key group; rows are added per 4-query group below
     const uint32_t drop_key = drop ? drop_bh_key(p.rng, b * p.h + item_head(it)) : 0u;
-    constexpr int QB_OFF = OFF_Q + cur * QT_BYTES, DOB_OFF = OFF_DO + cur * QT_BYTES;
 
-    int ds_stores = 0;   // dS spill stores issued by this wave in this item (wave-uniform)
+    f32x16 dcap;  // d(softcap*tanh(x/softcap))/dx = 1 - tanh^2 (reference flash_bwd_kernel.h:588 / utils.h:395-409)
+    if constexpr (XFORM) {
+      const float rcap = use_cap ? 1.f / p.softcap : 0.f;
 #pragma unroll
-    for (int qb = 0; qb < BMQ / 32; ++qb) {
-      const int q0 = m0 + 32 * qb;
-      if (!ds_tile_active(q0, wk0, sq, sk, shift, p.wl, p.wr)) continue;
-      const int sub = qb * 32 * ROW_BYTES;
-
-      // S[query][key] = Q.K^T ; dP[query][key] = dO.V^T   (column = key = lane).  The two accumulation chains alternate
-      // (op j = k-step j/2 of S for even j, of dP for odd j) and the LDS operands are read PF-1 ops ahead.
-      f32x16 s, dp;
-      {
-        constexpr int NOPS = 2 * KS, PF = FA_BWD_PF;
-        u32x4 ra[PF], rb[2];
-        const int k0p = opaque(k0), kv0p = opaque(kv0);
-        auto rd = [&](int j) __attribute__((always_inline)) {
-          const int ks = j >> 1;
-          if ((FA_DKDV_ABL & 2) && j >= 2) { ra[j % PF] = ra[(j & 1) % PF]; if (j & 1) rb[ks & 1] = rb[0]; return; }
-          if ((j & 1) == 0) {
-            ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (QB_OFF + sub) + (k0p ^ (ks << 5)));
-          } else {
-            ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (DOB_OFF + sub) + (k0p ^ (ks << 5)));
-            rb[ks & 1] = *(const u32x4 FA_LDS*)(lds + (kv0p ^ (ks << 5)));
+      for (int r = 0; r < 16; ++r) {
+        const int qrow = q0 + acc_row(r, hi);
+        float y = s[r] * p.scale;
+        if constexpr (F_CAP) {
+          dcap[r] = 1.f;
+          if (use_cap) {
+            const float t = fast_tanh(y * rcap);
+            y = p.softcap * t;
+            dcap[r] = 1.f - t * t;
           }
-        };
-#pragma unroll
-        for (int j = 0; j < PF - 1; ++j) rd(j);
-#pragma unroll
-        for (int j = 0; j < NOPS; ++j) {
-          if (j + PF - 1 < NOPS) rd(j + PF - 1);
-          __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this op's MFMA
-          const int ks = j >> 1;
-          f32x16 c = (j & 1) ? dp : s;
-          if (j < 2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = 0.f;
-          }
-          if ((FA_DKDV_ABL & 16) && j >= 2) { if ((j & 1) == 0) s = c; else dp = c; continue; }
-          if ((j & 1) == 0) s = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), kf[ks], c);
-          else dp = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), bitcast_u32x4<V8>(rb[ks & 1]), c);
         }
+        if constexpr (F_ALIBI) {
+          if (use_alibi) y -= slope * fabsf((float)(qrow + shift - my_key));
+        }
+        s[r] = y;
       }
-
-      f32x16 dcap;  // d(softcap*tanh(x/softcap))/dx = 1 - tanh^2 (reference flash_bwd_kernel.h:588 / utils.h:395-409)
-      if constexpr (XFORM) {
-        const float rcap = use_cap ? 1.f / p.softcap : 0.f;
+    }
+    bool need_mask = false;
+    if (p.wr >= 0) need_mask = need_mask || (wk1 > q0 + shift + p.wr);
+    if (p.wl >= 0) need_mask = need_mask || (wk0 < q0 + 31 + shift - p.wl);
+    if (need_mask) {
+      const int rel_lo = (p.wr >= 0) ? (my_key - shift - p.wr - q0 - 4 * hi) : -(1 << 30);
+      const int rel_hi = (p.wl >= 0) ? (my_key - shift + p.wl - q0 - 4 * hi) : (1 << 30);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int qrow = q0 + acc_row(r, hi);
-          float y = s[r] * p.scale;
-          if constexpr (F_CAP) {
-            dcap[r] = 1.f;
-            if (use_cap) {
-              const float t = fast_tanh(y * rcap);
-              y = p.softcap * t;
-              dcap[r] = 1.f - t * t;
-            }
-          }
-          if constexpr (F_ALIBI) {
-            if (use_alibi) y -= slope * fabsf((float)(qrow + shift - my_key));
-          }
-          s[r] = y;
-        }
-      }
-      bool need_mask = false;
-      if (p.wr >= 0) need_mask = need_mask || (wk1 > q0 + shift + p.wr);
-      if (p.wl >= 0) need_mask = need_mask || (wk0 < q0 + 31 + shift - p.wl);
-      if (need_mask) {
-        const int rel_lo = (p.wr >= 0) ? (my_key - shift - p.wr - q0 - 4 * hi) : -(1 << 30);
-        const int rel_hi = (p.wl >= 0) ? (my_key - shift + p.wl - q0 - 4 * hi) : (1 << 30);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int off = acc_row(r, 0);
-          s[r] = ((off >= rel_lo) && (off <= rel_hi)) ? s[r] : -INFINITY;
-        }
-      }
-
-      // P = exp2(S*c - LSE*log2e); dS = P * (dP - delta): rows are queries acc_row(r,hi)
-      V8 pfrag[2], dsfrag[2];
-      const int auxp = opaque(aux_lane);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (cur * 2 * BMQ + qb * 32 + 8 * g) * 4);
-        const f32x4 d4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (cur * 2 * BMQ + qb * 32 + 8 * g) * 4 + BMQ * 4);
-        // Dropout: the 4 lanes of a quad hold the 4 keys of one key group; lane a hashes query row a of this 4-row
-        // group (4 bytes = those 4 keys) and the quad exchanges words, so each lane reads its key's byte of every row.
-        uint32_t hq = 0u;
-        if constexpr (F_DROP) {
-          if (drop) hq = drop_bytes(drop_key, q0 + 8 * g + 4 * hi + (ki & 3), my_key >> 2);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g + j;
-          const float pv = (FA_DKDV_ABL & 1) ? __builtin_fmaf(s[r], cs, -l4[j]) : fast_exp2(__builtin_fmaf(s[r], cs, -l4[j]));
-          float pkeep = pv, dpe = dp[r];
-          if constexpr (F_DROP) {
-            if (drop) {  // Z = keep / (1 - p): dV uses P*Z (the 1/(1-p) is applied to dV at the end), dS = P*(dP*Z - delta)
-              const uint32_t hj = quad_bcast(hq, j);
-              const bool keep = ((hj >> (8 * (ki & 3))) & 0xffu) <= p.drop_thr8;
-              pkeep = keep ? pv : 0.f;
-              dpe = keep ? dp[r] * p.rp_keep : 0.f;
-            }
-          }
-          float dsv = pv * (dpe - d4[j]);
-          if constexpr (F_CAP) dsv *= dcap[r];
-          pfrag[r >> 3][r & 7] = (E)pkeep;
-          dsfrag[r >> 3][r & 7] = (E)dsv;
-        }
-      }
-
-      if (p.ds_ws) {  // dS spill: this sub-tile's fragments, one 16-byte slot per lane (fa_device.h ds_slot), for the dQ contraction
-        if (!key_valid) {  // keys past the end (their K rows are clamped copies over there): no contribution
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { dsfrag[0][j] = (E)0.f; dsfrag[1][j] = (E)0.f; }
-        }
-        E* dst = (E*)p.ds_ws + (((((int64_t)b * p.h + item_head(it)) * p.ds_nq32 + (q0 >> 5)) * p.ds_nk32 + (wk0 >> 5)) << 10) + ds_slot(ki, hi) * 8;
-        *(u32x4*)dst = __builtin_bit_cast(u32x4, dsfrag[0]);
-        *(u32x4*)(dst + 512) = __builtin_bit_cast(u32x4, dsfrag[1]);
-        ds_stores += 2;
-      }
-
-      // dV^T[d][key] += dO^T[d][query] . P[query][key] ;  dK^T[d][key] += Q^T[d][query] . dS[query][key]
-      // op i: source = dO (even) / Q (odd), d-block (i>>1) % DB, query half t = i / (2*DB); transpose reads PFT-1 ops ahead
-      {
-        constexpr int NOPS = 4 * DB, PFT = FA_BWD_PFT;
-        s16x4 tlo[PFT], thi[PFT];
-        const int t0p = opaque(tr_base[0]), t1p = opaque(tr_base[1]);
-        auto rd = [&](int i) __attribute__((always_inline)) {
-          const int db = (i >> 1) % DB, t = i / (2 * DB);
-          if ((FA_DKDV_ABL & 4) && i >= 2) { tlo[i % PFT] = tlo[(i & 1) % PFT]; thi[i % PFT] = thi[(i & 1) % PFT]; return; }
-          const int base = ((i & 1) ? QB_OFF : DOB_OFF) + sub + 16 * t * ROW_BYTES;
-          tlo[i % PFT] = lds_read_tr16(lds + base + (t0p ^ (db << 6)));
-          thi[i % PFT] = lds_read_tr16(lds + base + (t1p ^ (db << 6)));
-        };
-#pragma unroll
-        for (int i = 0; i < PFT - 1; ++i) rd(i);
-#pragma unroll
-        for (int i = 0; i < NOPS; ++i) {
-          if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
-          __builtin_amdgcn_sched_barrier(0);
-          const int db = (i >> 1) % DB, t = i / (2 * DB);
-          if ((FA_DKDV_ABL & 32) && i >= 2) continue;
-          if ((i & 1) == 0) dv_acc[db] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), pfrag[t], dv_acc[db]);
-          else dk_acc[db] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), dsfrag[t], dk_acc[db]);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int off = acc_row(r, 0);
+        s[r] = ((off >= rel_lo) && (off <= rel_hi)) ? s[r] : -INFINITY;
       }
     }
 
-    if (has_next) store_item(cur ^ 1);
-    // the next item's DMA loads were issued before this item's dS stores, and vmcnt retires in issue order: wait for the
-    // loads only, the (0, 2 or 4) stores stay in flight under the next item
-    if (FA_DKDV_ABL & 8) return;
-    if (ds_stores == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (ds_stores == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else lds_dma_wait_all();
-    __syncthreads();
+    const int auxp = opaque(aux_lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4);
+      const f32x4 d4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4 + BMQ * 4);
+      // Dropout: the 4 lanes of a quad hold the 4 keys of one key group; lane a hashes query row a of this 4-row
+      // group (4 bytes = those 4 keys) and the quad exchanges words, so each lane reads its key's byte of every row.
+      uint32_t hq = 0u;
+      if constexpr (F_DROP) {
+        if (drop) hq = drop_bytes(drop_key, q0 + 8 * g + 4 * hi + (ki & 3), my_key >> 2);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * g + j;
+        const float pv = (FA_DKDV_ABL & 1) ? __builtin_fmaf(s[r], cs, -l4[j]) : fast_exp2(__builtin_fmaf(s[r], cs, -l4[j]));
+        float pkeep = pv, dpe = dp[r];
+        if constexpr (F_DROP) {
+          if (drop) {  // Z = keep / (1 - p): dV uses P*Z (the 1/(1-p) is applied to dV at the end), dS = P*(dP*Z - delta)
+            const uint32_t hj = quad_bcast(hq, j);
+            const bool keep = ((hj >> (8 * (ki & 3))) & 0xffu) <= p.drop_thr8;
+            pkeep = keep ? pv : 0.f;
+            dpe = keep ? dp[r] * p.rp_keep : 0.f;
+          }
+        }
+        float dsv = pv * (dpe - d4[j]);
+        if constexpr (F_CAP) dsv *= dcap[r];
+        pfrag[r >> 3][r & 7] = (E)pkeep;
+        dsfrag[r >> 3][r & 7] = (E)dsv;
+      }
+    }
+
+    if (p.ds_ws) {  // dS spill: this sub-tile's fragments, one 16-byte slot per lane (fa_device.h ds_slot), for the dQ contraction
+      if (!key_valid) {  // keys past the end (their K rows are clamped copies over there): no contribution
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dsfrag[0][j] = (E)0.f; dsfrag[1][j] = (E)0.f; }
+      }
+      E* dst = (E*)p.ds_ws + (((((int64_t)b * p.h + item_head(it)) * p.ds_nq32 + (q0 >> 5)) * p.ds_nk32 + (wk0 >> 5)) << 10) + ds_slot(ki, hi) * 8;
+      *(u32x4*)dst = __builtin_bit_cast(u32x4, dsfrag[0]);
+      *(u32x4*)(dst + 512) = __builtin_bit_cast(u32x4, dsfrag[1]);
+    }
   };
-  for (int it = 0; it < n_items; it += 2) {
-    item(std::integral_constant<int, 0>{}, it);
-    if (it + 1 < n_items) item(std::integral_constant<int, 1>{}, it + 1);
+
+  // P2: dV^T[d][key] += dO^T[d][query] . P[query][key] ;  dK^T[d][key] += Q^T[d][query] . dS[query][key]
+  // op i: source = dO (even) / Q (odd), d-block (i>>1) % DB, query half t = i / (2*DB); transpose reads PFT-1 ops ahead
+  auto p2 = [&](auto bufc, auto qbc) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value, qb = decltype(qbc)::value;
+    constexpr int QB_OFF = OFF_Q + buf * QT_BYTES, DOB_OFF = OFF_DO + buf * QT_BYTES, sub = qb * 32 * ROW_BYTES;
+    constexpr int NOPS = 4 * DB, PFT = FA_BWD_PFT;
+    s16x4 tlo[PFT], thi[PFT];
+    const int t0p = opaque(tr_base[0]), t1p = opaque(tr_base[1]);
+    auto rd = [&](int i) __attribute__((always_inline)) {
+      const int db = (i >> 1) % DB, t = i / (2 * DB);
+      if ((FA_DKDV_ABL & 4) && i >= 2) { tlo[i % PFT] = tlo[(i & 1) % PFT]; thi[i % PFT] = thi[(i & 1) % PFT]; return; }
+      const int base = ((i & 1) ? QB_OFF : DOB_OFF) + sub + 16 * t * ROW_BYTES;
+      tlo[i % PFT] = lds_read_tr16(lds + base + (t0p ^ (db << 6)));
+      thi[i % PFT] = lds_read_tr16(lds + base + (t1p ^ (db << 6)));
+    };
+#pragma unroll
+    for (int i = 0; i < PFT - 1; ++i) rd(i);
+#pragma unroll
+    for (int i = 0; i < NOPS; ++i) {
+      if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int db = (i >> 1) % DB, t = i / (2 * DB);
+      if ((FA_DKDV_ABL & 32) && i >= 2) continue;
+      if ((i & 1) == 0) dv_acc[db] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), pfrag[t], dv_acc[db]);
+      else dk_acc[db] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), dsfrag[t], dk_acc[db]);
+    }
+  };
+
+  using Q0 = std::integral_constant<int, 0>;
+  using Q1 = std::integral_constant<int, 1>;
+  // role 0 = every wave in lock step (one barrier per item), 1 = the straight waves of the rotated schedule, 2 = its rotated waves.
+  // The roles are separate loops (one wave-uniform branch around the whole item loop): with the role tested inside the item the
+  // allocator had to agree on one register assignment for S / dP / accumulators at six merge points per item and spilled 246
+  // dwords.  Roles 1 and 2 execute the same two barriers per item.
+  auto item = [&](auto rolec, auto curc, int it) __attribute__((always_inline)) {
+    constexpr int role = decltype(rolec)::value, cur = decltype(curc)::value;
+    using CUR = std::integral_constant<int, cur>;
+    using NXT = std::integral_constant<int, cur ^ 1>;
+    const bool has_next = it + 1 < n_items;
+    if (has_next && !((FA_DKDV_ABL & 64) && it > 0)) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
+    const bool a0 = sub_active(it, 0), a1 = NQB > 1 && sub_active(it, 1);
+    if constexpr (role == 0) {
+      if (a0) { p1(CUR{}, Q0{}); sm(CUR{}, Q0{}, it); p2(CUR{}, Q0{}); }
+      if constexpr (NQB > 1) {
+        if (a1) { p1(CUR{}, Q1{}); sm(CUR{}, Q1{}, it); p2(CUR{}, Q1{}); }
+      }
+      if (has_next) store_item(cur ^ 1);
+      if (FA_DKDV_ABL & 8) return;
+      lds_dma_wait_all();
+      __syncthreads();
+    } else {
+      if constexpr (role == 1) {
+        if (a0) { p1(CUR{}, Q0{}); sm(CUR{}, Q0{}, it); p2(CUR{}, Q0{}); }
+        if (a1) { p1(CUR{}, Q1{}); sm(CUR{}, Q1{}, it); }
+      } else {  // P1 of sub-block 0 ran at the end of the previous item (the first one: before the loop)
+        if (a0) { sm(CUR{}, Q0{}, it); p2(CUR{}, Q0{}); }
+        if (a1) { p1(CUR{}, Q1{}); sm(CUR{}, Q1{}, it); p2(CUR{}, Q1{}); }
+      }
+      if (has_next) store_item(cur ^ 1);
+      if (!(FA_DKDV_ABL & 8)) {
+        lds_dma_wait_all();   // the next item's tile (issued at the top) has landed ...
+        __syncthreads();      // ... for every wave
+      }
+      if constexpr (role == 1) {
+        if (a1) p2(CUR{}, Q1{});
+      } else {
+        if (sub_active(it + 1, 0)) p1(NXT{}, Q0{});
+      }
+      if (!(FA_DKDV_ABL & 8)) __syncthreads();   // every wave is through with this item's tile: the next DMA may overwrite it
+    }
+  };
+  auto run = [&](auto rolec) __attribute__((always_inline)) {
+    using ROLE = decltype(rolec);
+    if constexpr (ROLE::value == 2) {
+      if (sub_active(0, 0)) p1(Q0{}, Q0{});
+    }
+    for (int it = 0; it < n_items; it += 2) {
+      item(ROLE{}, Q0{}, it);
+      if (it + 1 < n_items) item(ROLE{}, Q1{}, it + 1);
+    }
+  };
+  if constexpr (!ROT_OK) {
+    run(Q0{});
+  } else {
+    if (!rot) run(Q1{});
+    else run(std::integral_constant<int, 2>{});
   }
 
   // ---- epilogue: dK = scale * acc, dV = acc; every key row of the block is written (zeros included) --
