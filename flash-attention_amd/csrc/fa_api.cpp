@@ -75,7 +75,11 @@ LastSchedule& last_schedule() {
 }  // namespace fa
 namespace {
 
-bool head_dim_native(int d) { return d == 64 || d == 128 || d == 256; }
+// Head dims with their own kernels (the reference builds the same set: static_switch.h:92-110).  32 / 96 / 192 are "trimmed"
+// variants of the 64 / 128 / 256 kernels (fa_fwd.hip: same LDS pitch, fewer k-steps and output blocks) on the lock-step schedules.
+bool head_dim_trimmed(int d) { return d == 32 || d == 96 || d == 192; }
+bool head_dim_native(int d) { return d == 64 || d == 128 || d == 256 || head_dim_trimmed(d); }
+int head_dim_pitch(int d) { return d <= 64 ? 64 : d <= 128 ? 128 : 256; }  // row pitch of tiles and of split-KV partial rows
 
 // Reference flash_api.cpp:422-427 (+ :155-162): windows at least as wide as the key sequence are
 // unbounded, a single query row needs no causal mask, causal means window_right = 0.
@@ -123,7 +127,7 @@ int choose_splits(const FaFwdParams* a, int& split_tiles) {
 }
 int64_t splitkv_bytes(const FaFwdParams* a, int n_splits) {
   if (n_splits <= 1) return 0;
-  return (int64_t)n_splits * a->b * a->h * a->seqlen_q * (a->d + 1) * (int64_t)sizeof(float);
+  return (int64_t)n_splits * a->b * a->h * a->seqlen_q * (head_dim_pitch(a->d) + 1) * (int64_t)sizeof(float);
 }
 
 // Forward schedule code: 64 = 64-rows-per-wave kernel (fa_fwd_w64.hip, 4 waves, 256-row blocks), 34 / 38 = software-pipelined
@@ -150,7 +154,7 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
 // query rows per workgroup of the schedule the forward will run (the lock-step variants serve softcap / ALiBi / dropout /
 // head dim 256 / split keys)
 int fwd_block_rows(const FaFwdParams* a, int nw, bool split) {
-  if (a->d > 128 || split) return 128;
+  if (a->d > 128 || head_dim_trimmed(a->d) || split) return 128;
   if (nw == 64) return 256;
   if (nw == 34 || nw == 38) return 32 * (nw - 30);  // (the lock-step fallback of a pipelined schedule keeps the wave count)
   return nw == 16 ? 256 : 32 * nw;
@@ -172,7 +176,7 @@ int check_common(int b, int h, int h_k, int d, int dtype, float softcap) {
   if (dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_BF16)
     return fail(FA_ERR_INVALID_ARGUMENT, "FlashAttention only supports fp16 and bf16 data type");
   if (!head_dim_native(d))
-    return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: head dimension %d is not built natively (64, 128, 256); pad to the next one on the host", d);
+    return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: head dimension %d is not built natively (32, 64, 96, 128, 192, 256); pad to the next one on the host", d);
   if (softcap < 0.f) return fail(FA_ERR_INVALID_ARGUMENT, "softcap must be non-negative");
   return FA_OK;
 }
@@ -234,7 +238,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   if (a->dtype == FA_DTYPE_FP16 && k.rescale_thr > 15.f) k.rescale_thr = 15.f;
 
   int nw = fwd_schedule_nw(a, wl, wr);
-  if (a->d > 128) nw = 4;  // head dim 256: one 4-wave lock-step workgroup per CU (512-register budget)
+  if (a->d > 128 || head_dim_trimmed(a->d)) nw = 4;  // head dim 256: one 4-wave lock-step workgroup per CU (512-register budget); trimmed dims: 4-wave lock-step
   // decode: split the keys over several workgroups when (batch x heads) cannot fill the chip
   if (kvcache) {
     int split_tiles = 0;
@@ -244,7 +248,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
       if (a->workspace && a->workspace_bytes >= need) {
         k.n_splits = ns; k.split_tiles = split_tiles;
         k.o_accum = (float*)a->workspace;
-        k.lse_accum = k.o_accum + (int64_t)ns * a->b * a->h * a->seqlen_q * a->d;
+        k.lse_accum = k.o_accum + (int64_t)ns * a->b * a->h * a->seqlen_q * head_dim_pitch(a->d);
         nw = 4;
       } else if (a->num_splits > 1) {
         return fail(FA_ERR_WORKSPACE, "fa_fwd_kvcache: num_splits = %d needs a workspace of %lld bytes (fa_fwd_workspace_bytes)", a->num_splits, (long long)need);

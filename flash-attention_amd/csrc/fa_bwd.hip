@@ -51,10 +51,11 @@ constexpr float kLog2e = 1.4426950408889634f;
 // ------------------------------------------------------------------------------------------------
 // delta[b,h,i] = sum_d dO[i,d] * O[i,d]   (reference flash_bwd_preprocess_kernel.h:24-51, dropout off)
 // ------------------------------------------------------------------------------------------------
-template <typename E, int D>
+// (D, DV): tile pitch and head dimension present in memory, as in fa_fwd_kernel (fa_fwd.hip); DV < D = trimmed head dims 32 / 96 / 192
+template <typename E, int D, int DV>
 __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
   using V8 = typename ElemTraits<E>::v8;
-  constexpr int LPR = D / 8;        // lanes per row
+  constexpr int LPR = D / 8;        // lanes per row (a power of two; lanes past DV / 8 add nothing)
   constexpr int ROWS = 256 / LPR;   // rows per block
   const int b = blockIdx.z, h = blockIdx.y;
   int sq = p.sq;
@@ -69,7 +70,7 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
   const int row = blockIdx.x * ROWS + threadIdx.x / LPR;
   const int c = threadIdx.x % LPR;
   float acc = 0.f;
-  if (row < sq) {
+  if (row < sq && c < DV / 8) {
     const E* dop = (const E*)p.dout + do_boff + (row0 + row) * p.do_rs + (int64_t)h * p.do_hs + c * 8;
     const E* op = (const E*)p.o + o_boff + (row0 + row) * p.o_rs + (int64_t)h * p.o_hs + c * 8;
     const V8 a = bitcast_u32x4<V8>(*reinterpret_cast<const u32x4*>(dop));
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
 // ------------------------------------------------------------------------------------------------
 // dK / dV
 // ------------------------------------------------------------------------------------------------
-template <typename E, int D, int FEAT>
+template <typename E, int D, int DV, int FEAT>
 __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_dkdv_kernel(const BwdK p) {
   constexpr bool XFORM = (FEAT & (FEAT_CAP | FEAT_ALIBI)) != 0;  // scores pass through the scaled domain
   constexpr bool F_CAP = (FEAT & FEAT_CAP) != 0, F_ALIBI = (FEAT & FEAT_ALIBI) != 0, F_DROP = (FEAT & FEAT_DROP) != 0;
@@ -101,7 +102,8 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   constexpr int BNK = NW * 32;   // keys per workgroup
   constexpr int BMQ = (D > 128 || FA_DKDV_SPLIT) ? 32 : 64;  // queries per streamed tile (32-row sub-blocks)
   constexpr int CPR = D / 8, ROW_BYTES = D * 2;
-  constexpr int KS = D / 16, DB = D / 32;
+  constexpr int KS = DV / 16, DB = DV / 32, CV = DV / 8;   // k-steps / output blocks / 16-B chunks that exist
+  static_assert(DV % 32 == 0 && DV <= D && 2 * DV >= D, "DV: a multiple of 32 in [D/2, D]");
   constexpr int VBLK_BYTES = BNK * ROW_BYTES;
   constexpr int QT_BYTES = BMQ * ROW_BYTES;
   // LDS: Q0 | Q1 | dO0 | dO1 | V block | aux0 aux1   (aux = BMQ x LSE*log2e followed by BMQ x delta).  The streamed tiles
@@ -173,7 +175,7 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
     for (int i = 0; i < LDV; ++i) {
       const int idx = tid + i * NT;
       const int row = idx / CPR, ch = idx % CPR;
-      const u32x4 x = ld_global_16B(vp + (int64_t)(n0 + row) * p.v_rs + ch * 8, n0 + row < sk);
+      const u32x4 x = ld_global_16B(vp + (int64_t)(n0 + row) * p.v_rs + ch * 8, n0 + row < sk && (DV == D || ch < CV));
       *(u32x4 FA_LDS*)(lds + OFF_V + tile_off<D>(row, ch)) = x;
     }
   }
@@ -200,7 +202,8 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
       const int row = idx * RPD + lane / CPR;
       const int pc = lane % CPR;
       const int grow = min(m0 + row, sq - 1);
-      const int c = pc ^ swz16<D>(row);
+      int c = pc ^ swz16<D>(row);
+      if (DV < D) c = c < CV ? c : 0;  // columns past the head dimension are never read from LDS: fetch something that exists
       const E* qsrc = qp + (int64_t)grow * p.q_rs + c * 8;
       const E* dsrc = dop + (int64_t)grow * p.do_rs + c * 8;
       lds_dma_16B(qsrc, lds + OFF_Q + buf * QT_BYTES + idx * 1024);
@@ -491,14 +494,14 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   E* dktile = (E*)p.dk + dk_boff + (k_row0 + wk0) * p.dk_rs + (int64_t)hk * p.dk_hs;
   E* dvtile = (E*)p.dv + dv_boff + (k_row0 + wk0) * p.dv_rs + (int64_t)hk * p.dv_hs;
   char FA_LDS* stage = lds + wave * 32 * (ROW_BYTES + 16);
-  store_tile_via_lds<E, D>(stage, dk_acc, p.scale, dktile, p.dk_rs, sk - wk0, lane);
-  store_tile_via_lds<E, D>(stage, dv_acc, dv_scale, dvtile, p.dv_rs, sk - wk0, lane);
+  store_tile_via_lds<E, D, DV>(stage, dk_acc, p.scale, dktile, p.dk_rs, sk - wk0, lane);
+  store_tile_via_lds<E, D, DV>(stage, dv_acc, dv_scale, dvtile, p.dv_rs, sk - wk0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
 // dQ
 // ------------------------------------------------------------------------------------------------
-template <typename E, int D, int NW, int FEAT>
+template <typename E, int D, int DV, int NW, int FEAT>
 __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(const BwdK p) {
   constexpr bool XFORM = (FEAT & (FEAT_CAP | FEAT_ALIBI)) != 0;
   constexpr bool F_CAP = (FEAT & FEAT_CAP) != 0, F_ALIBI = (FEAT & FEAT_ALIBI) != 0, F_DROP = (FEAT & FEAT_DROP) != 0;
@@ -508,7 +511,8 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   constexpr int NT = NW * 64;
   constexpr int BM = NW * 32, BN = 64;
   constexpr int CPR = D / 8, ROW_BYTES = D * 2, TILE_BYTES = BN * ROW_BYTES;
-  constexpr int KS = D / 16, DB = D / 32;
+  constexpr int KS = DV / 16, DB = DV / 32, CV = DV / 8;
+  static_assert(DV % 32 == 0 && DV <= D && 2 * DV >= D, "DV: a multiple of 32 in [D/2, D]");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char FA_LDS* lds = (char FA_LDS*)smem;  // K0 | K1 | V0 | V1
@@ -583,7 +587,8 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
 #pragma unroll
       for (int i = 0; i < QDPW; ++i) {
         const int row = wave * 32 + i * RPDQ + lane / CPR;
-        const int c = (lane % CPR) ^ swz16<D>(row);
+        int c = (lane % CPR) ^ swz16<D>(row);
+        if (DV < D) c = c < CV ? c : 0;
         const int grow = min(m0 + row, sq - 1);
         const E* src = which ? (dosrc + (int64_t)grow * p.do_rs) : (qsrc + (int64_t)grow * p.q_rs);
         lds_dma_16B(src + c * 8, lds + (wave * QDPW + i) * 1024);
@@ -613,7 +618,8 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
     for (int i = 0; i < DPW; ++i) {
       const int idx = wave * DPW + i;
       const int row = idx * RPD + lane / CPR;
-      const int c = (lane % CPR) ^ swz16<D>(row);
+      int c = (lane % CPR) ^ swz16<D>(row);
+      if (DV < D) c = c < CV ? c : 0;
       const int key = min(n * BN + row, sk - 1);
       lds_dma_16B(kp + (int64_t)key * p.k_rs + c * 8, lds + buf * TILE_BYTES + idx * 1024);
       lds_dma_16B(vp + (int64_t)key * p.v_rs + c * 8, lds + (2 + buf) * TILE_BYTES + idx * 1024);
@@ -766,7 +772,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   if (!wave_valid) return;
   // dQ tile through the freed K/V buffers: whole-row stores (fa_device.h store_tile_via_lds)
   E* dqtile = (E*)p.dq + dq_boff + (q_row0 + w_row0) * p.dq_rs + (int64_t)h * p.dq_hs;
-  store_tile_via_lds<E, D>(lds + wave * 32 * (ROW_BYTES + 16), dq_acc, p.scale, dqtile, p.dq_rs, sq - w_row0, lane);
+  store_tile_via_lds<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), dq_acc, p.scale, dqtile, p.dq_rs, sq - w_row0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -776,19 +782,19 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
 int bwd_block_m(int nw) { return (nw == 8 || nw == 64) ? 256 : 128; }
 int bwd_block_n(int d) { return (d > 128 || FA_DKDV_SPLIT) ? 128 : 256; }
 
-template <typename E, int D>
+template <typename E, int D, int DV>
 static int launch_delta_t(const BwdK& p, hipStream_t stream) {
   constexpr int ROWS = 256 / (D / 8);
   dim3 grid((p.sq + ROWS - 1) / ROWS, p.h, p.b);
-  hipLaunchKernelGGL((fa_bwd_delta_kernel<E, D>), grid, dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((fa_bwd_delta_kernel<E, D, DV>), grid, dim3(256), 0, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <typename E, int D, int FEAT>
+template <typename E, int D, int DV, int FEAT>
 static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
   constexpr int NWK = (D > 128 || FA_DKDV_SPLIT) ? 4 : 8, BMQ = (D > 128 || FA_DKDV_SPLIT) ? 32 : 64;
   constexpr int smem = NWK * 32 * D * 2 + 4 * BMQ * D * 2 + 4 * BMQ * 4;
-  auto kern = fa_bwd_dkdv_kernel<E, D, FEAT>;
+  auto kern = fa_bwd_dkdv_kernel<E, D, DV, FEAT>;
   static std::atomic<unsigned long long> attr_mask{0};
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem) != 0) return -1;
   const long long total = p.k_list ? (long long)p.k_bound * p.h_k : units_grid(p.k_units, p.k_unit_size);
@@ -796,64 +802,77 @@ static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <typename E, int D>
+// trimmed head dims (DV < D) are built plain and as the run-time-checked all-features variant only
+template <typename E, int D, int DV>
 static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
-  switch (feat_code(p.softcap > 0.f, p.alibi != nullptr, p.rng != nullptr)) {
-    case FEAT_NONE: return launch_dkdv_a<E, D, FEAT_NONE>(p, stream);
-    case FEAT_CAP: return launch_dkdv_a<E, D, FEAT_CAP>(p, stream);
-    case FEAT_ALIBI: return launch_dkdv_a<E, D, FEAT_ALIBI>(p, stream);
-    case FEAT_DROP: return launch_dkdv_a<E, D, FEAT_DROP>(p, stream);
-    case FEAT_CAP | FEAT_DROP: return launch_dkdv_a<E, D, (FEAT_CAP | FEAT_DROP)>(p, stream);
-    case FEAT_ALIBI | FEAT_DROP: return launch_dkdv_a<E, D, (FEAT_ALIBI | FEAT_DROP)>(p, stream);
-    default: return launch_dkdv_a<E, D, FEAT_ALL>(p, stream);
+  const int feat = feat_code(p.softcap > 0.f, p.alibi != nullptr, p.rng != nullptr);
+  if constexpr (DV < D) {
+    return feat == FEAT_NONE ? launch_dkdv_a<E, D, DV, FEAT_NONE>(p, stream) : launch_dkdv_a<E, D, DV, FEAT_ALL>(p, stream);
+  } else {
+    switch (feat) {
+      case FEAT_NONE: return launch_dkdv_a<E, D, DV, FEAT_NONE>(p, stream);
+      case FEAT_CAP: return launch_dkdv_a<E, D, DV, FEAT_CAP>(p, stream);
+      case FEAT_ALIBI: return launch_dkdv_a<E, D, DV, FEAT_ALIBI>(p, stream);
+      case FEAT_DROP: return launch_dkdv_a<E, D, DV, FEAT_DROP>(p, stream);
+      case FEAT_CAP | FEAT_DROP: return launch_dkdv_a<E, D, DV, (FEAT_CAP | FEAT_DROP)>(p, stream);
+      case FEAT_ALIBI | FEAT_DROP: return launch_dkdv_a<E, D, DV, (FEAT_ALIBI | FEAT_DROP)>(p, stream);
+      default: return launch_dkdv_a<E, D, DV, FEAT_ALL>(p, stream);
+    }
   }
 }
 
-template <typename E, int D, int NW, int FEAT>
+template <typename E, int D, int DV, int NW, int FEAT>
 static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2 + NW * 32 * 16;  // K/V double buffers (+ the row padding of the staged dQ epilogue)
-  auto kern = fa_bwd_dq_kernel<E, D, NW, FEAT>;
+  auto kern = fa_bwd_dq_kernel<E, D, DV, NW, FEAT>;
   static std::atomic<unsigned long long> attr_mask{0};
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem) != 0) return -1;
   const long long total = p.q_list ? (long long)p.q_bound * p.h : units_grid(p.q_units, p.q_unit_size);
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-template <typename E, int D, int FEAT>
+template <typename E, int D, int DV, int FEAT>
 static int launch_dq_f(const BwdK& p, hipStream_t stream) {
-  if constexpr (D > 128) return launch_dq_nw<E, D, 4, FEAT>(p, stream);
-  else return bwd_block_m(p.dq_nw) == 256 ? launch_dq_nw<E, D, 8, FEAT>(p, stream) : launch_dq_nw<E, D, 4, FEAT>(p, stream);
+  if constexpr (D > 128 || DV < D) return launch_dq_nw<E, D, DV, 4, FEAT>(p, stream);
+  else return bwd_block_m(p.dq_nw) == 256 ? launch_dq_nw<E, D, DV, 8, FEAT>(p, stream) : launch_dq_nw<E, D, DV, 4, FEAT>(p, stream);
 }
-template <typename E, int D>
+template <typename E, int D, int DV>
 static int launch_dq_t(const BwdK& p, hipStream_t stream) {
-  switch (feat_code(p.softcap > 0.f, p.alibi != nullptr, p.rng != nullptr)) {
-    case FEAT_NONE: return launch_dq_f<E, D, FEAT_NONE>(p, stream);
-    case FEAT_CAP: return launch_dq_f<E, D, FEAT_CAP>(p, stream);
-    case FEAT_ALIBI: return launch_dq_f<E, D, FEAT_ALIBI>(p, stream);
-    case FEAT_DROP: return launch_dq_f<E, D, FEAT_DROP>(p, stream);
-    case FEAT_CAP | FEAT_DROP: return launch_dq_f<E, D, (FEAT_CAP | FEAT_DROP)>(p, stream);
-    case FEAT_ALIBI | FEAT_DROP: return launch_dq_f<E, D, (FEAT_ALIBI | FEAT_DROP)>(p, stream);
-    default: return launch_dq_f<E, D, FEAT_ALL>(p, stream);
+  const int feat = feat_code(p.softcap > 0.f, p.alibi != nullptr, p.rng != nullptr);
+  if constexpr (DV < D) {
+    return feat == FEAT_NONE ? launch_dq_f<E, D, DV, FEAT_NONE>(p, stream) : launch_dq_f<E, D, DV, FEAT_ALL>(p, stream);
+  } else {
+    switch (feat) {
+      case FEAT_NONE: return launch_dq_f<E, D, DV, FEAT_NONE>(p, stream);
+      case FEAT_CAP: return launch_dq_f<E, D, DV, FEAT_CAP>(p, stream);
+      case FEAT_ALIBI: return launch_dq_f<E, D, DV, FEAT_ALIBI>(p, stream);
+      case FEAT_DROP: return launch_dq_f<E, D, DV, FEAT_DROP>(p, stream);
+      case FEAT_CAP | FEAT_DROP: return launch_dq_f<E, D, DV, (FEAT_CAP | FEAT_DROP)>(p, stream);
+      case FEAT_ALIBI | FEAT_DROP: return launch_dq_f<E, D, DV, (FEAT_ALIBI | FEAT_DROP)>(p, stream);
+      default: return launch_dq_f<E, D, DV, FEAT_ALL>(p, stream);
+    }
   }
 }
 
+#define FA_BWD_DISPATCH_E(fn, E)                                       \
+  switch (d) {                                                         \
+    case 128: return fn<E, 128, 128>(p, stream);                       \
+    case 64: return fn<E, 64, 64>(p, stream);                          \
+    case 256: return fn<E, 256, 256>(p, stream);                       \
+    case 96: return fn<E, 128, 96>(p, stream);                         \
+    case 32: return fn<E, 64, 32>(p, stream);                          \
+    case 192: return fn<E, 256, 192>(p, stream);                       \
+    default: return -2;                                                \
+  }
 #define FA_BWD_DISPATCH(fn)                                            \
-  if (dtype_bf16) {                                                    \
-    if (d == 128) return fn<__bf16, 128>(p, stream);                   \
-    if (d == 64) return fn<__bf16, 64>(p, stream);                     \
-    if (d == 256) return fn<__bf16, 256>(p, stream);                   \
-  } else {                                                             \
-    if (d == 128) return fn<_Float16, 128>(p, stream);                 \
-    if (d == 64) return fn<_Float16, 64>(p, stream);                   \
-    if (d == 256) return fn<_Float16, 256>(p, stream);                 \
-  }                                                                    \
-  return -2;
+  if (dtype_bf16) { FA_BWD_DISPATCH_E(fn, __bf16) } else { FA_BWD_DISPATCH_E(fn, _Float16) }
 
 int launch_bwd_delta(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_delta_t) }
 int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_dkdv_t) }
 int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   LastSchedule& ls = last_schedule();
-  ls.bwd_dq_nw = d > 128 ? 4 : bwd_block_m(p.dq_nw) / 32;
+  const bool trimmed = (d == 32 || d == 96 || d == 192);
+  ls.bwd_dq_nw = (d > 128 || trimmed) ? 4 : bwd_block_m(p.dq_nw) / 32;
   if (p.dq_nw == 64) {   // 64-rows-per-wave schedule where it applies, else the 8-wave kernel on the same 256-row blocks
     const int rc = launch_bwd_dq_w64(p, dtype_bf16, d, stream);
     if (rc != -2) { ls.bwd_dq_nw = 64; return rc; }

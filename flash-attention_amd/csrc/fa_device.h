@@ -125,15 +125,16 @@ FA_DEVINL int xcd_interleave(int bid, int n_units, int unit_size, int hpx) {
 // Epilogue store of one wave's 32 x D tile held in the transposed accumulator layout (lane & 31 = row, registers = 4-element
 // groups of the row at columns 32*db + 8*g + 4*hi): written directly, each store instruction puts 16 bytes into each of 32
 // rows (512 partial-line writes per wave).  Staged through `stage` (32 padded rows of LDS private to the wave) every
-// instruction writes whole rows.  Rows >= rows_valid are not stored.
-template <typename E, int D>
-FA_DEVINL void store_tile_via_lds(char FA_LDS* stage, const f32x16 (&acc)[D / 32], float scale, E* gtile, int64_t row_stride,
+// instruction writes whole rows.  Rows >= rows_valid are not stored.  DV < D (trimmed head dims): the tile has DV / 32
+// blocks and only the first DV columns of a (pitch D) staging row are written out.
+template <typename E, int D, int DV = D>
+FA_DEVINL void store_tile_via_lds(char FA_LDS* stage, const f32x16 (&acc)[DV / 32], float scale, E* gtile, int64_t row_stride,
                                   int rows_valid, int lane) {
   using V4 = typename ElemTraits<E>::v4;
   constexpr int ROW_BYTES = D * 2, RS = ROW_BYTES + 16, CPR = D / 8, RPI = 64 / CPR;
   const int qi = lane & 31, hi = lane >> 5;
 #pragma unroll
-  for (int db = 0; db < D / 32; ++db)
+  for (int db = 0; db < DV / 32; ++db)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       V4 ov;
@@ -145,7 +146,7 @@ FA_DEVINL void store_tile_via_lds(char FA_LDS* stage, const f32x16 (&acc)[D / 32
   for (int i = 0; i < 32 / RPI; ++i) {
     const int row = i * RPI + lane / CPR, ch = lane % CPR;
     const u32x4 x = *reinterpret_cast<const u32x4 FA_LDS*>(stage + row * RS + ch * 16);
-    if (row < rows_valid) *reinterpret_cast<u32x4*>(gtile + (int64_t)row * row_stride + ch * 8) = x;
+    if (row < rows_valid && (DV == D || ch < DV / 8)) *reinterpret_cast<u32x4*>(gtile + (int64_t)row * row_stride + ch * 8) = x;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging rows may be rewritten by the caller's next tile
 }

@@ -50,7 +50,11 @@ template <int D> FA_DEVINL constexpr int v_swz(int row) { return D >= 128 ? (row
 
 template <int N> using IC = std::integral_constant<int, N>;
 
-template <typename E, int D, int NW, int FEAT, bool PP>
+// D = row pitch of the LDS tiles and of the staging layout (64 / 128 / 256); DV = head dimension actually present in memory and
+// contracted over (DV <= D, a multiple of 32).  DV < D are the "trimmed" variants for head dims 32 / 96 / 192 (the reference builds
+// those sizes too: static_switch.h:92-110): the QK^T loop runs DV/16 k-steps, the output has DV/32 blocks, tile columns >= DV are
+// never read -- the DMA lanes that would fetch them re-fetch column chunk 0 instead -- and never stored.
+template <typename E, int D, int DV, int NW, int FEAT, bool PP>
 __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const FwdK p) {
   constexpr bool XFORM = (FEAT & (FEAT_CAP | FEAT_ALIBI)) != 0;  // scores pass through the scaled domain
   constexpr bool F_CAP = (FEAT & FEAT_CAP) != 0, F_ALIBI = (FEAT & FEAT_ALIBI) != 0, F_DROP = (FEAT & FEAT_DROP) != 0;
@@ -61,9 +65,12 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   constexpr int ROW_BYTES = D * 2;
   constexpr int TILE_BYTES = BN * ROW_BYTES;
   constexpr int LD = (BN * CPR) / NT;  // 16-B chunks each thread moves per tile (K and V each)
-  constexpr int KS = D / 16;           // k-steps of the QK^T contraction
-  constexpr int DB = D / 32;           // 32-wide d blocks of the output
-  static_assert(D == 64 || D == 128 || D == 256, "head dims built natively: 64, 128, 256");
+  constexpr int KS = DV / 16;          // k-steps of the QK^T contraction
+  constexpr int DB = DV / 32;          // 32-wide d blocks of the output
+  constexpr int CV = DV / 8;           // 16-B chunks of a row that exist in memory
+  static_assert(DV % 32 == 0 && DV <= D && 2 * DV >= D, "DV: a multiple of 32 in [D/2, D]");
+  static_assert(DV == D || !PP, "trimmed head dims run the lock-step schedule");
+  static_assert(D == 64 || D == 128 || D == 256, "tile pitches: 64, 128, 256");
   static_assert(D <= 128 || (NW == 4 && !PP), "D = 256: 4 waves (one per SIMD, 512 registers), lock-step schedule");
   static_assert(LD >= 1 && (BN * CPR) % NT == 0, "tile does not divide over the workgroup");
   static_assert(!PP || NW == 8, "ping-pong schedule pairs waves w and w+4");
@@ -237,7 +244,8 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
     for (int i = 0; i < DPW; ++i) {
       const int row = (wave * DPW + i) * RPD + lane / CPR, pc = lane % CPR;
       const int grow = min(n * BN + row, sk - 1) - n * BN;
-      const int c = ISV ? ((((pc >> 2) ^ v_swz<D>(row)) << 2) | (pc & 3)) : (pc ^ k_swz<D>(row));
+      int c = ISV ? ((((pc >> 2) ^ v_swz<D>(row)) << 2) | (pc & 3)) : (pc ^ k_swz<D>(row));
+      if (DV < D) c = c < CV ? c : 0;  // columns past the head dimension: never read from LDS, fetch something that exists
       lds_dma_16B(base + (int64_t)grow * rs + c * 8, dst + i * 1024);
     }
   };
@@ -427,7 +435,9 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
       for (int i = 0; i < QDPW; ++i) {
         const int row = wave * 32 + i * RPD + lane / CPR, pc = lane % CPR;
         const int grow = min(m0 + row, sq - 1);
-        lds_dma_16B(qp + (int64_t)grow * p.q_rs + (pc ^ k_swz<D>(row)) * 8, lds + (wave * QDPW + i) * 1024);
+        int c = pc ^ k_swz<D>(row);
+        if (DV < D) c = c < CV ? c : 0;
+        lds_dma_16B(qp + (int64_t)grow * p.q_rs + c * 8, lds + (wave * QDPW + i) * 1024);
       }
       lds_dma_wait_all();
       const int qb = (wave * 32 + qi) * ROW_BYTES;
@@ -529,13 +539,13 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
     return;
   }
   // O tile through the freed K/V buffers: whole-row stores (fa_device.h store_tile_via_lds)
-  store_tile_via_lds<E, D>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op + (int64_t)w_row0 * p.o_rs, p.o_rs, sq - w_row0, lane);
+  store_tile_via_lds<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op + (int64_t)w_row0 * p.o_rs, p.o_rs, sq - w_row0, lane);
   if (row_valid && hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
 }
 
 // Merge of the split-KV partials (reference combine_attn_seqk_parallel, flash_fwd_kernel.h:1117-1299): one wave per
 // (batch, head, query row); lse = log sum_s exp(lse_s), out = sum_s exp(lse_s - lse) * out_s.
-template <typename E, int D>
+template <typename E, int D, int DV>
 __global__ void __launch_bounds__(256) fa_splitkv_combine_kernel(const FwdK p) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -554,7 +564,8 @@ __global__ void __launch_bounds__(256) fa_splitkv_combine_kernel(const FwdK p) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
   const float wgt = dead ? 0.f : e / sum;  // exp(lse_s - lse)
-  constexpr int EPL = D / 64;              // output elements per lane
+  constexpr int EPL = D / 64;              // output elements per lane (partial rows have pitch D; columns >= DV do not exist)
+  const bool col_ok = lane * EPL < DV;
   float acc[EPL];
 #pragma unroll
   for (int t = 0; t < EPL; ++t) acc[t] = 0.f;
@@ -567,7 +578,7 @@ __global__ void __launch_bounds__(256) fa_splitkv_combine_kernel(const FwdK p) {
       ws[j] = (s0 + j < p.n_splits) ? __shfl(wgt, s) : 0.f;
       const float* src = p.o_accum + ((int64_t)s * rows + r) * D + lane * EPL;
 #pragma unroll
-      for (int t = 0; t < EPL; ++t) part[j][t] = src[t];
+      for (int t = 0; t < EPL; ++t) part[j][t] = col_ok ? src[t] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -576,21 +587,28 @@ __global__ void __launch_bounds__(256) fa_splitkv_combine_kernel(const FwdK p) {
   }
   E* dst = (E*)p.o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + (int64_t)h * p.o_hs + lane * EPL;
 #pragma unroll
-  for (int t = 0; t < EPL; ++t) dst[t] = (E)acc[t];
+  for (int t = 0; t < EPL; ++t)
+    if (col_ok) dst[t] = (E)acc[t];
   if (lane == 0) p.lse[((int64_t)b * p.h + h) * p.sq + i] = dead ? INFINITY : (mx + __logf(sum));
 }
 
+template <typename E>
+static int launch_combine_e(const FwdK& p, int d, dim3 grid, dim3 block, hipStream_t stream) {
+  switch (d) {
+    case 256: hipLaunchKernelGGL((fa_splitkv_combine_kernel<E, 256, 256>), grid, block, 0, stream, p); break;
+    case 192: hipLaunchKernelGGL((fa_splitkv_combine_kernel<E, 256, 192>), grid, block, 0, stream, p); break;
+    case 128: hipLaunchKernelGGL((fa_splitkv_combine_kernel<E, 128, 128>), grid, block, 0, stream, p); break;
+    case 96: hipLaunchKernelGGL((fa_splitkv_combine_kernel<E, 128, 96>), grid, block, 0, stream, p); break;
+    case 64: hipLaunchKernelGGL((fa_splitkv_combine_kernel<E, 64, 64>), grid, block, 0, stream, p); break;
+    case 32: hipLaunchKernelGGL((fa_splitkv_combine_kernel<E, 64, 32>), grid, block, 0, stream, p); break;
+    default: return -2;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int launch_splitkv_combine(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   const int64_t rows = (int64_t)p.b * p.h * p.sq;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (dtype_bf16 && d == 256) hipLaunchKernelGGL((fa_splitkv_combine_kernel<__bf16, 256>), grid, block, 0, stream, p);
-  else if (d == 256) hipLaunchKernelGGL((fa_splitkv_combine_kernel<_Float16, 256>), grid, block, 0, stream, p);
-  else if (dtype_bf16 && d == 128) hipLaunchKernelGGL((fa_splitkv_combine_kernel<__bf16, 128>), grid, block, 0, stream, p);
-  else if (dtype_bf16 && d == 64) hipLaunchKernelGGL((fa_splitkv_combine_kernel<__bf16, 64>), grid, block, 0, stream, p);
-  else if (d == 128) hipLaunchKernelGGL((fa_splitkv_combine_kernel<_Float16, 128>), grid, block, 0, stream, p);
-  else if (d == 64) hipLaunchKernelGGL((fa_splitkv_combine_kernel<_Float16, 64>), grid, block, 0, stream, p);
-  else return -2;
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  return dtype_bf16 ? launch_combine_e<__bf16>(p, d, grid, block, stream) : launch_combine_e<_Float16>(p, d, grid, block, stream);
 }
 
 // Rotary embedding (reference csrc/flash_attn/src/rotary.h, flash_fwd_kernel.h:640-720): one thread rotates 8 channel
@@ -760,10 +778,10 @@ int launch_kv_append(const KvAppendK& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <typename E, int D, int NW, int FEAT, bool PP>
+template <typename E, int D, int DV, int NW, int FEAT, bool PP>
 static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2 + NW * 32 * 16;  // K/V double buffers (+ the row padding of the staged O epilogue)
-  auto kern = fa_fwd_kernel<E, D, NW, FEAT, PP>;
+  auto kern = fa_fwd_kernel<E, D, DV, NW, FEAT, PP>;
   static std::atomic<unsigned long long> attr_mask{0};
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem) != 0) return -1;
   const long long total = units_grid(p.n_units, p.unit_size);
@@ -771,9 +789,9 @@ static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   if (hipGetLastError() != hipSuccess) return -1;
   LastSchedule& ls = last_schedule();
-  ls.fwd_kernel = 1; ls.fwd_nw = PP ? 16 : NW; ls.fwd_feat = FEAT; ls.fwd_splits = p.n_splits; ls.fwd_list = p.work_list != nullptr; ls.d = D;
+  ls.fwd_kernel = 1; ls.fwd_nw = PP ? 16 : NW; ls.fwd_feat = FEAT; ls.fwd_splits = p.n_splits; ls.fwd_list = p.work_list != nullptr; ls.d = DV;
   ls.bf16 = std::is_same<E, __bf16>::value;
-  snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_kernel<%s,%d,%d,feat%d,%s>", ls.bf16 ? "bf16" : "f16", D, NW, FEAT, PP ? "pingpong" : "lockstep");
+  snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_kernel<%s,%d,%d,feat%d,%s>", ls.bf16 ? "bf16" : "f16", DV, NW, FEAT, PP ? "pingpong" : "lockstep");
   return 0;
 }
 
@@ -783,12 +801,12 @@ template <typename E, int D, int FEAT>
 static int launch_fwd_f(const FwdK& p, int nw, hipStream_t stream) {
   if constexpr (D > 128) {
     (void)nw;
-    return launch_fwd_t<E, D, 4, FEAT, false>(p, stream);
+    return launch_fwd_t<E, D, D, 4, FEAT, false>(p, stream);
   } else {
-    if (nw == 8) return launch_fwd_t<E, D, 8, FEAT, false>(p, stream);
-    if (nw == 4) return launch_fwd_t<E, D, 4, FEAT, false>(p, stream);
+    if (nw == 8) return launch_fwd_t<E, D, D, 8, FEAT, false>(p, stream);
+    if (nw == 4) return launch_fwd_t<E, D, D, 4, FEAT, false>(p, stream);
     if constexpr (FEAT == FEAT_NONE || FEAT == FEAT_ALL) {  // the ping-pong schedule is built plain and all-features only
-      if (nw == 16) return launch_fwd_t<E, D, 8, FEAT, true>(p, stream);
+      if (nw == 16) return launch_fwd_t<E, D, D, 8, FEAT, true>(p, stream);
     }
     return -2;
   }
@@ -807,21 +825,30 @@ static int launch_fwd_ed(const FwdK& p, int nw, hipStream_t stream) {
     default: return launch_fwd_f<E, D, FEAT_ALL>(p, nw, stream);
   }
 }
+// trimmed head dims (32 / 96 / 192): 4-wave lock-step schedule; plain, or the run-time-checked all-features variant
+template <typename E, int D, int DV>
+static int launch_fwd_trim(const FwdK& p, hipStream_t stream) {
+  if (p.softcap > 0.f || p.alibi != nullptr || p.rng != nullptr) return launch_fwd_t<E, D, DV, 4, FEAT_ALL, false>(p, stream);
+  return launch_fwd_t<E, D, DV, 4, FEAT_NONE, false>(p, stream);
+}
+template <typename E>
+static int launch_fwd_e(const FwdK& p, int d, int nw, hipStream_t stream) {
+  switch (d) {
+    case 128: return launch_fwd_ed<E, 128>(p, nw, stream);
+    case 64: return launch_fwd_ed<E, 64>(p, nw, stream);
+    case 256: return launch_fwd_ed<E, 256>(p, nw, stream);
+    case 96: return nw == 4 ? launch_fwd_trim<E, 128, 96>(p, stream) : -2;
+    case 32: return nw == 4 ? launch_fwd_trim<E, 64, 32>(p, stream) : -2;
+    case 192: return nw == 4 ? launch_fwd_trim<E, 256, 192>(p, stream) : -2;
+    default: return -2;
+  }
+}
 
 // nw: 4 / 8 = lock-step schedule with 4 / 8 waves per workgroup, 16 = 8-wave ping-pong schedule
 int launch_fwd(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream) {
   // the scalar-base + 32-bit lane-offset tile loads need one tile's extent to fit 32 bits
   if ((uint64_t)64 * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 31)) return -3;
-  if (dtype_bf16) {
-    if (d == 128) return launch_fwd_ed<__bf16, 128>(p, nw, stream);
-    if (d == 64) return launch_fwd_ed<__bf16, 64>(p, nw, stream);
-    if (d == 256) return launch_fwd_ed<__bf16, 256>(p, nw, stream);
-  } else {
-    if (d == 128) return launch_fwd_ed<_Float16, 128>(p, nw, stream);
-    if (d == 64) return launch_fwd_ed<_Float16, 64>(p, nw, stream);
-    if (d == 256) return launch_fwd_ed<_Float16, 256>(p, nw, stream);
-  }
-  return -2;
+  return dtype_bf16 ? launch_fwd_e<__bf16>(p, d, nw, stream) : launch_fwd_e<_Float16>(p, d, nw, stream);
 }
 
 }  // namespace fa

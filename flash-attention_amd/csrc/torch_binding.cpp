@@ -37,10 +37,11 @@ int dtype_code(const Tensor& q) {
   return q.dtype() == at::kBFloat16 ? FA_DTYPE_BF16 : FA_DTYPE_FP16;
 }
 
+// next head dim with its own kernels (the reference's set, static_switch.h:92-110): tensors whose head dim is one of these go to
+// the kernels as they are, no padded copies
 int native_head_dim(int64_t d) {
-  if (d <= 64) return 64;
-  if (d <= 128) return 128;
   TORCH_CHECK(d <= 256, "FlashAttention only supports head dimension at most 256");
+  for (int n : {32, 64, 96, 128, 192}) if (d <= n) return n;
   return 256;
 }
 
@@ -484,7 +485,8 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tenso
   const int64_t page = paged ? kcache.size(1) : 0;
   const int64_t Sk = paged ? block_table_->size(1) * page : kcache.size(1);
   TORCH_CHECK(B > 0, "batch size must be positive");
-  TORCH_CHECK(D == 64 || D == 128 || D == 256, "libfa_gfx950: fwd_kvcache is built for head dimensions 64, 128 and 256");
+  // (the cache cannot be padded on the fly, so the decode path takes the head dims that have their own kernels)
+  TORCH_CHECK(D == native_head_dim(D), "libfa_gfx950: fwd_kvcache is built for head dimensions 32, 64, 96, 128, 192 and 256");
   TORCH_CHECK(H % Hk == 0, "Number of heads in key/value must divide number of heads in query");
   TORCH_CHECK(kcache.size(3) == D && vcache.sizes() == kcache.sizes(), "kcache / vcache shape mismatch");
   if (paged) {

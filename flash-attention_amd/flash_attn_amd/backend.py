@@ -16,7 +16,7 @@ import torch
 
 from . import _cabi
 
-_NATIVE_HEAD_DIMS = (64, 128, 256)
+_NATIVE_HEAD_DIMS = (32, 64, 96, 128, 192, 256)  # head dims with their own kernels (csrc/fa_api.cpp head_dim_native)
 
 
 def reload_knobs() -> None:
@@ -487,7 +487,7 @@ def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_,
     page = kcache.shape[1] if paged else 0
     Sk = block_table_.shape[1] * page if paged else kcache.shape[1]
     if D not in _NATIVE_HEAD_DIMS:
-        raise RuntimeError("libfa_gfx950: fwd_kvcache is built for head dimensions 64, 128 and 256")
+        raise RuntimeError("libfa_gfx950: fwd_kvcache is built for head dimensions 32, 64, 96, 128, 192 and 256")
     if H % Hk != 0:
         raise RuntimeError("Number of heads in key/value must divide number of heads in query")
     if paged and page % 256 != 0:
