@@ -53,6 +53,7 @@ const fa::Knobs* read_knobs() {
   k->lds_pad = env_int("FA_IL_LDS_PAD", 0);
   k->w64_persist = env_int("FA_W64_PERSIST", 1);
   k->strict = env_int("FA_STRICT", 0);
+  k->pack_gqa = env_int("FA_PACK_GQA", 1);
   if (k->strict) k->rescale_thr = 0.f;
   return k;
 }
@@ -110,13 +111,22 @@ template <typename K> void fill_dropout(K& k, float p_dropout, const uint64_t* r
 // Split-KV schedule of the decode path (reference num_splits_heuristic, flash_api.cpp:275-347, re-derived for 256 CUs
 // with two workgroups each): split only single-block query lengths whose (batch x head) grid leaves most CUs idle,
 // into the fewest key splits that give every CU two workgroups; a split is a whole number of 64-key tiles.
+// Head packing on the KV-cache path (FwdK::pack_g; the reference packs only the single-row decode step by reshaping q,
+// flash_api.cpp:429-437 -- FA3 generalises it as PackGQA, hopper/pack_gqa.h): when all g query heads of a KV group times the
+// query rows fit one 128-row block, the group's heads become rows of that block and K/V are streamed once per KV head instead
+// of once per query head.  Returns g (1 = no packing).
+int pack_group(const FaFwdParams* a) {
+  const int g = a->h_k > 0 ? a->h / a->h_k : 1;
+  if (g <= 1 || !fa::knobs().pack_gqa || a->cu_seqlens_q || a->p_dropout > 0.f || a->seqlen_q < 1 || (long)a->seqlen_q * g > 128) return 1;
+  return g;
+}
 int choose_splits(const FaFwdParams* a, int& split_tiles) {
   const int tiles = (a->seqlen_k + 63) / 64;
   split_tiles = tiles;
   if (a->seqlen_q > 128 || tiles < 2 || a->num_splits == 1) return 1;
   int want = a->num_splits;
   if (want <= 0) {
-    const long units = (long)a->b * a->h;
+    const long units = (long)a->b * a->h / pack_group(a);   // workgroups of the unsplit grid
     if (units >= 384) return 1;
     want = (int)((512 + units - 1) / units);
     want = std::min(want, std::max(1, tiles / 4));  // at least 4 tiles (256 keys) per split
@@ -210,6 +220,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
 
   fa::FwdK k{};
   k.n_splits = 1;
+  k.pack_g = 1;
   k.q = a->q; k.k = a->k; k.v = a->v; k.o = a->o; k.lse = a->softmax_lse;
   k.q_bs = a->q_batch_stride; k.q_rs = a->q_row_stride; k.q_hs = a->q_head_stride;
   k.k_bs = a->k_batch_stride; k.k_rs = a->k_row_stride; k.k_hs = a->k_head_stride;
@@ -238,6 +249,11 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   if (a->dtype == FA_DTYPE_FP16 && k.rescale_thr > 15.f) k.rescale_thr = 15.f;
 
   int nw = fwd_schedule_nw(a, wl, wr);
+  const int pack = kvcache ? pack_group(a) : 1;
+  if (pack > 1) {  // grouped query heads become rows of one block (4-wave lock-step kernel)
+    k.pack_g = pack; k.h = a->h_k; k.hk_ratio = 1; k.sq = a->seqlen_q * pack;
+    nw = 4;
+  }
   if (a->d > 128 || head_dim_trimmed(a->d)) nw = 4;  // head dim 256: one 4-wave lock-step workgroup per CU (512-register budget); trimmed dims: 4-wave lock-step
   // decode: split the keys over several workgroups when (batch x heads) cannot fill the chip
   if (kvcache) {
@@ -256,13 +272,13 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     }
   }
   // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
-  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && k.n_splits == 1;
+  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && k.n_splits == 1 && pack == 1;
   const bool w64 = nw == 64 && plain && !a->block_table;
   if (nw == 64 && !w64) nw = 8;   // features / paged KV: 8-wave lock-step kernel (same 256-row blocks)
   const bool il = (nw == 34 || nw == 38) && plain;
   if ((nw == 34 || nw == 38) && !il) nw -= 30;
   const int bm = w64 ? 256 : il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
-  k.nmb = (a->seqlen_q + bm - 1) / bm;
+  k.nmb = (k.sq + bm - 1) / bm;
   if (varlen && !kvcache) {  // uneven packed batch: enumerate the non-empty query blocks, heaviest first
     const int64_t entries = varlen_list_entries(a, bm);
     if (entries > 0 && a->workspace && a->workspace_bytes >= (entries + 1) * 8) {
@@ -275,10 +291,11 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
       k.work_bound = (int)entries;
     }
   }
-  fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb * k.n_splits, k.n_units, k.unit_size, k.unit_hpx);
+  fa::choose_units(a->b, a->h_k, k.hk_ratio, k.nmb * k.n_splits, k.n_units, k.unit_size, k.unit_hpx);
   int rc = w64  ? fa::launch_fwd_w64(k, a->dtype == FA_DTYPE_BF16, a->d, (hipStream_t)stream)
            : il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, a->d, nw - 30, (hipStream_t)stream)
                 : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
+  if (rc == 0) fa::last_schedule().fwd_pack = k.pack_g;
   if (rc == 0 && k.n_splits > 1) rc = fa::launch_splitkv_combine(k, a->dtype == FA_DTYPE_BF16, a->d, (hipStream_t)stream);
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
   if (rc == -3)
@@ -422,7 +439,7 @@ const char* fa_last_error(void) { return g_err; }
 void fa_knobs_reload(void) { g_knobs.store(read_knobs(), std::memory_order_release); }
 int fa_last_schedule(int32_t* out, int n) {
   const fa::LastSchedule& ls = fa::last_schedule();
-  const int32_t v[FA_SCHEDULE_FIELDS] = {ls.fwd_kernel, ls.fwd_nw, ls.fwd_feat, ls.fwd_splits, ls.fwd_list, ls.d, ls.bf16, ls.bwd_dq_nw, ls.bwd_list, ls.bwd_spill};
+  const int32_t v[FA_SCHEDULE_FIELDS] = {ls.fwd_kernel, ls.fwd_nw, ls.fwd_feat, ls.fwd_splits, ls.fwd_list, ls.d, ls.bf16, ls.bwd_dq_nw, ls.bwd_list, ls.bwd_spill, ls.fwd_pack};
   for (int i = 0; i < n && i < FA_SCHEDULE_FIELDS; ++i) out[i] = v[i];
   return FA_SCHEDULE_FIELDS;
 }

@@ -151,6 +151,33 @@ FA_DEVINL void store_tile_via_lds(char FA_LDS* stage, const f32x16 (&acc)[DV / 3
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging rows may be rewritten by the caller's next tile
 }
 
+// The same for head-packed rows (fa_fwd_kernel, FwdK::pack_g): tile row r is packed row row0 + r = query (row0 + r) / g of head
+// (row0 + r) % g in the group, stored at gbase + query * row_stride + head * head_stride; rows >= rows_total do not exist.
+template <typename E, int D, int DV = D>
+FA_DEVINL void store_tile_via_lds_packed(char FA_LDS* stage, const f32x16 (&acc)[DV / 32], float scale, E* gbase, int64_t row_stride,
+                                         int64_t head_stride, int g, int row0, int rows_total, int lane) {
+  using V4 = typename ElemTraits<E>::v4;
+  constexpr int ROW_BYTES = D * 2, RS = ROW_BYTES + 16, CPR = D / 8, RPI = 64 / CPR;
+  const int qi = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int db = 0; db < DV / 32; ++db)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      V4 ov;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) ov[jj] = (E)(acc[db][4 * gq + jj] * scale);
+      *reinterpret_cast<V4 FA_LDS*>(stage + qi * RS + (32 * db + 8 * gq + 4 * hi) * 2) = ov;
+    }
+#pragma unroll
+  for (int i = 0; i < 32 / RPI; ++i) {
+    const int row = i * RPI + lane / CPR, ch = lane % CPR;
+    const u32x4 x = *reinterpret_cast<const u32x4 FA_LDS*>(stage + row * RS + ch * 16);
+    const int prow = row0 + row, iq = prow / g, hh = prow - iq * g;
+    if (prow < rows_total && (DV == D || ch < DV / 8)) *reinterpret_cast<u32x4*>(gbase + (int64_t)iq * row_stride + (int64_t)hh * head_stride + ch * 8) = x;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // Unified LDS tile layout (rows of D 16-bit elements, 16-B chunks XOR-swizzled) that is
 // conflict-free for both access patterns used on the same tile:
 //   - ds_read_b128 operand rows (16 distinct rows per lane group, same logical chunk),

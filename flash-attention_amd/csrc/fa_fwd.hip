@@ -130,20 +130,27 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   }
   const int m0 = m_block * BM;
   if (m0 >= sq) return;
+  // Head packing (FwdK::pack_g = g > 1; decode / short chunks with grouped heads): this "head" is KV head h and its rows are the
+  // g * Sq (query, head-in-group) pairs, row r = query r / g of query head h * g + r % g -- K/V stream once per KV head.
+  // Masks, Q / O / LSE addresses and ALiBi slopes go through (row / g, row % g); everything else works on packed rows.
+  const int g = p.pack_g;
+  const bool packed = g > 1;
+  auto q_of = [&](int row) __attribute__((always_inline)) { return packed ? row / g : row; };
 
-  const E* __restrict__ qp = (const E*)p.q + q_boff + q_row0 * p.q_rs + (int64_t)h * p.q_hs;
+  const E* __restrict__ qp = (const E*)p.q + q_boff + q_row0 * p.q_rs + (int64_t)h * g * p.q_hs;
   const E* __restrict__ kp = (const E*)p.k + k_boff + k_row0 * p.k_rs + (int64_t)hk * p.k_hs;
   const E* __restrict__ vp = (const E*)p.v + v_boff + k_row0 * p.v_rs + (int64_t)hk * p.v_hs;
-  E* __restrict__ op = (E*)p.o + o_boff + q_row0 * p.o_rs + (int64_t)h * p.o_hs;
+  E* __restrict__ op = (E*)p.o + o_boff + q_row0 * p.o_rs + (int64_t)h * g * p.o_hs;
   float* __restrict__ lsep = p.cu_q ? (p.lse + (int64_t)h * p.total_q + q_row0)
-                                    : (p.lse + ((int64_t)b * p.h + h) * p.sq);
+                                    : (p.lse + ((int64_t)b * p.h + h) * p.sq);  // packed: (b, h*g + r%g, r/g) == this base + (r%g)*(sq/g) + r/g
 
   // ---- key range of the block, per-wave and per-lane visibility limits --------------------------
-  const int shift = sk - sq;  // bottom-right alignment
+  const int sq_true = packed ? sq / g : sq;
+  const int shift = sk - sq_true;  // bottom-right alignment
   const int blk_last = min(m0 + BM, sq) - 1;
   int kmax = sk - 1, kmin = 0;
-  if (p.wr >= 0) kmax = min(kmax, blk_last + shift + p.wr);
-  if (p.wl >= 0) kmin = max(0, m0 + shift - p.wl);
+  if (p.wr >= 0) kmax = min(kmax, q_of(blk_last) + shift + p.wr);
+  if (p.wl >= 0) kmin = max(0, q_of(m0) + shift - p.wl);
   int n_min = kmin / BN;
   int n_max = (kmax >= kmin) ? (kmax / BN + 1) : n_min;
   if (p.n_splits > 1) {  // this workgroup's share of the key tiles (may be empty)
@@ -155,21 +162,24 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   const int w_row0 = m0 + wave * 32;
   const int w_row1 = min(w_row0 + 31, sq - 1);
   const bool wave_valid = w_row0 < sq;
-  const int w_kmax = (p.wr >= 0) ? min(sk - 1, w_row1 + shift + p.wr) : sk - 1;   // last key any row sees
-  const int w_kmin = (p.wl >= 0) ? max(0, w_row0 + shift - p.wl) : 0;             // first key any row sees
-  const int w_full_hi = (p.wr >= 0) ? min(sk - 1, w_row0 + shift + p.wr) : sk - 1;  // keys <= this: visible to all rows
-  const int w_full_lo = (p.wl >= 0) ? (w_row1 + shift - p.wl) : 0;                  // keys >= this: visible to all rows
+  const int w_q0 = q_of(w_row0), w_q1 = q_of(w_row1);  // first / last query of the wave's rows
+  const int w_kmax = (p.wr >= 0) ? min(sk - 1, w_q1 + shift + p.wr) : sk - 1;   // last key any row sees
+  const int w_kmin = (p.wl >= 0) ? max(0, w_q0 + shift - p.wl) : 0;             // first key any row sees
+  const int w_full_hi = (p.wr >= 0) ? min(sk - 1, w_q0 + shift + p.wr) : sk - 1;  // keys <= this: visible to all rows
+  const int w_full_lo = (p.wl >= 0) ? (w_q1 + shift - p.wl) : 0;                  // keys >= this: visible to all rows
 
   const int my_row = w_row0 + qi;
   const bool row_valid = my_row < sq;
-  const int lim_hi = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
-  const int lim_lo = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
+  const int my_q = q_of(my_row);           // query index of this lane's row
+  const int my_hh = my_row - my_q * g;     // head within the group (0 unless packed)
+  const int lim_hi = (p.wr >= 0) ? min(sk - 1, my_q + shift + p.wr) : sk - 1;
+  const int lim_lo = (p.wl >= 0) ? (my_q + shift - p.wl) : 0;
 
   // softcap / ALiBi / dropout are compile-time variants (FEAT) so the common kernel carries none of them
   const float cs = XFORM ? kLog2e : p.scale_log2;  // multiplier taking S to the log2 domain
   const bool use_alibi = F_ALIBI && (FEAT != FEAT_ALL || p.alibi != nullptr);
   const bool use_cap = F_CAP && (FEAT != FEAT_ALL || p.softcap > 0.f);
-  const float slope = use_alibi ? p.alibi[(int64_t)b * p.alibi_bs + h] : 0.f;
+  const float slope = use_alibi ? p.alibi[(int64_t)b * p.alibi_bs + h * g + my_hh] : 0.f;
   // dropout: per-(batch, head) stream key and this lane's row base
   const bool drop = F_DROP && (FEAT != FEAT_ALL || p.rng != nullptr);
   const uint32_t drop_key = drop ? drop_bh_key(p.rng, b * p.h + h) : 0u;
@@ -178,9 +188,9 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane = query row, 8 consecutive d per k-step -----
   V8 qf[KS];
-  const bool q_staged = !PP && sq >= 64;  // lock-step schedule: the Q block goes through LDS by coalesced DMA (prologue below)
-  if (!q_staged) {  // few query rows (decode) or ping-pong schedule: 16-byte loads at row stride
-    const E* qrow = qp + (int64_t)my_row * p.q_rs + 8 * hi;
+  const bool q_staged = !PP && sq >= 64 && !packed;  // lock-step schedule: the Q block goes through LDS by coalesced DMA (prologue below)
+  if (!q_staged) {  // few query rows (decode), packed heads or ping-pong schedule: 16-byte loads at row stride
+    const E* qrow = qp + (int64_t)my_q * p.q_rs + (int64_t)my_hh * p.q_hs + 8 * hi;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = bitcast_u32x4<V8>(ld_global_16B(qrow + 16 * ks, row_valid));
   }
@@ -322,7 +332,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
           if constexpr (F_ALIBI) {
             if (use_alibi) {
               const int key = kv0 + 32 * kb + acc_row(r, hi);
-              y -= slope * fabsf((float)(my_row + shift - key));
+              y -= slope * fabsf((float)(my_q + shift - key));
             }
           }
           s[kb][r] = y;
@@ -539,6 +549,11 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
     return;
   }
   // O tile through the freed K/V buffers: whole-row stores (fa_device.h store_tile_via_lds)
+  if (packed) {
+    store_tile_via_lds_packed<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op, p.o_rs, p.o_hs, g, w_row0, sq, lane);
+    if (row_valid && hi == 0) lsep[(int64_t)my_hh * sq_true + my_q] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
+    return;
+  }
   store_tile_via_lds<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op + (int64_t)w_row0 * p.o_rs, p.o_rs, sq - w_row0, lane);
   if (row_valid && hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
 }
@@ -585,11 +600,13 @@ __global__ void __launch_bounds__(256) fa_splitkv_combine_kernel(const FwdK p) {
 #pragma unroll
       for (int t = 0; t < EPL; ++t) acc[t] += ws[j] * part[j][t];
   }
-  E* dst = (E*)p.o + (int64_t)b * p.o_bs + (int64_t)i * p.o_rs + (int64_t)h * p.o_hs + lane * EPL;
+  const int g = p.pack_g;                  // packed heads (fa_fwd_kernel): row i of "head" h is query i / g of head h * g + i % g
+  const int iq = g > 1 ? i / g : i, hh = i - iq * g;
+  E* dst = (E*)p.o + (int64_t)b * p.o_bs + (int64_t)iq * p.o_rs + ((int64_t)h * g + hh) * p.o_hs + lane * EPL;
 #pragma unroll
   for (int t = 0; t < EPL; ++t)
     if (col_ok) dst[t] = (E)acc[t];
-  if (lane == 0) p.lse[((int64_t)b * p.h + h) * p.sq + i] = dead ? INFINITY : (mx + __logf(sum));
+  if (lane == 0) p.lse[((int64_t)b * p.h + h) * p.sq + (int64_t)hh * (p.sq / g) + iq] = dead ? INFINITY : (mx + __logf(sum));
 }
 
 template <typename E>

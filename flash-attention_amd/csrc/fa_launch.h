@@ -19,6 +19,7 @@ struct Knobs {
   int bwd_ds_cap_mb;   // FA_BWD_DS_CAP_MB: largest dS workspace FA_BWD_MODE=2 asks for (default 8192)
   int lds_pad;         // FA_IL_LDS_PAD (occupancy experiments, FA_IL_EXPERIMENTS builds only)
   int w64_persist;     // FA_W64_PERSIST: 0 = one workgroup per block (no persistent walk) in the 64-rows-per-wave forward
+  int pack_gqa;        // FA_PACK_GQA: 0 = never pack the query heads of a KV group into the rows of a block on the KV-cache path (A/B, tests)
   int strict;          // FA_STRICT=1: the reference's numerics contract -- rescale on any growth of a row maximum (threshold 0) and
                        // softmax_scale applied in fp32 to every score (never the bf16 pre-scaled Q of the 64-rows-per-wave kernel)
 };
@@ -33,6 +34,7 @@ struct LastSchedule {
   int fwd_list;     // 1 = varlen work list
   int d, bf16;
   int bwd_dq_nw, bwd_list, bwd_spill;
+  int fwd_pack;     // query heads packed into the rows (FwdK::pack_g)
   char name[96];
 };
 LastSchedule& last_schedule();

@@ -259,3 +259,63 @@ def test_varlen_forward_with_paged_kv_and_with_leftpad(kv, causal):
         fin = torch.from_numpy(np.isfinite(l_ref[0]))   # causal with fewer keys than queries: the first rows see no key (lse = +inf)
         assert torch.equal(torch.isposinf(lse[:, qs].cpu()), ~fin)
         assert max_abs(lse[:, qs].cpu()[fin], torch.from_numpy(l_ref[0]).float()[fin]) < 2e-3
+
+
+@pytest.mark.parametrize("feature", ["plain", "local", "alibi", "softcap"])
+@pytest.mark.parametrize("paged,num_splits", [(False, 0), (False, 1), (True, 5)])
+@pytest.mark.parametrize("sq,h,hk", [(1, 8, 2), (2, 16, 2), (5, 8, 1), (16, 8, 1), (7, 12, 4), (32, 8, 2)])
+def test_kvcache_packed_query_heads(kv, knobs, sq, h, hk, paged, num_splits, feature):
+    """Short query chunks with grouped heads (speculative decoding / chunked prefill): the g = H / Hk query heads of a KV
+    group are packed into the rows of one block when g * Sq <= 128 (fa_api.cpp pack_group; FA3's PackGQA, the
+    generalisation of the reference's single-row swap flash_api.cpp:429-437).  Checked against the fp64 oracle and, bit for
+    bit, against the same call with packing switched off (same kernel, same arithmetic per row)."""
+    from flash_attn_amd import backend as be
+    from oracle import attention_oracle as orc
+    torch.manual_seed(11)
+    B, d, cap = 3, 128, 1024
+    g = h // hk
+    causal = True
+    window = (100, 0) if feature == "local" else (-1, -1)
+    softcap = 20.0 if feature == "softcap" else 0.0
+    slopes = (torch.rand(h, device="cuda") * 0.3) if feature == "alibi" else None
+    q = torch.randn(B, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    kn = torch.randn(B, sq, hk, d, device="cuda", dtype=torch.bfloat16)
+    vn = torch.randn_like(kn)
+    lens = torch.tensor([cap - sq, 300, 0], dtype=torch.int32, device="cuda")
+    if paged:
+        page, per = 256, cap // 256
+        kc = torch.randn(B * per + 2, page, hk, d, device="cuda", dtype=torch.bfloat16)
+        vc = torch.randn_like(kc)
+        table = torch.randperm(B * per + 2, device="cuda")[: B * per].reshape(B, per).to(torch.int32)
+    else:
+        kc = torch.randn(B, cap, hk, d, device="cuda", dtype=torch.bfloat16)
+        vc = torch.randn_like(kc)
+        table = None
+
+    def run():
+        kcc, vcc = kc.clone(), vc.clone()
+        o, l = kv.fwd_kvcache(q, kcc, vcc, kn, vn, lens, None, None, None, None, table, slopes, None, d ** -0.5, causal, window[0], window[1],
+                              softcap, True, num_splits)
+        return o, l, kcc, vcc
+
+    out, lse, kc1, vc1 = run()
+    # the binder's own single-row swap (no window, no ALiBi) hands the library a (g, Hk) problem; everything else packs inside
+    swapped = sq == 1 and feature in ("plain", "softcap")
+    assert be.last_schedule()["fwd_pack"] == (1 if swapped else g), be.last_schedule()
+    knobs.set("FA_PACK_GQA", 0)
+    out0, lse0, _, _ = run()
+    assert be.last_schedule()["fwd_pack"] == 1
+    knobs.unset("FA_PACK_GQA")
+    if num_splits == 1:   # unsplit: identical per-row arithmetic (a heuristic split count may differ between the two grids)
+        assert torch.equal(out, out0) and torch.equal(lse, lse0)
+    k_log = kc1[table.long()].reshape(B, cap, hk, d) if paged else kc1
+    v_log = vc1[table.long()].reshape(B, cap, hk, d) if paged else vc1
+    f = lambda t: t.float().cpu().numpy()
+    a = None if slopes is None else slopes.double().cpu().numpy()
+    for b in range(B):
+        L = int(lens[b]) + sq
+        o_ref, l_ref = orc.attention_fwd(f(q[b:b + 1]), f(k_log[b:b + 1, :L]), f(v_log[b:b + 1, :L]), None, causal, window, softcap, a)
+        assert max_abs(out[b:b + 1].float().cpu(), torch.from_numpy(o_ref).float()) < 2e-2
+        fin = np.isfinite(l_ref)
+        assert max_abs(lse[b:b + 1].cpu()[torch.from_numpy(fin)], torch.from_numpy(l_ref[fin]).float()) < 2e-3
+        assert max_abs(out0[b:b + 1].float().cpu(), torch.from_numpy(o_ref).float()) < 2e-2
