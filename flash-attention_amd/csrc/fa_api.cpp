@@ -285,6 +285,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
       fa::SchedK sk{};
       sk.cu_a = a->cu_seqlens_q; sk.cu_o = a->cu_seqlens_k; sk.seqused_o = a->seqused_k;
       sk.list = (int2*)a->workspace; sk.nb = a->b; sk.blk = bm; sk.bound = (int)entries; sk.wl = wl; sk.wr = wr; sk.keys_blocked = 0;
+      sk.work_shift = fa::sched_work_shift(a->seqlen_k);
       if (fa::launch_varlen_schedule(sk, (hipStream_t)stream) != 0)
         return fail(FA_ERR_LAUNCH, "schedule kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
       k.work_list = (const int2*)a->workspace;
@@ -401,6 +402,7 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
       if (qe) {
         sk.cu_a = a->cu_seqlens_q; sk.cu_o = a->cu_seqlens_k; sk.list = (int2*)ws; sk.bound = (int)qe; sk.keys_blocked = 0;
         sk.blk = a->d > 128 ? 128 : fa::bwd_block_m(k.dq_nw);
+        sk.work_shift = fa::sched_work_shift(a->seqlen_k);
         if (fa::launch_varlen_schedule(sk, s) != 0) return fail(FA_ERR_LAUNCH, "schedule kernel launch failed");
         k.q_list = (const int2*)ws; k.q_bound = (int)qe;
         ws += (qe + 1) * 8;
@@ -408,6 +410,7 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
       if (ke) {
         sk.cu_a = a->cu_seqlens_k; sk.cu_o = a->cu_seqlens_q; sk.list = (int2*)ws; sk.bound = (int)ke; sk.keys_blocked = 1;
         sk.blk = fa::bwd_block_n(a->d);
+        sk.work_shift = fa::sched_work_shift(a->seqlen_q);
         if (fa::launch_varlen_schedule(sk, s) != 0) return fail(FA_ERR_LAUNCH, "schedule kernel launch failed");
         k.k_list = (const int2*)ws; k.k_bound = (int)ke;
       }

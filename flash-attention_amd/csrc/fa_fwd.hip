@@ -694,14 +694,18 @@ int launch_rotary(const RotaryK& p, int dtype_bf16, hipStream_t stream) {
 
 // Varlen work list (FA3 has a scheduler pre-pass for the same reason, hopper/flash_prepare_scheduler.cu): one workgroup
 // enumerates the non-empty blocks of the blocked side (query blocks for the forward / dQ, key blocks for dK/dV), estimates
-// each block's work from the mask geometry and writes them heaviest first by a counting sort on work in 64-row tiles.  The
-// order inside a bucket depends on atomics, the results of the attention kernels do not.
+// each block's work from the mask geometry and writes them heaviest first by a counting sort over 1024 work buckets
+// (bucket width = 2^work_shift rows of the other side, chosen on the host so that the longest sequence spans the buckets).
+// The order inside a bucket depends on atomics, the results of the attention kernels do not.
+// Sequences of up to 8 blocks are handled one per thread (thousands of short sequences in parallel); longer ones are queued
+// and walked by the whole workgroup, 1024 blocks at a time (a single 128k-token sequence is 1024 blocks).
 __global__ void __launch_bounds__(1024) fa_varlen_schedule_kernel(const SchedK p) {
   __shared__ int hist[1024];
-  __shared__ int total;
+  __shared__ int long_seq[1024];
+  __shared__ int total, n_long;
   const int t = threadIdx.x;
   hist[t] = 0;
-  if (t == 0) total = 0;
+  if (t == 0) { total = 0; n_long = 0; }
   __syncthreads();
   auto work_key = [&](int len_a, int len_o, int blkidx) {
     const int a0 = blkidx * p.blk, a1 = min(a0 + p.blk, len_a) - 1;
@@ -718,20 +722,46 @@ __global__ void __launch_bounds__(1024) fa_varlen_schedule_kernel(const SchedK p
       if (p.wl >= 0) hi = min(hi, a1 - shift + p.wl);
     }
     const int w = max(0, hi - lo + 1);
-    return 1023 - min(1023, (w + 63) >> 6);  // bucket 0 = heaviest
+    return 1023 - min(1023, (w + (1 << p.work_shift) - 1) >> p.work_shift);  // bucket 0 = heaviest
   };
+  auto seq_lens = [&](int b, int& len_a, int& len_o) {
+    len_a = p.cu_a[b + 1] - p.cu_a[b];
+    len_o = p.cu_o[b + 1] - p.cu_o[b];
+    if (p.seqused_o) len_o = min(len_o, p.seqused_o[b]);
+  };
+  constexpr int SHORT = 8;
   for (int pass = 0; pass < 2; ++pass) {
+    auto visit = [&](int b, int len_a, int len_o, int m) {
+      const int key = work_key(len_a, len_o, m);
+      const int pos = atomicAdd(&hist[key], 1);   // pass 0: count; pass 1: hist holds the bucket cursors
+      if (pass == 1 && pos < p.bound) p.list[1 + pos] = make_int2(b, m);
+    };
     for (int b = t; b < p.nb; b += 1024) {
-      const int len_a = p.cu_a[b + 1] - p.cu_a[b];
-      int len_o = p.cu_o[b + 1] - p.cu_o[b];
-      if (p.seqused_o) len_o = min(len_o, p.seqused_o[b]);
+      int len_a, len_o;
+      seq_lens(b, len_a, len_o);
       const int nblk = (len_a + p.blk - 1) / p.blk;
-      for (int m = 0; m < nblk; ++m) {
-        const int key = work_key(len_a, len_o, m);
-        const int pos = atomicAdd(&hist[key], 1);   // pass 0: count; pass 1: hist holds the bucket cursors
-        if (pass == 1 && pos < p.bound) p.list[1 + pos] = make_int2(b, m);
+      if (nblk <= SHORT) {
+        for (int m = 0; m < nblk; ++m) visit(b, len_a, len_o, m);
+      } else if (pass == 0) {
+        const int slot = atomicAdd(&n_long, 1);
+        if (slot < 1024) long_seq[slot] = b;
+        else for (int m = 0; m < nblk; ++m) visit(b, len_a, len_o, m);   // (more than 1024 long sequences: this thread walks it)
+      } else if (p.nb > 1024) {  // pass 1: was this sequence queued?  Only an overflowing queue leaves unqueued long sequences.
+        bool queued = false;
+        const int nl = min(n_long, 1024);
+        for (int i = 0; i < nl && !queued; ++i) queued = long_seq[i] == b;
+        if (!queued) for (int m = 0; m < nblk; ++m) visit(b, len_a, len_o, m);
       }
       if (pass == 0) atomicAdd(&total, nblk);
+    }
+    __syncthreads();
+    const int nl = min(n_long, 1024);
+    for (int i = 0; i < nl; ++i) {
+      const int b = long_seq[i];
+      int len_a, len_o;
+      seq_lens(b, len_a, len_o);
+      const int nblk = (len_a + p.blk - 1) / p.blk;
+      for (int m = t; m < nblk; m += 1024) visit(b, len_a, len_o, m);
     }
     __syncthreads();
     if (pass == 0) {

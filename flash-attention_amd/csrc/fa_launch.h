@@ -102,7 +102,9 @@ int launch_kv_append(const KvAppendK& p, hipStream_t stream);
 struct SchedK {
   const int32_t* cu_a; const int32_t* cu_o; const int32_t* seqused_o;
   int2* list; int32_t nb, blk, bound, wl, wr, keys_blocked;
+  int32_t work_shift;   // log2 of the work-bucket width in rows of side o: the longest sequence of side o spans the 1024 buckets
 };
+inline int sched_work_shift(int max_len_o) { int s = 6; while (((long)max_len_o >> s) > 1023) ++s; return s; }
 int launch_varlen_schedule(const SchedK& p, hipStream_t stream);
 struct RotaryK {
   const void* x; void* y; const void* cos; const void* sin; const int32_t* offsets;

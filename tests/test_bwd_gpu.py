@@ -240,3 +240,46 @@ def test_varlen_work_list_equals_dense_grid(be, knobs, hk, causal, window):
         rq, rk, rv, _ = orc.attention_bwd(do[qs][None], q[qs][None], k[ks][None], v[ks][None], None, None, scale, causal, window)
         for got, ref in ((listed[2][qs], rq[0]), (listed[3][ks], rk[0]), (listed[4][ks], rv[0])):
             assert max_abs(got.float().cpu(), torch.from_numpy(ref)) < 4e-2 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("shape", ["one_long_many_short", "thousands_of_short"])
+def test_varlen_work_list_extreme_batches(be, knobs, shape):
+    """The schedule pre-pass at its limits: a sequence longer than 64k keys next to short ones (work buckets are scaled to the
+    longest sequence; sequences of more than 8 blocks are walked by the whole workgroup) and a batch of thousands of
+    sequences (one thread each).  Work list == dense grid bit for bit, forward and backward."""
+    g = torch.Generator().manual_seed(7)
+    if shape == "one_long_many_short":
+        lens = [70000, 3, 129, 2500] + [int(x) for x in torch.randint(1, 200, (40,), generator=g)]
+        H, hk, d = 2, 1, 64
+    else:
+        lens = [int(x) for x in torch.randint(0, 70, (3000,), generator=g)] + [1400, 900]
+        H, hk, d = 2, 2, 64
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    torch.manual_seed(1)
+    q = torch.randn(sum(lens), H, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(sum(lens), hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    do = torch.randn_like(q)
+    scale = d ** -0.5
+
+    def run():
+        out, lse, _, _ = be.varlen_fwd(q, k, v, None, cu, cu, None, None, None, None, max(lens), max(lens), 0.0, scale, False, True, -1, -1, 0.0,
+                                       False, None)
+        sched = be.last_schedule()
+        dq, dk, dv, _ = be.varlen_bwd(do, q, k, v, out, lse, None, None, None, cu, cu, None, max(lens), max(lens), 0.0, scale, False, True,
+                                      -1, -1, 0.0, False, None, None)
+        return (out, lse, dq, dk, dv), sched, be.last_schedule()
+
+    listed, s_f, s_b = run()
+    assert s_f["fwd_list"] == 1 and s_b["bwd_list"] == 3, (s_f, s_b)
+    knobs.set("FA_VARLEN_LIST", "0")
+    dense, s_f0, _ = run()
+    assert s_f0["fwd_list"] == 0
+    for a, b_ in zip(listed, dense):
+        assert torch.equal(a, b_)
+    # spot check against the fp32 reference on the tail of the longest sequence's neighbour and a short sequence
+    from tests._util import attention_torch
+    for b in (1, 2, len(lens) - 1):
+        sl = slice(int(cu[b]), int(cu[b + 1]))
+        o32, _ = attention_torch(q[sl][None].float(), k[sl][None].float(), v[sl][None].float(), True)
+        assert max_abs(listed[0][sl].float(), o32[0]) < 2e-2
