@@ -52,9 +52,9 @@ def _sources(names):
 
 def build_lib(force=False):
     hdrs = _sources(["fa_device.h", "fa_kernel_params.h", "fa_launch.h"]) + [os.path.join(ROOT, "include", "fa_gfx950.h")]
-    units = ["fa_fwd.hip", "fa_fwd_il.hip", "fa_fwd_w64.hip", "fa_bwd.hip", "fa_bwd_w64.hip", "fa_api.cpp"]
+    units = ["fa_fwd.hip", "fa_fwd_il.hip", "fa_fwd_w64.hip", "fa_bwd.hip", "fa_bwd_w64.hip", "fa_bwd_dkdv64.hip", "fa_api.cpp"]
     # per-file flags: fa_fwd_w64.hip places its row-sum adds by hand (see the note on asm helpers there)
-    extra = {"fa_fwd_w64.hip": ["-fno-slp-vectorize"], "fa_bwd_w64.hip": ["-fno-slp-vectorize"]}
+    extra = {"fa_fwd_w64.hip": ["-fno-slp-vectorize"], "fa_bwd_w64.hip": ["-fno-slp-vectorize"], "fa_bwd_dkdv64.hip": ["-fno-slp-vectorize"]}
     objs, cmds = [], []
     for u in units:
         src = os.path.join(CSRC, u)

@@ -49,6 +49,7 @@ const fa::Knobs* read_knobs() {
   k->il_sched = env_int("FA_IL_SCHED", 3);
   k->bwd_dq_nw = env_int("FA_BWD_DQ_NW", 0);
   k->bwd_mode = env_int("FA_BWD_MODE", 0);
+  k->bwd_dkdv = env_int("FA_BWD_DKDV", 0);
   k->bwd_ds_cap_mb = env_int("FA_BWD_DS_CAP_MB", 8192);
   k->lds_pad = env_int("FA_IL_LDS_PAD", 0);
   k->w64_persist = env_int("FA_W64_PERSIST", 1);
@@ -316,6 +317,13 @@ int bwd_dq_schedule(const FaBwdParams* a) {
   return (a->d == 128 && plain && a->seqlen_k >= 2048 && a->seqlen_q >= 512) ? 64 : 4;
 }
 
+// dK/dV schedule (fa_launch.h Knobs::bwd_dkdv)
+int bwd_dkdv_schedule(const FaBwdParams* a) {
+  const int knob = fa::knobs().bwd_dkdv;
+  if (knob == 8 || knob == 64) return knob;
+  return 8;
+}
+
 int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
   g_err[0] = 0;
@@ -421,7 +429,12 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   // shapes are handled by the binder, which zero-fills as flash_api.cpp:992-999 does).
   if (a->seqlen_q == 0 || a->seqlen_k == 0 || a->total_q == 0 || a->total_k == 0) return FA_OK;
   int rc = fa::launch_bwd_delta(k, bf, a->d, s);
-  if (rc == 0) rc = fa::launch_bwd_dkdv(k, bf, a->d, s);
+  if (rc == 0) {
+    int dkdv_nw = 64;
+    rc = bwd_dkdv_schedule(a) == 64 ? fa::launch_bwd_dkdv_w64(k, bf, a->d, s) : -2;
+    if (rc == -2) { dkdv_nw = a->d > 128 ? 4 : 8; rc = fa::launch_bwd_dkdv(k, bf, a->d, s); }
+    fa::last_schedule().bwd_dkdv_nw = dkdv_nw;
+  }
   if (rc == 0) rc = k.ds_ws ? fa::launch_bwd_dq_ds(k, bf, a->d, s) : fa::launch_bwd_dq(k, bf, a->d, s);
   if (rc == 0) { fa::last_schedule().bwd_spill = k.ds_ws != nullptr; fa::last_schedule().bwd_list = (k.q_list != nullptr) + 2 * (k.k_list != nullptr); }
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no backward kernel for head dim %d", a->d);
@@ -442,7 +455,7 @@ const char* fa_last_error(void) { return g_err; }
 void fa_knobs_reload(void) { g_knobs.store(read_knobs(), std::memory_order_release); }
 int fa_last_schedule(int32_t* out, int n) {
   const fa::LastSchedule& ls = fa::last_schedule();
-  const int32_t v[FA_SCHEDULE_FIELDS] = {ls.fwd_kernel, ls.fwd_nw, ls.fwd_feat, ls.fwd_splits, ls.fwd_list, ls.d, ls.bf16, ls.bwd_dq_nw, ls.bwd_list, ls.bwd_spill, ls.fwd_pack};
+  const int32_t v[FA_SCHEDULE_FIELDS] = {ls.fwd_kernel, ls.fwd_nw, ls.fwd_feat, ls.fwd_splits, ls.fwd_list, ls.d, ls.bf16, ls.bwd_dq_nw, ls.bwd_list, ls.bwd_spill, ls.fwd_pack, ls.bwd_dkdv_nw};
   for (int i = 0; i < n && i < FA_SCHEDULE_FIELDS; ++i) out[i] = v[i];
   return FA_SCHEDULE_FIELDS;
 }

@@ -189,8 +189,12 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   constexpr int DPW = NDMA / NW;                   // per wave
   static_assert(NDMA % NW == 0 && DPW >= 1, "tile does not divide over the waves");
   float aux_reg = 0.f;  // threads [0,BMQ): LSE*log2e of row tid; [BMQ,2BMQ): delta of row tid-BMQ
-  auto item_head = [&](int it) { return hk * p.hk_ratio + it / nm; };
-  auto item_m0 = [&](int it) { return (m_lo + it % nm) * BMQ; };
+  // item it = (query head it / nm of the group, query tile it % nm), kept as counters for the current and the next item (the
+  // only two anybody asks about): a division per use is ~35 instructions of mixed scalar / vector code, several times per item
+  int it_cur = 0, c_im = 0, c_ih = 0, n_im = (nm > 1) ? 1 : 0, n_ih = (nm > 1) ? 0 : 1;
+  auto item_head = [&](int it) { return hk * p.hk_ratio + (it == it_cur ? c_ih : n_ih); };
+  auto item_m0 = [&](int it) { return (m_lo + (it == it_cur ? c_im : n_im)) * BMQ; };
+  auto item_done = [&]() { ++it_cur; c_im = n_im; c_ih = n_ih; if (++n_im == nm) { n_im = 0; ++n_ih; } };
   auto load_item = [&](int it, int buf) {
     const int h = item_head(it);
     const int m0 = item_m0(it);
@@ -476,7 +480,8 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
     }
     for (int it = 0; it < n_items; it += 2) {
       item(ROLE{}, Q0{}, it);
-      if (it + 1 < n_items) item(ROLE{}, Q1{}, it + 1);
+      item_done();
+      if (it + 1 < n_items) { item(ROLE{}, Q1{}, it + 1); item_done(); }
     }
   };
   if constexpr (!ROT_OK) {

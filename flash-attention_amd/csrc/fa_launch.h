@@ -14,6 +14,7 @@ struct Knobs {
   int varlen_list;     // FA_VARLEN_LIST: 0 = always the dense varlen grid
   int il_sched;        // FA_IL_SCHED: 0 = compiler-ordered pipelined step, else hand-placed slots
   int bwd_dq_nw;       // FA_BWD_DQ_NW: 0 = heuristic; recomputing dQ kernel of 4 or 8 waves x 32 rows, 64 = 4 waves x 64 rows (fa_bwd_w64.hip)
+  int bwd_dkdv;        // FA_BWD_DKDV: 0 = heuristic; 8 = eight waves x 32 keys (fa_bwd.hip), 64 = four waves x 64 keys, software-pipelined (fa_bwd_dkdv64.hip)
   int bwd_mode;        // FA_BWD_MODE: 0 / 1 = the dQ kernel recomputes S, dP, dS (7 contractions, no O(S^2) scratch); 2 = the dK/dV kernel spills
                        // dS and dQ is one contraction (5), fixed-length batches whose dS workspace fits FA_BWD_DS_CAP_MB
   int bwd_ds_cap_mb;   // FA_BWD_DS_CAP_MB: largest dS workspace FA_BWD_MODE=2 asks for (default 8192)
@@ -35,6 +36,7 @@ struct LastSchedule {
   int d, bf16;
   int bwd_dq_nw, bwd_list, bwd_spill;
   int fwd_pack;     // query heads packed into the rows (FwdK::pack_g)
+  int bwd_dkdv_nw;  // dK/dV schedule: 8 = eight waves x 32 keys (4 at head dim 256), 64 = four waves x 64 keys (fa_bwd_dkdv64.hip)
   char name[96];
 };
 LastSchedule& last_schedule();
@@ -124,6 +126,7 @@ int launch_bwd_delta(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_dq_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
+int launch_bwd_dkdv_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);   // fa_bwd_dkdv64.hip: 64 keys per wave, software-pipelined; -2 = not covered
 int launch_bwd_dq_ds(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);    // fa_bwd_w64.hip: dQ = dS.K from the spilled dS   // fa_bwd_w64.hip; -2 = shape / feature not covered
 int bwd_block_m(int dq_nw);   // query rows per dQ workgroup of schedule dq_nw (BwdK::dq_nw)
 int bwd_block_n(int d);   // key rows per dK/dV workgroup (256; 128 for head dim 256)

@@ -24,7 +24,7 @@ def reload_knobs() -> None:
     _cabi.load().fa_knobs_reload()
 
 
-_SCHED_FIELDS = ("fwd_kernel", "fwd_nw", "fwd_feat", "fwd_splits", "fwd_list", "d", "bf16", "bwd_dq_nw", "bwd_list", "bwd_spill", "fwd_pack")
+_SCHED_FIELDS = ("fwd_kernel", "fwd_nw", "fwd_feat", "fwd_splits", "fwd_list", "d", "bf16", "bwd_dq_nw", "bwd_list", "bwd_spill", "fwd_pack", "bwd_dkdv_nw")
 FWD_KERNEL_NAMES = {0: "none", 1: "fa_fwd_kernel", 2: "fa_fwd_il_kernel", 3: "fa_fwd_w64_kernel"}
 
 

@@ -198,8 +198,9 @@ void fa_knobs_reload(void);
  * FA_SCHEDULE_FIELDS int32: {forward kernel id (0 none, 1 lock-step fa_fwd_kernel, 2 pipelined fa_fwd_il_kernel,
  * 3 64-rows-per-wave fa_fwd_w64_kernel), waves per workgroup (16 = 8-wave ping-pong), feature variant, key splits,
  * varlen work list used, head dim, bf16, dQ-kernel waves, backward work lists used, backward spilled dS (5 contractions),
- * query heads packed into the rows of a block (fa_fwd_kvcache, 1 = none)}; returns FA_SCHEDULE_FIELDS (fields are only ever appended). */
-#define FA_SCHEDULE_FIELDS 11
+ * query heads packed into the rows of a block (fa_fwd_kvcache, 1 = none), dK/dV schedule (8 waves x 32 keys, 4 at head dim 256,
+ * or 64 = 4 waves x 64 keys)}; returns FA_SCHEDULE_FIELDS (fields are only ever appended). */
+#define FA_SCHEDULE_FIELDS 12
 int fa_last_schedule(int32_t* out, int n);
 /* Name of the forward kernel instantiation of that call, e.g. "fa::fa_fwd_il_kernel<bf16,128,4,3>" ("" if none). */
 const char* fa_last_kernel_name(void);
