@@ -39,6 +39,9 @@
 #ifndef FA_DKDV_ROT
 #define FA_DKDV_ROT 0  // experiment: 1 = waves 4-7 of the plain D <= 128 dK/dV kernel run their phases rotated by one (see the kernel);
 #endif                 // measured no faster than lock step (profiles/r02_bwd_schedules.txt), so off
+#ifndef FA_DKDV_WALK_DOWN
+#define FA_DKDV_WALK_DOWN 1  // 0 = query tiles always in ascending order (A/B)
+#endif
 #ifndef FA_DKDV_ABL
 #define FA_DKDV_ABL 0  // timing ablations of the dK/dV kernel (results become wrong; tools/ablate_dkdv.sh): 1 no exp2, 2 row-major LDS
 #endif                 // operands read once per sub-tile, 4 transposed operands read once, 8 no DMA wait / barrier per item,
@@ -193,7 +196,15 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   // only two anybody asks about): a division per use is ~35 instructions of mixed scalar / vector code, several times per item
   int it_cur = 0, c_im = 0, c_ih = 0, n_im = (nm > 1) ? 1 : 0, n_ih = (nm > 1) ? 0 : 1;
   auto item_head = [&](int it) { return hk * p.hk_ratio + (it == it_cur ? c_ih : n_ih); };
-  auto item_m0 = [&](int it) { return (m_lo + (it == it_cur ? c_im : n_im)) * BMQ; };
+  // Walk order of the query tiles.  Under a causal (right-bounded) mask key block n sees the tiles m_lo(n) .. last: walking them
+  // DOWN from the last one, all key blocks of a (batch, head) -- co-resident on one XCD -- read the same Q/dO tile at the same
+  // time and it is fetched into that L2 once; walking up, every key block starts at its own m_lo and the L2 would have to
+  // hold the head's whole Q and dO (the round-1 counters: 51 % L2 hits, 2.8x the algorithmic HBM traffic at config 3).
+  const bool walk_down = FA_DKDV_WALK_DOWN && p.wr >= 0 && p.wl < 0;
+  auto item_m0 = [&](int it) {
+    const int im = (it == it_cur ? c_im : n_im);
+    return (m_lo + (walk_down ? nm - 1 - im : im)) * BMQ;
+  };
   auto item_done = [&]() { ++it_cur; c_im = n_im; c_ih = n_ih; if (++n_im == nm) { n_im = 0; ++n_ih; } };
   auto load_item = [&](int it, int buf) {
     const int h = item_head(it);
