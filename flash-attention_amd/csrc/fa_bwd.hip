@@ -39,6 +39,9 @@
 #ifndef FA_DKDV_ROT
 #define FA_DKDV_ROT 0  // experiment: 1 = waves 4-7 of the plain D <= 128 dK/dV kernel run their phases rotated by one (see the kernel);
 #endif                 // measured no faster than lock step (profiles/r02_bwd_schedules.txt), so off
+#ifndef FA_DKDV_CARRY
+#define FA_DKDV_CARRY 0  // experiment: 1 = the first transposed operands of the dV / dK segment are read before the vector phase (in flight under
+#endif                   // it); measured identical (1441 | 2138 vs 1447 | 2146 us, profiles/r02_bwd_schedules.txt)
 #ifndef FA_DKDV_WALK_DOWN
 #define FA_DKDV_WALK_DOWN 1  // 0 = query tiles always in ascending order (A/B)
 #endif
@@ -415,7 +418,9 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
 
   // P2: dV^T[d][key] += dO^T[d][query] . P[query][key] ;  dK^T[d][key] += Q^T[d][query] . dS[query][key]
   // op i: source = dO (even) / Q (odd), d-block (i>>1) % DB, query half t = i / (2*DB); transpose reads PFT-1 ops ahead
-  auto p2 = [&](auto bufc, auto qbc) __attribute__((always_inline)) {
+  // `mid` (the vector phase of the same sub-block, or nothing) runs between the first operand reads and the MFMAs: both waves of a
+  // SIMD reach this point together, so nobody hides the LDS round trip of a segment's first operands unless they are already in flight.
+  auto p2 = [&](auto bufc, auto qbc, auto&& mid) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value, qb = decltype(qbc)::value;
     constexpr int QB_OFF = OFF_Q + buf * QT_BYTES, DOB_OFF = OFF_DO + buf * QT_BYTES, sub = qb * 32 * ROW_BYTES;
     constexpr int NOPS = 4 * DB, PFT = FA_BWD_PFT;
@@ -428,8 +433,13 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
       tlo[i % PFT] = lds_read_tr16(lds + base + (t0p ^ (db << 6)));
       thi[i % PFT] = lds_read_tr16(lds + base + (t1p ^ (db << 6)));
     };
+    if (!FA_DKDV_CARRY) mid();
 #pragma unroll
     for (int i = 0; i < PFT - 1; ++i) rd(i);
+    if (FA_DKDV_CARRY) {
+      __builtin_amdgcn_sched_barrier(0);
+      mid();
+    }
 #pragma unroll
     for (int i = 0; i < NOPS; ++i) {
       if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
@@ -455,9 +465,9 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
     if (has_next && !((FA_DKDV_ABL & 64) && it > 0)) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
     const bool a0 = sub_active(it, 0), a1 = NQB > 1 && sub_active(it, 1);
     if constexpr (role == 0) {
-      if (a0) { p1(CUR{}, Q0{}); sm(CUR{}, Q0{}, it); p2(CUR{}, Q0{}); }
+      if (a0) { p1(CUR{}, Q0{}); p2(CUR{}, Q0{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q0{}, it); }); }
       if constexpr (NQB > 1) {
-        if (a1) { p1(CUR{}, Q1{}); sm(CUR{}, Q1{}, it); p2(CUR{}, Q1{}); }
+        if (a1) { p1(CUR{}, Q1{}); p2(CUR{}, Q1{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q1{}, it); }); }
       }
       if (has_next) store_item(cur ^ 1);
       if (FA_DKDV_ABL & 8) return;
@@ -465,11 +475,11 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
       __syncthreads();
     } else {
       if constexpr (role == 1) {
-        if (a0) { p1(CUR{}, Q0{}); sm(CUR{}, Q0{}, it); p2(CUR{}, Q0{}); }
+        if (a0) { p1(CUR{}, Q0{}); p2(CUR{}, Q0{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q0{}, it); }); }
         if (a1) { p1(CUR{}, Q1{}); sm(CUR{}, Q1{}, it); }
       } else {  // P1 of sub-block 0 ran at the end of the previous item (the first one: before the loop)
-        if (a0) { sm(CUR{}, Q0{}, it); p2(CUR{}, Q0{}); }
-        if (a1) { p1(CUR{}, Q1{}); sm(CUR{}, Q1{}, it); p2(CUR{}, Q1{}); }
+        if (a0) p2(CUR{}, Q0{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q0{}, it); });
+        if (a1) { p1(CUR{}, Q1{}); p2(CUR{}, Q1{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q1{}, it); }); }
       }
       if (has_next) store_item(cur ^ 1);
       if (!(FA_DKDV_ABL & 8)) {
@@ -477,7 +487,7 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
         __syncthreads();      // ... for every wave
       }
       if constexpr (role == 1) {
-        if (a1) p2(CUR{}, Q1{});
+        if (a1) p2(CUR{}, Q1{}, []() {});
       } else {
         if (sub_active(it + 1, 0)) p1(NXT{}, Q0{});
       }
