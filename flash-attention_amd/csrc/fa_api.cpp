@@ -81,6 +81,10 @@ namespace {
 // variants of the 64 / 128 / 256 kernels (fa_fwd.hip: same LDS pitch, fewer k-steps and output blocks) on the lock-step schedules.
 bool head_dim_trimmed(int d) { return d == 32 || d == 96 || d == 192; }
 bool head_dim_native(int d) { return d == 64 || d == 128 || d == 256 || head_dim_trimmed(d); }
+// kernel head dim a forward call runs on: the next built size.  A head dim between the built sizes (a multiple of 8) runs the forward
+// with a run-time column bound (FwdK::d_chunks: the chunks behind the head dim read as zeros, lock-step kernel); the backward has
+// no such bound -- the binders pad training tensors to a built size, and only the KV-cache path sends in-between sizes.
+int head_dim_kernel(int d) { for (int n : {32, 64, 96, 128, 192}) if (d <= n) return n; return 256; }
 int head_dim_pitch(int d) { return d <= 64 ? 64 : d <= 128 ? 128 : 256; }  // row pitch of tiles and of split-KV partial rows
 
 // Reference flash_api.cpp:422-427 (+ :155-162): windows at least as wide as the key sequence are
@@ -165,7 +169,7 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
 // query rows per workgroup of the schedule the forward will run (the lock-step variants serve softcap / ALiBi / dropout /
 // head dim 256 / split keys)
 int fwd_block_rows(const FaFwdParams* a, int nw, bool split) {
-  if (a->d > 128 || head_dim_trimmed(a->d) || split) return 128;
+  if (a->d > 128 || !head_dim_native(a->d) || head_dim_trimmed(a->d) || split) return 128;
   if (nw == 64) return 256;
   if (nw == 34 || nw == 38) return 32 * (nw - 30);  // (the lock-step fallback of a pipelined schedule keeps the wave count)
   return nw == 16 ? 256 : 32 * nw;
@@ -178,7 +182,7 @@ int64_t varlen_list_entries(const FaFwdParams* a, int bm) {
   return (dense * 4 > bound * 5 && dense >= 64) ? bound : 0;
 }
 
-int check_common(int b, int h, int h_k, int d, int dtype, float softcap) {
+int check_common(int b, int h, int h_k, int d, int dtype, float softcap, bool forward = false) {
   if (b <= 0) return fail(FA_ERR_INVALID_ARGUMENT, "batch size must be positive");
   if (h <= 0 || h_k <= 0 || h % h_k != 0)
     return fail(FA_ERR_INVALID_ARGUMENT, "Number of heads in key/value must divide number of heads in query");
@@ -186,7 +190,7 @@ int check_common(int b, int h, int h_k, int d, int dtype, float softcap) {
     return fail(FA_ERR_INVALID_ARGUMENT, "head dimension must be a multiple of 8 and at most 256");
   if (dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_BF16)
     return fail(FA_ERR_INVALID_ARGUMENT, "FlashAttention only supports fp16 and bf16 data type");
-  if (!head_dim_native(d))
+  if (!head_dim_native(d) && !forward)
     return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: head dimension %d is not built natively (32, 64, 96, 128, 192, 256); pad to the next one on the host", d);
   if (softcap < 0.f) return fail(FA_ERR_INVALID_ARGUMENT, "softcap must be non-negative");
   return FA_OK;
@@ -195,7 +199,7 @@ int check_common(int b, int h, int h_k, int d, int dtype, float softcap) {
 int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false) {
   if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
   g_err[0] = 0;
-  if (int rc = check_common(a->b, a->h, a->h_k, a->d, a->dtype, a->softcap)) return rc;
+  if (int rc = check_common(a->b, a->h, a->h_k, a->d, a->dtype, a->softcap, true)) return rc;
   if (!a->q || !a->k || !a->v || !a->o || !a->softmax_lse)
     return fail(FA_ERR_INVALID_ARGUMENT, "q, k, v, o and softmax_lse must be non-NULL");
   if (varlen != (a->cu_seqlens_q != nullptr) || varlen != (a->cu_seqlens_k != nullptr))
@@ -255,7 +259,10 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     k.pack_g = pack; k.h = a->h_k; k.hk_ratio = 1; k.sq = a->seqlen_q * pack;
     nw = 4;
   }
-  if (a->d > 128 || head_dim_trimmed(a->d)) nw = 4;  // head dim 256: one 4-wave lock-step workgroup per CU (512-register budget); trimmed dims: 4-wave lock-step
+  const int dk = head_dim_kernel(a->d);   // kernel head dim; != a->d: run-time column bound
+  const bool bounded = dk != a->d;
+  if (bounded) k.d_chunks = a->d / 8;
+  if (dk > 128 || head_dim_trimmed(dk) || bounded) nw = 4;  // head dim 256: one 4-wave lock-step workgroup per CU (512-register budget); trimmed / bounded dims: 4-wave lock-step
   // decode: split the keys over several workgroups when (batch x heads) cannot fill the chip
   if (kvcache) {
     int split_tiles = 0;
@@ -273,7 +280,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     }
   }
   // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
-  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && k.n_splits == 1 && pack == 1;
+  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && k.n_splits == 1 && pack == 1 && !bounded;
   const bool w64 = nw == 64 && plain && !a->block_table;
   if (nw == 64 && !w64) nw = 8;   // features / paged KV: 8-wave lock-step kernel (same 256-row blocks)
   const bool il = (nw == 34 || nw == 38) && plain;
@@ -294,11 +301,11 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
     }
   }
   fa::choose_units(a->b, a->h_k, k.hk_ratio, k.nmb * k.n_splits, k.n_units, k.unit_size, k.unit_hpx);
-  int rc = w64  ? fa::launch_fwd_w64(k, a->dtype == FA_DTYPE_BF16, a->d, (hipStream_t)stream)
-           : il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, a->d, nw - 30, (hipStream_t)stream)
-                : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, a->d, nw, (hipStream_t)stream);
+  int rc = w64  ? fa::launch_fwd_w64(k, a->dtype == FA_DTYPE_BF16, dk, (hipStream_t)stream)
+           : il ? fa::launch_fwd_il(k, a->dtype == FA_DTYPE_BF16, dk, nw - 30, (hipStream_t)stream)
+                : fa::launch_fwd(k, a->dtype == FA_DTYPE_BF16, dk, nw, (hipStream_t)stream);
   if (rc == 0) fa::last_schedule().fwd_pack = k.pack_g;
-  if (rc == 0 && k.n_splits > 1) rc = fa::launch_splitkv_combine(k, a->dtype == FA_DTYPE_BF16, a->d, (hipStream_t)stream);
+  if (rc == 0 && k.n_splits > 1) rc = fa::launch_splitkv_combine(k, a->dtype == FA_DTYPE_BF16, dk, (hipStream_t)stream);
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
   if (rc == -3)
     return fail(FA_ERR_UNSUPPORTED, "k/v row stride too large: one 64-key tile (64 * row_stride * 2 bytes) must span less than 2 GiB "

@@ -129,7 +129,7 @@ FA_DEVINL int xcd_interleave(int bid, int n_units, int unit_size, int hpx) {
 // blocks and only the first DV columns of a (pitch D) staging row are written out.
 template <typename E, int D, int DV = D>
 FA_DEVINL void store_tile_via_lds(char FA_LDS* stage, const f32x16 (&acc)[DV / 32], float scale, E* gtile, int64_t row_stride,
-                                  int rows_valid, int lane) {
+                                  int rows_valid, int lane, int chunks_valid = DV / 8) {
   using V4 = typename ElemTraits<E>::v4;
   constexpr int ROW_BYTES = D * 2, RS = ROW_BYTES + 16, CPR = D / 8, RPI = 64 / CPR;
   const int qi = lane & 31, hi = lane >> 5;
@@ -146,7 +146,7 @@ FA_DEVINL void store_tile_via_lds(char FA_LDS* stage, const f32x16 (&acc)[DV / 3
   for (int i = 0; i < 32 / RPI; ++i) {
     const int row = i * RPI + lane / CPR, ch = lane % CPR;
     const u32x4 x = *reinterpret_cast<const u32x4 FA_LDS*>(stage + row * RS + ch * 16);
-    if (row < rows_valid && (DV == D || ch < DV / 8)) *reinterpret_cast<u32x4*>(gtile + (int64_t)row * row_stride + ch * 8) = x;
+    if (row < rows_valid && ch < chunks_valid) *reinterpret_cast<u32x4*>(gtile + (int64_t)row * row_stride + ch * 8) = x;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging rows may be rewritten by the caller's next tile
 }
@@ -155,7 +155,7 @@ FA_DEVINL void store_tile_via_lds(char FA_LDS* stage, const f32x16 (&acc)[DV / 3
 // (row0 + r) % g in the group, stored at gbase + query * row_stride + head * head_stride; rows >= rows_total do not exist.
 template <typename E, int D, int DV = D>
 FA_DEVINL void store_tile_via_lds_packed(char FA_LDS* stage, const f32x16 (&acc)[DV / 32], float scale, E* gbase, int64_t row_stride,
-                                         int64_t head_stride, int g, int row0, int rows_total, int lane) {
+                                         int64_t head_stride, int g, int row0, int rows_total, int lane, int chunks_valid = DV / 8) {
   using V4 = typename ElemTraits<E>::v4;
   constexpr int ROW_BYTES = D * 2, RS = ROW_BYTES + 16, CPR = D / 8, RPI = 64 / CPR;
   const int qi = lane & 31, hi = lane >> 5;
@@ -173,7 +173,7 @@ FA_DEVINL void store_tile_via_lds_packed(char FA_LDS* stage, const f32x16 (&acc)
     const int row = i * RPI + lane / CPR, ch = lane % CPR;
     const u32x4 x = *reinterpret_cast<const u32x4 FA_LDS*>(stage + row * RS + ch * 16);
     const int prow = row0 + row, iq = prow / g, hh = prow - iq * g;
-    if (prow < rows_total && (DV == D || ch < DV / 8)) *reinterpret_cast<u32x4*>(gbase + (int64_t)iq * row_stride + (int64_t)hh * head_stride + ch * 8) = x;
+    if (prow < rows_total && ch < chunks_valid) *reinterpret_cast<u32x4*>(gbase + (int64_t)iq * row_stride + (int64_t)hh * head_stride + ch * 8) = x;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }

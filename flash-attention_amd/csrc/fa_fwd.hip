@@ -50,6 +50,9 @@ template <int D> FA_DEVINL constexpr int v_swz(int row) { return D >= 128 ? (row
 
 template <int N> using IC = std::integral_constant<int, N>;
 
+// 16 bytes of zeros in global memory: where a DMA lane fetches from when its chunk lies behind the head dim (FwdK::d_chunks)
+__device__ const uint4 fa_zero_chunk = {0u, 0u, 0u, 0u};
+
 // D = row pitch of the LDS tiles and of the staging layout (64 / 128 / 256); DV = head dimension actually present in memory and
 // contracted over (DV <= D, a multiple of 32).  DV < D are the "trimmed" variants for head dims 32 / 96 / 192 (the reference builds
 // those sizes too: static_switch.h:92-110): the QK^T loop runs DV/16 k-steps, the output has DV/32 blocks, tile columns >= DV are
@@ -135,6 +138,9 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   // Masks, Q / O / LSE addresses and ALiBi slopes go through (row / g, row % g); everything else works on packed rows.
   const int g = p.pack_g;
   const bool packed = g > 1;
+  const int cvr = p.d_chunks > 0 ? p.d_chunks : CV;   // 16-byte chunks of a row that exist in memory (< CV: the rest reads as zeros)
+  const bool bounded = cvr < CV;
+  const E* zsrc = (const E*)&fa_zero_chunk;
   auto q_of = [&](int row) __attribute__((always_inline)) { return packed ? row / g : row; };
 
   const E* __restrict__ qp = (const E*)p.q + q_boff + q_row0 * p.q_rs + (int64_t)h * g * p.q_hs;
@@ -192,7 +198,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   if (!q_staged) {  // few query rows (decode), packed heads or ping-pong schedule: 16-byte loads at row stride
     const E* qrow = qp + (int64_t)my_q * p.q_rs + (int64_t)my_hh * p.q_hs + 8 * hi;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = bitcast_u32x4<V8>(ld_global_16B(qrow + 16 * ks, row_valid));
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = bitcast_u32x4<V8>(ld_global_16B(qrow + 16 * ks, row_valid && 2 * ks + hi < cvr));
   }
 
   // ---- staging: global -> registers -> LDS.  Tile n of K starts at the uniform address
@@ -256,7 +262,9 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
       const int grow = min(n * BN + row, sk - 1) - n * BN;
       int c = ISV ? ((((pc >> 2) ^ v_swz<D>(row)) << 2) | (pc & 3)) : (pc ^ k_swz<D>(row));
       if (DV < D) c = c < CV ? c : 0;  // columns past the head dimension: never read from LDS, fetch something that exists
-      lds_dma_16B(base + (int64_t)grow * rs + c * 8, dst + i * 1024);
+      const E* src = base + (int64_t)grow * rs + c * 8;
+      if (bounded) src = c < cvr ? src : zsrc;
+      lds_dma_16B(src, dst + i * 1024);
     }
   };
 
@@ -447,7 +455,9 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
         const int grow = min(m0 + row, sq - 1);
         int c = pc ^ k_swz<D>(row);
         if (DV < D) c = c < CV ? c : 0;
-        lds_dma_16B(qp + (int64_t)grow * p.q_rs + c * 8, lds + (wave * QDPW + i) * 1024);
+        const E* src = qp + (int64_t)grow * p.q_rs + c * 8;
+        if (bounded) src = c < cvr ? src : zsrc;
+        lds_dma_16B(src, lds + (wave * QDPW + i) * 1024);
       }
       lds_dma_wait_all();
       const int qb = (wave * 32 + qi) * ROW_BYTES;
@@ -550,11 +560,11 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
   }
   // O tile through the freed K/V buffers: whole-row stores (fa_device.h store_tile_via_lds)
   if (packed) {
-    store_tile_via_lds_packed<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op, p.o_rs, p.o_hs, g, w_row0, sq, lane);
+    store_tile_via_lds_packed<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op, p.o_rs, p.o_hs, g, w_row0, sq, lane, cvr);
     if (row_valid && hi == 0) lsep[(int64_t)my_hh * sq_true + my_q] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
     return;
   }
-  store_tile_via_lds<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op + (int64_t)w_row0 * p.o_rs, p.o_rs, sq - w_row0, lane);
+  store_tile_via_lds<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op + (int64_t)w_row0 * p.o_rs, p.o_rs, sq - w_row0, lane, cvr);
   if (row_valid && hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
 }
 
@@ -580,7 +590,7 @@ __global__ void __launch_bounds__(256) fa_splitkv_combine_kernel(const FwdK p) {
   for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
   const float wgt = dead ? 0.f : e / sum;  // exp(lse_s - lse)
   constexpr int EPL = D / 64;              // output elements per lane (partial rows have pitch D; columns >= DV do not exist)
-  const bool col_ok = lane * EPL < DV;
+  const bool col_ok = lane * EPL < (p.d_chunks > 0 ? 8 * p.d_chunks : DV);
   float acc[EPL];
 #pragma unroll
   for (int t = 0; t < EPL; ++t) acc[t] = 0.f;

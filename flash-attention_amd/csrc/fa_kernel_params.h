@@ -39,6 +39,9 @@ struct FwdK {
   float rescale_thr;         // O rescale deferred until a row max grows by more than this (log2 units)
   int32_t pack_g;            // >= 1.  g > 1 (fa_fwd_kernel, KV-cache path): the g query heads of a KV group are packed into the rows: h = h_k,
                              // hk_ratio = 1, sq = g * (true query count), row r = query r / g of query head head * g + r % g
+  int32_t d_chunks;          // fa_fwd_kernel: > 0 => only the first d_chunks 16-byte chunks of a row exist in memory (head dim = 8 * d_chunks <
+                             // the kernel's DV); the chunks behind them are read as zeros and never stored (KV-cache path, head dims between
+                             // the built sizes: a cache cannot be padded on the fly)
   int32_t persist_total;     // fa_fwd_w64: > 0 => persistent launch, blocks 0 .. persist_total-1 are walked by gridDim.x workgroups
   int32_t work_bound;        // entries the list can hold (grid = work_bound * h)
   const int2* work_list;     // varlen: {count,0}, then {batch, query block} pairs, heaviest first (nullptr => dense grid)

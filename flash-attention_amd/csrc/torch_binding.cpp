@@ -485,8 +485,8 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tenso
   const int64_t page = paged ? kcache.size(1) : 0;
   const int64_t Sk = paged ? block_table_->size(1) * page : kcache.size(1);
   TORCH_CHECK(B > 0, "batch size must be positive");
-  // (the cache cannot be padded on the fly, so the decode path takes the head dims that have their own kernels)
-  TORCH_CHECK(D == native_head_dim(D), "libfa_gfx950: fwd_kvcache is built for head dimensions 32, 64, 96, 128, 192 and 256");
+  // (a cache cannot be padded on the fly: head dims between the built sizes run the forward with a run-time column bound)
+  TORCH_CHECK(D % 8 == 0 && D <= 256, "libfa_gfx950: fwd_kvcache takes head dimensions that are a multiple of 8, up to 256");
   TORCH_CHECK(H % Hk == 0, "Number of heads in key/value must divide number of heads in query");
   TORCH_CHECK(kcache.size(3) == D && vcache.sizes() == kcache.sizes(), "kcache / vcache shape mismatch");
   if (paged) {

@@ -486,8 +486,8 @@ def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_,
     Hk = kcache.shape[2]
     page = kcache.shape[1] if paged else 0
     Sk = block_table_.shape[1] * page if paged else kcache.shape[1]
-    if D not in _NATIVE_HEAD_DIMS:
-        raise RuntimeError("libfa_gfx950: fwd_kvcache is built for head dimensions 32, 64, 96, 128, 192 and 256")
+    if D % 8 != 0 or D > 256:
+        raise RuntimeError("libfa_gfx950: fwd_kvcache takes head dimensions that are a multiple of 8, up to 256")
     if H % Hk != 0:
         raise RuntimeError("Number of heads in key/value must divide number of heads in query")
     if paged and page % 256 != 0:

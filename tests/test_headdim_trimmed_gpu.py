@@ -215,3 +215,49 @@ def test_interface_pads_only_to_the_next_native_size():
         assert max_abs(out.float(), o32) <= 2 * max_abs(opt.float(), o32) + 1e-4
         out.sum().backward()
         assert q.grad.shape == q.shape and torch.isfinite(q.grad).all()
+
+
+@pytest.mark.parametrize("binder", ["ext", "ctypes"])
+@pytest.mark.parametrize("d", [8, 40, 72, 80, 104, 160, 224])
+@pytest.mark.parametrize("sq,causal,num_splits,paged", [(1, False, 0, False), (1, False, 5, True), (3, True, 1, False), (70, True, 0, True)])
+def test_kvcache_head_dims_between_the_built_sizes(binder, d, sq, causal, num_splits, paged):
+    """fwd_kvcache takes any head dim that is a multiple of 8 (reference mha_fwd_kvcache, flash_api.cpp:1300-1310, predicates the
+    columns in-kernel).  Here the next built kernel runs with a run-time column bound (FwdK::d_chunks): chunks behind the head dim
+    read as zeros -- the memory there is the NEXT head's data, so a kernel that read it would miss the oracle -- and are never
+    stored (the output rows are followed by the next head's output)."""
+    from oracle import attention_oracle as orc
+    if binder == "ext":
+        import flash_attn_2_cuda as kv
+    else:
+        from flash_attn_amd import backend as kv
+    from flash_attn_amd import backend as be
+    torch.manual_seed(6)
+    B, H, hk, cap = 2, 4, 2, 1024
+    q = torch.randn(B, sq, H, d, device="cuda", dtype=torch.bfloat16)
+    kn = torch.randn(B, sq, hk, d, device="cuda", dtype=torch.bfloat16)
+    vn = torch.randn_like(kn)
+    lens = torch.tensor([cap - sq, 130], dtype=torch.int32, device="cuda")
+    if paged:
+        page, per = 256, cap // 256
+        kc = torch.randn(B * per + 1, page, hk, d, device="cuda", dtype=torch.bfloat16)
+        vc = torch.randn_like(kc)
+        table = torch.randperm(B * per + 1, device="cuda")[: B * per].reshape(B, per).to(torch.int32)
+    else:
+        kc = torch.randn(B, cap, hk, d, device="cuda", dtype=torch.bfloat16)
+        vc = torch.randn_like(kc)
+        table = None
+    out_buf = torch.full((B, sq, H, d), float("nan"), device="cuda", dtype=torch.bfloat16)
+    out, lse = kv.fwd_kvcache(q, kc, vc, kn, vn, lens, None, None, None, None, table, None, out_buf, d ** -0.5, causal, -1, -1, 0.0, True, num_splits)
+    s = be.last_schedule()
+    dk = next(n for n in (32, 64, 96, 128, 192, 256) if d <= n)
+    assert s["d"] == dk and s["fwd_kernel"] == 1, s
+    k_log = kc[table.long()].reshape(B, cap, hk, d) if paged else kc
+    v_log = vc[table.long()].reshape(B, cap, hk, d) if paged else vc
+    f = lambda t: t.float().cpu().numpy()
+    for b in range(B):
+        L = int(lens[b]) + sq
+        assert torch.equal(k_log[b, L - sq:L], kn[b]) and torch.equal(v_log[b, L - sq:L], vn[b])
+        o_ref, l_ref = orc.attention_fwd(f(q[b:b + 1]), f(k_log[b:b + 1, :L]), f(v_log[b:b + 1, :L]), None, causal, (-1, -1))
+        assert torch.isfinite(out[b]).all()
+        assert max_abs(out[b:b + 1].float().cpu(), torch.from_numpy(o_ref).float()) < 2e-2
+        assert max_abs(lse[b:b + 1].cpu(), torch.from_numpy(l_ref).float()) < 2e-3
