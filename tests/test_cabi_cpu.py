@@ -53,8 +53,13 @@ def test_cabi_rejects_bad_arguments_without_touching_the_gpu(built):
     a.b, a.h, a.h_k, a.d, a.dtype = 1, 3, 2, 128, _cabi.FA_DTYPE_BF16
     assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT
     assert b"heads" in lib.fa_last_error()
-    a.h_k, a.d = 1, 72
-    assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_UNSUPPORTED
+    a.h_k, a.d = 1, 72   # the forward takes any multiple of 8 (run-time column bound): rejected later, for its NULL tensors
+    assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"non-NULL" in lib.fa_last_error()
+    a.d = 60
+    assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"multiple of 8" in lib.fa_last_error()
+    g = _cabi.FaBwdParams()   # the backward is built for 32 / 64 / 96 / 128 / 192 / 256 only
+    g.b, g.h, g.h_k, g.d, g.dtype = 1, 2, 1, 72, _cabi.FA_DTYPE_BF16
+    assert lib.fa_bwd(ctypes.byref(g), None) == _cabi.FA_ERR_UNSUPPORTED and b"72" in lib.fa_last_error()
     a.d, a.dtype = 128, 7
     assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT
     a.dtype = _cabi.FA_DTYPE_FP16
