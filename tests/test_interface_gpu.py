@@ -167,3 +167,53 @@ def test_single_query_row_grouped_heads_swap(varlen):
                 ref, lse_ref = orc.attention_fwd(q[b:b + 1], ks, vs, None, False)
                 assert float((out[b].float().cpu() - torch.from_numpy(ref)[0, 0]).abs().max()) < 2e-2
                 assert float((lse[:, b].cpu() - torch.from_numpy(lse_ref)[0, :, 0]).abs().max()) < 2e-3
+
+
+def test_first_calls_from_two_threads_and_per_thread_schedule_report():
+    """Launcher state under threads, in a fresh process so that these ARE the first calls: the dynamic-LDS attribute of every
+    kernel instantiation is set on first use (per device, lock-free: fa_launch.h ensure_dyn_lds) and fa_last_schedule /
+    fa_last_error are thread-local.  Two threads start at a barrier, one on head dim 64 and one on 128 (kernels with > 64 KB
+    of dynamic LDS), each on its own stream; both must match the single-threaded results bit for bit and each must read its
+    own schedule report."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, threading
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+from flash_attn_amd import backend as be
+torch.manual_seed(0)
+shapes = {64: (2, 1024, 4, 64), 128: (2, 1024, 4, 128)}
+inp = {d: [torch.randn(*s, device="cuda", dtype=torch.bfloat16) for _ in range(4)] for d, s in shapes.items()}
+res, sched, errs = {}, {}, []
+bar = threading.Barrier(2)
+def work(d):
+    try:
+        q, k, v, do = inp[d]
+        st = torch.cuda.Stream()
+        bar.wait()
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                out, lse, _, _ = be.fwd(q, k, v, None, None, 0.0, d ** -0.5, True, -1, -1, 0.0, False, None)
+                s1 = be.last_schedule()
+                g = be.bwd(do, q, k, v, out, lse, None, None, None, None, 0.0, d ** -0.5, True, -1, -1, 0.0, False, None, None)
+        st.synchronize()
+        res[d] = (out, lse) + tuple(g[:3]); sched[d] = s1
+    except Exception as e:  # noqa
+        errs.append(repr(e))
+ts = [threading.Thread(target=work, args=(d,)) for d in (64, 128)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not errs, errs
+for d in (64, 128):
+    assert sched[d]["d"] == d, sched
+    q, k, v, do = inp[d]
+    out, lse, _, _ = be.fwd(q, k, v, None, None, 0.0, d ** -0.5, True, -1, -1, 0.0, False, None)
+    g = be.bwd(do, q, k, v, out, lse, None, None, None, None, 0.0, d ** -0.5, True, -1, -1, 0.0, False, None, None)
+    for a, b in zip(res[d], (out, lse) + tuple(g[:3])):
+        assert torch.equal(a, b)
+print("threads ok")
+''' % (root, os.path.join(root, "flash-attention_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "threads ok" in r.stdout, r.stdout + r.stderr
