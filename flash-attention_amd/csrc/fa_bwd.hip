@@ -42,6 +42,9 @@
 #ifndef FA_DKDV_CARRY
 #define FA_DKDV_CARRY 0  // experiment: 1 = the first transposed operands of the dV / dK segment are read before the vector phase (in flight under
 #endif                   // it); measured identical (1441 | 2138 vs 1447 | 2146 us, profiles/r02_bwd_schedules.txt)
+#ifndef FA_DKDV_PRESCALE
+#define FA_DKDV_PRESCALE 1  // 0 = the plain dK/dV kernel subtracts LSE and delta on the vector ALU like the feature variants (A/B)
+#endif
 #ifndef FA_DKDV_WALK_DOWN
 #define FA_DKDV_WALK_DOWN 1  // 0 = query tiles always in ascending order (A/B)
 #endif
@@ -112,6 +115,13 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   static_assert(DV % 32 == 0 && DV <= D && 2 * DV >= D, "DV: a multiple of 32 in [D/2, D]");
   constexpr int VBLK_BYTES = BNK * ROW_BYTES;
   constexpr int QT_BYTES = BMQ * ROW_BYTES;
+  // PRE (plain variant): the matrix pipe does the two per-element subtractions.  This wave's K fragments are multiplied by
+  // softmax_scale*log2(e) once, when they are loaded (rounded once to the input dtype, like Q in fa_fwd_w64.hip), and the score chain's
+  // first MFMA takes C = -LSE*log2(e) of its rows instead of 0, so the scores leave the pipe as the exponent of P; the dP chain
+  // starts from C = -delta.  Per element that leaves exp2, one multiply and the packing (was: fma, exp2, sub, mul, packing) -- in a kernel
+  // whose vector phase does not overlap its matrix phases (profiles/r02_bwd_schedules.txt).  FA_STRICT=1 runs the run-time-checked
+  // variant instead, which scales every score in fp32.
+  constexpr bool PRE = (FEAT == FEAT_NONE) && FA_DKDV_PRESCALE;
   // LDS: Q0 | Q1 | dO0 | dO1 | V block | aux0 aux1   (aux = BMQ x LSE*log2e followed by BMQ x delta).  The streamed tiles
   // sit below 64 KB so that (buffer, sub-block) offsets fit the 16-bit immediate of ds_read.
   constexpr int OFF_Q = 0, OFF_DO = 2 * QT_BYTES, OFF_V = 4 * QT_BYTES, OFF_AUX = OFF_V + VBLK_BYTES;
@@ -173,6 +183,12 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
     const E* krow = kp + (int64_t)my_key * p.k_rs + 8 * hi;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) kf[ks] = bitcast_u32x4<V8>(ld_global_16B(krow + 16 * ks, key_valid));
+    if constexpr (PRE) {  // K <- K * softmax_scale * log2(e), rounded once to the input dtype (see PRE above)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[ks][j] = (E)((float)kf[ks][j] * p.scale_log2);
+    }
   }
   // V block -> LDS (B operand of dP = dO.V^T is re-read per step to keep registers for the accumulators)
   {
@@ -234,6 +250,7 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
       const float* src = (tid < BMQ ? p.lse : p.delta) + base + m0 + r;
       const float x = ok ? *src : 0.f;
       aux_reg = (tid < BMQ) ? (ok ? x * kLog2e : INFINITY) : x;  // rows past the end: LSE = +inf => P = 0
+      if constexpr (PRE) aux_reg = -aux_reg;                           // (the C operands of the score / dP chains)
     }
   };
   auto store_item = [&](int buf) {
@@ -301,6 +318,17 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
     constexpr int NOPS = 2 * KS, PF = FA_BWD_PF;
     u32x4 ra[PF], rb[2];
     const int k0p = opaque(k0), kv0p = opaque(kv0);
+    f32x16 c_s, c_dp;   // PRE: -LSE*log2e / -delta of the accumulator rows (queries acc_row(r, hi))
+    if constexpr (PRE) {
+      const int auxp = opaque(aux_lane);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4);
+        const f32x4 d4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4 + BMQ * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c_s[4 * g + j] = l4[j]; c_dp[4 * g + j] = d4[j]; }
+      }
+    }
     auto rd = [&](int j) __attribute__((always_inline)) {
       const int ks = j >> 1;
       if ((FA_DKDV_ABL & 2) && j >= 2) { ra[j % PF] = ra[(j & 1) % PF]; if (j & 1) rb[ks & 1] = rb[0]; return; }
@@ -320,8 +348,12 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
       const int ks = j >> 1;
       f32x16 c = (j & 1) ? dp : s;
       if (j < 2) {
+        if constexpr (PRE) {
+          c = (j & 1) ? c_dp : c_s;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+          for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        }
       }
       if ((FA_DKDV_ABL & 16) && j >= 2) { if ((j & 1) == 0) s = c; else dp = c; continue; }
       if ((j & 1) == 0) s = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), kf[ks], c);
@@ -377,8 +409,11 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
     const int auxp = opaque(aux_lane);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4);
-      const f32x4 d4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4 + BMQ * 4);
+      f32x4 l4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (!PRE) {
+        l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4);
+        d4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4 + BMQ * 4);
+      }
       // Dropout: the 4 lanes of a quad hold the 4 keys of one key group; lane a hashes query row a of this 4-row
       // group (4 bytes = those 4 keys) and the quad exchanges words, so each lane reads its key's byte of every row.
       uint32_t hq = 0u;
@@ -388,7 +423,8 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = 4 * g + j;
-        const float pv = (FA_DKDV_ABL & 1) ? __builtin_fmaf(s[r], cs, -l4[j]) : fast_exp2(__builtin_fmaf(s[r], cs, -l4[j]));
+        const float ex = PRE ? s[r] : __builtin_fmaf(s[r], cs, -l4[j]);   // PRE: the pipe already delivered S*c - LSE*log2e, and dP - delta
+        const float pv = (FA_DKDV_ABL & 1) ? ex : fast_exp2(ex);
         float pkeep = pv, dpe = dp[r];
         if constexpr (F_DROP) {
           if (drop) {  // Z = keep / (1 - p): dV uses P*Z (the 1/(1-p) is applied to dV at the end), dS = P*(dP*Z - delta)
@@ -398,7 +434,7 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
             dpe = keep ? dp[r] * p.rp_keep : 0.f;
           }
         }
-        float dsv = pv * (dpe - d4[j]);
+        float dsv = PRE ? pv * dpe : pv * (dpe - d4[j]);
         if constexpr (F_CAP) dsv *= dcap[r];
         pfrag[r >> 3][r & 7] = (E)pkeep;
         dsfrag[r >> 3][r & 7] = (E)dsv;
@@ -831,7 +867,8 @@ static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
 // trimmed head dims (DV < D) are built plain and as the run-time-checked all-features variant only
 template <typename E, int D, int DV>
 static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
-  const int feat = feat_code(p.softcap > 0.f, p.alibi != nullptr, p.rng != nullptr);
+  int feat = feat_code(p.softcap > 0.f, p.alibi != nullptr, p.rng != nullptr);
+  if (feat == FEAT_NONE && knobs().strict) feat = FEAT_ALL;   // FA_STRICT: every score scaled in fp32 (the plain variant pre-scales K)
   if constexpr (DV < D) {
     return feat == FEAT_NONE ? launch_dkdv_a<E, D, DV, FEAT_NONE>(p, stream) : launch_dkdv_a<E, D, DV, FEAT_ALL>(p, stream);
   } else {

@@ -206,3 +206,25 @@ def test_dkdv_w64_kernel_matches_eight_wave_kernel_and_fp32(be, knobs, dtype, sh
         e64 = float((w[i].float() - r[i]).abs().max())
         assert torch.isfinite(w[i].float()).all()
         assert e64 <= max(2 * e8, floor), (i, e64, e8)
+
+
+@pytest.mark.parametrize("shape", [SHAPES[1], SHAPES[5], SHAPES[8]], ids=lambda s: "B%d_Sq%d_Sk%d_H%d_%d_c%d_w%d_%d" % s)
+def test_strict_knob_keeps_fp32_score_scaling_in_the_backward(be, knobs, shape):
+    """The plain dK/dV kernel multiplies its K fragments by softmax_scale*log2(e) once (rounded to the input dtype) and lets the
+    matrix pipe subtract LSE and delta (C operands of the score / dP chains).  FA_STRICT=1 routes to the variant that scales every
+    score in fp32, as the reference does (flash_bwd_kernel.h:536).  Both must sit inside the usual error budget of the fp32
+    reference; the strict one is the yardstick."""
+    B, Sq, Sk, H, Hk, causal, wl, wr = shape
+    torch.manual_seed(0)
+    q = torch.randn(B, Sq, H, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, Sk, Hk, 128, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    do = torch.randn_like(q)
+    fast = run_bwd(be, q, k, v, do, causal, wl, wr)
+    knobs.set("FA_STRICT", 1)
+    strict = run_bwd(be, q, k, v, do, causal, wl, wr)
+    r = ref_grads(q, k, v, do, causal, wl, wr)
+    for i in range(3):
+        e_s = float((strict[i].float() - r[i]).abs().max())
+        e_f = float((fast[i].float() - r[i]).abs().max())
+        assert e_f <= max(2 * e_s, 1e-2), (i, e_f, e_s)
