@@ -841,7 +841,17 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
 // launchers
 // ------------------------------------------------------------------------------------------------
 // query rows per dQ workgroup for the schedule BwdK::dq_nw: 4 | 8 waves x 32 rows, or 64 = 4 waves x 64 rows (fa_bwd_w64.hip)
+// The launchers come in two halves so that build.py can compile this file twice side by side (-DFA_BWD_PART=1: delta + dK/dV,
+// =2: dQ; 0 = everything in one object): the dK/dV and dQ instantiations are independent and dominate the library's build time.
+#ifndef FA_BWD_PART
+#define FA_BWD_PART 0
+#endif
+#if FA_BWD_PART != 1
 int bwd_block_m(int nw) { return (nw == 8 || nw == 64) ? 256 : 128; }
+#else
+int bwd_block_m(int nw);
+#endif
+#if FA_BWD_PART != 2
 int bwd_block_n(int d) { return (d > 128 || FA_DKDV_SPLIT) ? 128 : 256; }
 
 template <typename E, int D, int DV>
@@ -884,6 +894,8 @@ static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
   }
 }
 
+#endif  // FA_BWD_PART != 2
+#if FA_BWD_PART != 1
 template <typename E, int D, int DV, int NW, int FEAT>
 static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2 + NW * 32 * 16;  // K/V double buffers (+ the row padding of the staged dQ epilogue)
@@ -917,6 +929,8 @@ static int launch_dq_t(const BwdK& p, hipStream_t stream) {
   }
 }
 
+#endif  // FA_BWD_PART != 1
+
 #define FA_BWD_DISPATCH_E(fn, E)                                       \
   switch (d) {                                                         \
     case 128: return fn<E, 128, 128>(p, stream);                       \
@@ -930,8 +944,11 @@ static int launch_dq_t(const BwdK& p, hipStream_t stream) {
 #define FA_BWD_DISPATCH(fn)                                            \
   if (dtype_bf16) { FA_BWD_DISPATCH_E(fn, __bf16) } else { FA_BWD_DISPATCH_E(fn, _Float16) }
 
+#if FA_BWD_PART != 2
 int launch_bwd_delta(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_delta_t) }
 int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_dkdv_t) }
+#endif
+#if FA_BWD_PART != 1
 int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   LastSchedule& ls = last_schedule();
   const bool trimmed = (d == 32 || d == 96 || d == 192);
@@ -942,5 +959,6 @@ int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   }
   FA_BWD_DISPATCH(launch_dq_t)
 }
+#endif
 
 }  // namespace fa

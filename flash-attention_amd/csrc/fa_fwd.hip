@@ -51,7 +51,15 @@ template <int D> FA_DEVINL constexpr int v_swz(int row) { return D >= 128 ? (row
 template <int N> using IC = std::integral_constant<int, N>;
 
 // 16 bytes of zeros in global memory: where a DMA lane fetches from when its chunk lies behind the head dim (FwdK::d_chunks)
-__device__ const uint4 fa_zero_chunk = {0u, 0u, 0u, 0u};
+static __device__ const uint4 fa_zero_chunk = {0u, 0u, 0u, 0u};
+
+// build.py compiles this file twice side by side (-DFA_FWD_PART=1: the bf16 instantiations of fa_fwd_kernel + everything else in
+// here, =2: the fp16 instantiations only; 0 = one object): its ~130 kernel instantiations are the slowest unit of the build.
+#ifndef FA_FWD_PART
+#define FA_FWD_PART 0
+#endif
+int launch_fwd_bf16(const FwdK& p, int d, int nw, hipStream_t stream);
+int launch_fwd_f16(const FwdK& p, int d, int nw, hipStream_t stream);
 
 // D = row pitch of the LDS tiles and of the staging layout (64 / 128 / 256); DV = head dimension actually present in memory and
 // contracted over (DV <= D, a multiple of 32).  DV < D are the "trimmed" variants for head dims 32 / 96 / 192 (the reference builds
@@ -619,6 +627,7 @@ __global__ void __launch_bounds__(256) fa_splitkv_combine_kernel(const FwdK p) {
   if (lane == 0) p.lse[((int64_t)b * p.h + h) * p.sq + (int64_t)hh * (p.sq / g) + iq] = dead ? INFINITY : (mx + __logf(sum));
 }
 
+#if FA_FWD_PART != 2
 template <typename E>
 static int launch_combine_e(const FwdK& p, int d, dim3 grid, dim3 block, hipStream_t stream) {
   switch (d) {
@@ -835,6 +844,8 @@ int launch_kv_append(const KvAppendK& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+#endif  // FA_FWD_PART != 2
+
 template <typename E, int D, int DV, int NW, int FEAT, bool PP>
 static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2 + NW * 32 * 16;  // K/V double buffers (+ the row padding of the staged O epilogue)
@@ -852,7 +863,9 @@ static int launch_fwd_t(const FwdK& p, hipStream_t stream) {
   return 0;
 }
 
+#if FA_FWD_PART != 2
 int fwd_block_m(int nw) { return nw == 16 ? 256 : 32 * nw; }
+#endif
 
 template <typename E, int D, int FEAT>
 static int launch_fwd_f(const FwdK& p, int nw, hipStream_t stream) {
@@ -901,11 +914,17 @@ static int launch_fwd_e(const FwdK& p, int d, int nw, hipStream_t stream) {
   }
 }
 
+#if FA_FWD_PART != 1
+int launch_fwd_f16(const FwdK& p, int d, int nw, hipStream_t stream) { return launch_fwd_e<_Float16>(p, d, nw, stream); }
+#endif
+#if FA_FWD_PART != 2
+int launch_fwd_bf16(const FwdK& p, int d, int nw, hipStream_t stream) { return launch_fwd_e<__bf16>(p, d, nw, stream); }
 // nw: 4 / 8 = lock-step schedule with 4 / 8 waves per workgroup, 16 = 8-wave ping-pong schedule
 int launch_fwd(const FwdK& p, int dtype_bf16, int d, int nw, hipStream_t stream) {
   // the scalar-base + 32-bit lane-offset tile loads need one tile's extent to fit 32 bits
   if ((uint64_t)64 * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 31)) return -3;
-  return dtype_bf16 ? launch_fwd_e<__bf16>(p, d, nw, stream) : launch_fwd_e<_Float16>(p, d, nw, stream);
+  return dtype_bf16 ? launch_fwd_bf16(p, d, nw, stream) : launch_fwd_f16(p, d, nw, stream);
 }
+#endif
 
 }  // namespace fa

@@ -765,20 +765,34 @@ static int launch_fwd_w64_t(const FwdK& p, hipStream_t stream) {
   return 0;
 }
 
+// build.py compiles this file twice side by side (-DFA_W64_PART=1: bf16, =2: fp16; 0 = one object): the hand-unrolled steps make it
+// the slowest unit of the build.
+#ifndef FA_W64_PART
+#define FA_W64_PART 0
+#endif
+int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream);
+int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream);
+#if FA_W64_PART != 1
+int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream) {
+  if (d == 128) return launch_fwd_w64_t<_Float16, 128>(p, stream);
+  if (d == 64) return launch_fwd_w64_t<_Float16, 64>(p, stream);
+  return -2;
+}
+#endif
+#if FA_W64_PART != 2
+int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream) {
+  if (d == 128) return launch_fwd_w64_t<__bf16, 128>(p, stream);
+  if (d == 64) return launch_fwd_w64_t<__bf16, 64>(p, stream);
+  return -2;
+}
 // 4 waves x 64 query rows per workgroup.  Plain attention only (no softcap / ALiBi / dropout / split keys / paged KV).
 int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   if (p.softcap > 0.f || p.alibi != nullptr || p.rng != nullptr || p.n_splits > 1 || p.block_table != nullptr) return -2;
   // buffer addressing: 32-bit byte offsets from the (batch, kv-head) base
   const uint64_t span = ((uint64_t)(p.sk > 0 ? p.sk : 1) + 128) * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u;
   if (span >= (1ull << 32)) return -3;
-  if (dtype_bf16) {
-    if (d == 128) return launch_fwd_w64_t<__bf16, 128>(p, stream);
-    if (d == 64) return launch_fwd_w64_t<__bf16, 64>(p, stream);
-  } else {
-    if (d == 128) return launch_fwd_w64_t<_Float16, 128>(p, stream);
-    if (d == 64) return launch_fwd_w64_t<_Float16, 64>(p, stream);
-  }
-  return -2;
+  return dtype_bf16 ? launch_fwd_w64_bf16(p, d, stream) : launch_fwd_w64_f16(p, d, stream);
 }
+#endif
 
 }  // namespace fa

@@ -10,7 +10,7 @@ if [ "$1" != "run" ]; then
   mkdir -p gpurun_abl
   for m in $MASKS; do
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFA_DKDV_ABL=$m $EXTRA -c $PKG/csrc/fa_bwd.hip -o gpurun_abl/bwd_$m.o &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_dkdv_$m.so $PKG/csrc/fa_fwd.o $PKG/csrc/fa_fwd_il.o $PKG/csrc/fa_fwd_w64.o gpurun_abl/bwd_$m.o $PKG/csrc/fa_bwd_w64.o $PKG/csrc/fa_api.o && rm gpurun_abl/bwd_$m.o ) &
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_dkdv_$m.so $PKG/csrc/fa_fwd_bf16.o $PKG/csrc/fa_fwd_f16.o $PKG/csrc/fa_fwd_il.o $PKG/csrc/fa_fwd_w64_bf16.o $PKG/csrc/fa_fwd_w64_f16.o gpurun_abl/bwd_$m.o $PKG/csrc/fa_bwd_w64.o $PKG/csrc/fa_bwd_dkdv64.o $PKG/csrc/fa_api.o && rm gpurun_abl/bwd_$m.o ) &
   done
   wait
   ls gpurun_abl

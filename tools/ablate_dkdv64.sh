@@ -10,7 +10,7 @@ if [ "$1" != "run" ]; then
   for v in $VARIANTS; do
     name=${v%%:*}; flags=$(echo "${v#*:}" | tr ',' ' ')
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c $PKG/csrc/fa_bwd_dkdv64.hip -o gpurun_abl/dk64_$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Spill|Scratch" | sort | uniq -c | tr '\n' ' '; echo " <- $name";
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_dk64_$name.so $PKG/csrc/fa_fwd.o $PKG/csrc/fa_fwd_il.o $PKG/csrc/fa_fwd_w64.o $PKG/csrc/fa_bwd.o $PKG/csrc/fa_bwd_w64.o gpurun_abl/dk64_$name.o $PKG/csrc/fa_api.o && rm gpurun_abl/dk64_$name.o ) &
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_dk64_$name.so $PKG/csrc/fa_fwd_bf16.o $PKG/csrc/fa_fwd_f16.o $PKG/csrc/fa_fwd_il.o $PKG/csrc/fa_fwd_w64_bf16.o $PKG/csrc/fa_fwd_w64_f16.o $PKG/csrc/fa_bwd_dkdv.o $PKG/csrc/fa_bwd_dq.o $PKG/csrc/fa_bwd_w64.o gpurun_abl/dk64_$name.o $PKG/csrc/fa_api.o && rm gpurun_abl/dk64_$name.o ) &
   done
   wait
   ls gpurun_abl

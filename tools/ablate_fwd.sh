@@ -7,7 +7,7 @@ C=flash-attention_amd/csrc
 if [ "$1" = build ]; then
   for n in 0 1 2 3 4 5 6 7 8 9; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFA_ABL=$n -c $C/fa_fwd_il.hip -o /tmp/fa_fwd_il_abl$n.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_abl$n.so $C/fa_fwd.o /tmp/fa_fwd_il_abl$n.o $C/fa_bwd.o $C/fa_api.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_abl$n.so $C/fa_fwd_bf16.o $C/fa_fwd_f16.o $C/fa_fwd_w64_bf16.o $C/fa_fwd_w64_f16.o /tmp/fa_fwd_il_abl$n.o $C/fa_bwd_dkdv.o $C/fa_bwd_dq.o $C/fa_bwd_w64.o $C/fa_bwd_dkdv64.o $C/fa_api.o
   done
 else
   for n in 0 1 2 3 4 5 6 7 8 9; do
