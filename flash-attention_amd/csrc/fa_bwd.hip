@@ -42,6 +42,9 @@
 #ifndef FA_DKDV_CARRY
 #define FA_DKDV_CARRY 0  // experiment: 1 = the first transposed operands of the dV / dK segment are read before the vector phase (in flight under
 #endif                   // it); measured identical (1441 | 2138 vs 1447 | 2146 us, profiles/r02_bwd_schedules.txt)
+#ifndef FA_DKDV_PRIO
+#define FA_DKDV_PRIO 0  // experiment: 1 = waves 4-7 of the eight-wave dK/dV kernel run at s_setprio 1 (MI355X_MICROARCH.md, static priority for
+#endif                  // the second-dispatched half)
 #ifndef FA_DKDV_PRESCALE
 #define FA_DKDV_PRESCALE 1  // 0 = the plain dK/dV kernel subtracts LSE and delta on the vector ALU like the feature variants (A/B)
 #endif
@@ -276,6 +279,7 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
     for (int r = 0; r < 16; ++r) { dk_acc[db][r] = 0.f; dv_acc[db][r] = 0.f; }
 
   const float cs = XFORM ? kLog2e : p.scale_log2;
+  if (FA_DKDV_PRIO && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   if (n_items > 0) {
     load_item(0, 0);
