@@ -1,6 +1,6 @@
 """Headline benchmark: attention forward (and forward+backward) TFLOP/s on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-sweep] [--no-cpu] [--no-traffic]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--windows 5] [--preroll-ms 400] [--no-sweep] [--no-cpu] [--no-traffic]
 
 Workload (BASELINE.json): config 3 -- B=4 H=32 S=4096 D=128 bf16 causal, synthetic N(0,1) inputs
 resident in HBM.  One "step" = one forward pass of the hot path (fa_fwd through the C ABI); the
@@ -8,7 +8,11 @@ forward+backward rate on the same config and the reference's seqlen sweep (S = 5
 reported as extra keys, `roofline.kernel` is what fa_last_schedule() says the C ABI launched, `roofline.traffic` comes from
 two rocprofv3 --pmc passes run from here (outside the timed region).  FLOP convention = the reference's (benchmarks/benchmark_flash_attention.py:
 27-30): fwd = 4*B*H*S^2*D (/2 causal), bwd = 2.5x, fwd+bwd = 3.5x.
-N>1: independent replicas, one process per GPU (the path has no exchange step).
+Timing: an untimed clock ramp (>= --preroll-ms of the same launch), W counted warm-up launches, then --windows regions of EXACTLY K
+launches each, every region bracketed by barrier + synchronize; `ms_per_step` / `value` come from the median region (max over ranks),
+min / max are kept under `windows`.
+N>1: independent replicas, one process per GPU (the path has no exchange step): under a launcher (WORLD_SIZE set) this
+process is one rank; without one, `--gpus N` starts the N ranks itself.
 """
 import argparse
 import json
@@ -157,64 +161,150 @@ def sweep(be, dev, sync):
     return {"head_dim": D, "heads": H, "dtype": "bf16", "rows": rows}
 
 
-def main():
+def preroll(fn, sync, min_ms):
+    """Clock ramp: the same launch, back to back, for at least `min_ms` of wall time (outside every timed region).  A count-based
+    warm-up of a 0.6 ms kernel ends ~3 ms after process start, before the chip has left its idle clocks (round 2: headline 9 %
+    under the same kernel's sweep row in the same process)."""
+    t0 = time.perf_counter()
+    sync()
+    while (time.perf_counter() - t0) * 1e3 < min_ms:
+        for _ in range(16):
+            fn()
+        sync()
+    return (time.perf_counter() - t0) * 1e3
+
+
+def timed_windows(fn, steps, windows, sync, world, dev, use_events=True):
+    """`windows` timed regions of EXACTLY `steps` launches each, every one bracketed by barrier + synchronize on both sides (sync());
+    per window: host seconds (max over ranks) and device ms per step (HIP events on the launch stream)."""
+    out = []
+    for _ in range(windows):
+        sync()
+        if use_events:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        if use_events:
+            e0.record()
+        for _ in range(steps):
+            fn()
+        if use_events:
+            e1.record()
+        sync()
+        wall = time.perf_counter() - t0
+        ms_dev = e0.elapsed_time(e1) / steps if use_events else wall / steps * 1e3
+        _, wall_max = replica_aggregate(wall, 0.0, world, dev)
+        out.append((wall_max, ms_dev))
+    return out
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawned_rank(rank, argv, world, port):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    main(argv)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps launches; ms_per_step / value = the median window")
+    ap.add_argument("--preroll-ms", type=float, default=400.0, help="clock ramp before the counted warm-up (same launch, untimed)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the seqlen sweep (extra key `sweep`)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--one-launch", action="store_true", help="(internal) a few forward launches of the workload, for the PMC passes")
-    a = ap.parse_args()
+    ap.add_argument("--stub-workload", action="store_true",
+                    help="(tests only) CPU + gloo run of the launcher / timing / aggregation code with a sleep in place of the kernel; the line says so")
+    return ap.parse_args(argv)
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    from flash_attn_amd import backend as be
 
-    B, H, S, D, causal = 4, 32, 4096, 128, True
-    scale = D ** -0.5
-    if a.one_launch:
-        torch.manual_seed(0)
-        q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
-        k, v = torch.randn_like(q), torch.randn_like(q)
-        for _ in range(3):
-            be.fwd(q, k, v, None, None, 0.0, scale, causal, -1, -1, 0.0, False, None)
-        torch.cuda.synchronize(dev)
+def main(argv=None):
+    a = parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks here, one process per device (replicas only: the ranks share nothing but the barriers and
+        # the max-over-ranks reduction of the window times)
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned_rank, args=(list(sys.argv[1:] if argv is None else argv), a.gpus, _free_port()), nprocs=a.gpus, join=True)
         return
 
-    rank, world = dist_setup("nccl", dev)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    B, H, S, D, causal = 4, 32, 4096, 128, True
+    scale = D ** -0.5
+    if a.stub_workload:
+        dev = torch.device("cpu")
+        rank, world = dist_setup("gloo")
+        be = None
+        fwd = lambda: time.sleep(1e-3)
+        dev_sync = lambda: None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        from flash_attn_amd import backend as be
+        if a.one_launch:
+            torch.manual_seed(0)
+            q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
+            k, v = torch.randn_like(q), torch.randn_like(q)
+            for _ in range(3):
+                be.fwd(q, k, v, None, None, 0.0, scale, causal, -1, -1, 0.0, False, None)
+            torch.cuda.synchronize(dev)
+            return
+        rank, world = dist_setup("nccl", dev)
+        torch.manual_seed(rank)
+        q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
+        k = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
+        v = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
+        fwd = lambda: be.fwd(q, k, v, None, None, 0.0, scale, causal, -1, -1, 0.0, False, None)
+        dev_sync = lambda: torch.cuda.synchronize(dev)
     dist_on = world > 1
     if dist_on:
         import torch.distributed as dist
 
-    torch.manual_seed(rank)
-    q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
-    k = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
-    v = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
-    fwd = lambda: be.fwd(q, k, v, None, None, 0.0, scale, causal, -1, -1, 0.0, False, None)
-
     def sync():
-        torch.cuda.synchronize(dev)
+        dev_sync()
         if dist_on:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            dev_sync()
 
-    local_sync = lambda: torch.cuda.synchronize(dev)
     sync()
-    wall, ms = time_kernel(fwd, a.steps, a.warmup, sync)
-    sched = be.last_schedule()   # which kernel instantiation the C ABI enqueued (fa_last_schedule / fa_last_kernel_name)
+    preroll_ms = preroll(fwd, dev_sync, a.preroll_ms)
+    for _ in range(a.warmup):
+        fwd()
+    wins = timed_windows(fwd, a.steps, max(1, a.windows), sync, world, dev, use_events=not a.stub_workload)
+    wins_sorted = sorted(wins)
+    wall_max, ms = wins_sorted[len(wins_sorted) // 2]      # the median window (host clock, max over ranks) and ITS device time per step
     flops = fwd_flops(B, H, S, D, causal)
-    rate, wall_max = replica_aggregate(wall, flops * a.steps, world, dev)
-    value = rate / 1e12  # whole-job aggregate over replicas, host-clocked
+    value = world * flops * a.steps / wall_max / 1e12      # whole-job aggregate over replicas, host-clocked
+    sched = be.last_schedule() if be else {"name": "stub (sleep 1 ms)", "fwd_nw": 0}
+
+    if a.stub_workload:
+        if rank == 0:
+            print(json.dumps({"metric": "attention_fwd_tflops", "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": a.steps,
+                              "warmup": a.warmup, "ms_per_step": round(wall_max / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "none", "data": "STUB: no kernel ran (launcher / aggregation self-test on CPU)",
+                              "config": {"workload": "stub", "parallelism": f"replicas x{world}"}, "preroll_ms": round(preroll_ms, 1)}), flush=True)
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # forward + backward on the same config (extra keys)
     out, lse, _, _ = fwd()
     do = torch.randn_like(out)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     bwd = lambda: be.bwd(do, q, k, v, out, lse, dq, dk, dv, None, 0.0, scale, causal, -1, -1, 0.0, False, None, None)
-    _, ms_bwd = time_kernel(bwd, max(5, a.steps // 5), 3, sync)
+    nb = max(5, a.steps // 5)
+    for _ in range(3):
+        bwd()
+    bw = sorted(timed_windows(bwd, nb, 3, sync, world, dev))
+    ms_bwd = bw[len(bw) // 2][1]
 
     if rank == 0:
         algo_bytes = 2 * (q.numel() + k.numel() + v.numel() + out.numel()) + 4 * lse.numel()
@@ -224,6 +314,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: B=4 H=32 S=4096 D=128 bf16 causal, forward (flash_attn_func path, fa_fwd via C ABI)",
                        "batch": B, "heads": H, "seqlen": S, "head_dim": D, "causal": causal, "parallelism": f"replicas x{world}"},
+            "preroll_ms": round(preroll_ms, 1),
+            "windows": {"n": len(wins), "steps_each": a.steps, "reported": "median", "ms_per_step_min": round(wins_sorted[0][0] / a.steps * 1e3, 4),
+                        "ms_per_step_max": round(wins_sorted[-1][0] / a.steps * 1e3, 4)},
             "roofline": {"bound": "mfma", "achieved": round(flops / ms / 1e9, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel": sched["name"], "kernel_waves_per_workgroup": sched["fwd_nw"],
@@ -232,18 +325,13 @@ def main():
                         "bwd_ms": round(ms_bwd, 4), "frac_of_peak": round(3.5 * flops / (ms + ms_bwd) / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)},
         }
         # HBM traffic of the dominant kernel, measured now (two rocprofv3 --pmc passes over `bench.py --one-launch`, outside
-        # the timed region); if the profiler is unavailable the committed measurement is reported under its own key.
+        # the timed region); null (with the reason) when the profiler is unavailable.
         if world == 1 and not a.no_traffic:
             nbytes, detail = measure_traffic(sched["name"].split("::")[-1].split("<")[0])
             res["roofline"]["traffic"] = nbytes
             res["roofline"]["traffic_detail"] = detail
-        if res["roofline"]["traffic"] is None:
-            tpath = os.path.join(ROOT, "profiles", "r02_fwd_traffic.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    res["roofline"]["traffic_profiled"] = {"hbm_bytes_per_launch": json.load(f)["hbm_bytes_per_launch"], "source": "profiles/r02_fwd_traffic.json"}
         if world == 1 and not a.no_sweep:
-            res["sweep"] = sweep(be, dev, local_sync)
+            res["sweep"] = sweep(be, dev, dev_sync)
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(D, S, causal)
         print(json.dumps(res), flush=True)

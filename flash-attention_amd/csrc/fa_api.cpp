@@ -148,13 +148,22 @@ int64_t splitkv_bytes(const FaFwdParams* a, int n_splits) {
 // Forward schedule code: 64 = 64-rows-per-wave kernel (fa_fwd_w64.hip, 4 waves, 256-row blocks), 34 / 38 = software-pipelined
 // kernel (fa_fwd_il.hip) with 4 / 8 waves per workgroup, 4 / 8 = lock-step kernel with 4 / 8 waves, 16 = 8-wave ping-pong
 // (fa_fwd.hip).  wl / wr = normalised window.
+// The 64-rows-per-wave forward addresses K and V through buffer descriptors with 32-bit byte offsets from the (batch, kv-head)
+// base (fa_fwd_w64.hip: launch_fwd_w64): the whole key range of a sequence plus two tiles of overshoot must span < 4 GiB.
+bool w64_span_ok(const FaFwdParams* a) {
+  const uint64_t rs = (uint64_t)std::max<int64_t>(a->k_row_stride, a->v_row_stride);
+  return ((uint64_t)(a->seqlen_k > 0 ? a->seqlen_k : 1) + 128) * rs * 2u < (1ull << 32);
+}
 int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
   // Schedule (measured on MI355X, tools/ab_bench.py, profiles/r02_fwd_schedules.txt; FA_FWD_NW overrides):
-  //   head dim 128, long key loops (>= ~48 tiles of 64 keys per query block): the 64-rows-per-wave kernel -- its steady state
-  //   is 15-20 % faster than the pipelined kernels (1.19-1.26 vs 1.02-1.05 PFLOP/s at S = 16k), but with one 256-row
-  //   workgroup per CU nothing hides a block's prologue / epilogue, so shorter loops (config 3: 32 tiles on average) stay on
-  //   the 4-wave pipelined kernel (Q fragments in registers, two workgroups per CU hide each other's prologue / epilogue).
-  //   D = 64 has half the MFMA work per softmax element and prefers 4-wave pipelined workgroups throughout.
+  //   head dim 128, key loops of >= 32 tiles of 64 keys per query block on average (non-causal S >= 2048, causal S >= 4096 --
+  //   config 3 included) and >= 512 query rows: the 64-rows-per-wave kernel (persistent 256-row workgroups, one per CU) -- its
+  //   steady state is 15-20 % faster than the pipelined kernels (1.19-1.26 vs 1.02-1.05 PFLOP/s at S = 16k); shorter loops
+  //   stay on the 4-wave pipelined kernel (Q fragments in registers, two workgroups per CU hide each other's prologue /
+  //   epilogue).  FA_STRICT keeps the pipelined kernels (fp32 scaling of every score).  D = 64 has half the MFMA work per
+  //   softmax element and prefers 4-wave pipelined workgroups throughout.
+  //   K/V views whose key range spans >= 4 GiB (w64_span_ok) fall back from the 64-rows-per-wave kernel to the pipelined one,
+  //   which addresses tile by tile.
   int nw = fa::knobs().fwd_nw;
   if (nw != 4 && nw != 8 && nw != 16 && nw != 34 && nw != 38 && nw != 64) {
     const bool right_bounded = (wr >= 0);
@@ -164,6 +173,7 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
     if (a->d == 128) nw = (tiles >= 32 && a->seqlen_q >= 512) ? (fa::knobs().strict ? (tiles >= 48 ? 38 : 34) : 64) : (a->seqlen_q > 128 ? 34 : 4);
     else nw = (a->seqlen_q > 128) ? 34 : 4;
   }
+  if (nw == 64 && !w64_span_ok(a)) nw = 38;
   return nw;
 }
 // query rows per workgroup of the schedule the forward will run (the lock-step variants serve softcap / ALiBi / dropout /
@@ -308,8 +318,10 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   if (rc == 0 && k.n_splits > 1) rc = fa::launch_splitkv_combine(k, a->dtype == FA_DTYPE_BF16, dk, (hipStream_t)stream);
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
   if (rc == -3)
-    return fail(FA_ERR_UNSUPPORTED, "k/v row stride too large: one 64-key tile (64 * row_stride * 2 bytes) must span less than 2 GiB "
-                                    "(the kernels address a tile with 32-bit lane offsets)");
+    return fail(FA_ERR_UNSUPPORTED, w64 ? "k/v key range too large for the 64-rows-per-wave forward: (seqlen_k + 128) * row_stride * 2 bytes must be < 4 GiB "
+                                          "(FA_FWD_NW=64 was forced; the default schedule falls back to the pipelined kernel)"
+                                        : "k/v row stride too large: one 64-key tile (64 * row_stride * 2 bytes) must span less than 2 GiB "
+                                          "(the kernels address a tile with 32-bit lane offsets)");
   if (rc != 0) return fail(FA_ERR_LAUNCH, "forward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   return FA_OK;
 }
@@ -318,6 +330,9 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
 // kernel wins from ~2k keys at head dim 128 (config 3: dQ 955 vs 997 us, S = 16k non-causal 1383 vs 1584 us) and loses on
 // short sequences, where its 256-row blocks leave CUs idle.
 int bwd_dq_schedule(const FaBwdParams* a) {
+  // trimmed head dims (32 / 96 / 192) and head dim 256 only have the 4-wave, 128-row dQ kernel (fa_bwd.hip: launch_dq_f): the
+  // block size fill_bwd / bwd_list_entries derive from the schedule has to be that kernel's, whatever the knob says
+  if (head_dim_trimmed(a->d) || a->d > 128) return 4;
   const int knob = fa::knobs().bwd_dq_nw;
   if (knob == 4 || knob == 8 || knob == 64) return knob;
   const bool plain = a->softcap <= 0.f && !a->alibi_slopes && a->p_dropout <= 0.f;

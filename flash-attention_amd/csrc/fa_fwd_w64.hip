@@ -34,7 +34,8 @@
 #endif                // 1 no exp2, 2 no row-sum adds, 4 no packing, 8 no row-max tree, 16 LDS operand reads only once per step,
                       // 32 no K/V DMA after the first tiles, 64 row-sum adds lag their exp2 by one gap, 128 no LDS operand reads at all,
                       // 256 LSE output = shader clocks per MFMA of the wave's tile loop, 512 no DMA wait / barrier per tile,
-                      // 1024 no decision (row-max finish + branch)
+                      // 1024 no decision (row-max finish + branch), 2048 LSE output = this wave's clock stamps (lane i = stamp i: 0 prologue
+                      // barrier passed, 1 Q converted, 2 K_0 landed, 3 tile loop starts, 4+u iteration u done, 62 O stored), tools/w64_stamps.py
 
 namespace fa {
 
@@ -136,22 +137,30 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     return k.m_block * BM < k.sq;
   };
   // this wave's 64 rows of a block's Q -> its rows of the LDS Q region (coalesced DMA, K-style swizzle on the source chunk)
+  constexpr int QDMA = (BM * ROW_BYTES) / 1024 / NW;   // 1-KiB pieces of a block's Q per wave
+  auto q_base = [&](const Blk& k) __attribute__((always_inline)) { return (const E*)p.q + k.q_boff + k.q_row0 * p.q_rs + (int64_t)k.h * p.q_hs; };
+  auto dma_q_piece = [&](const E* qsrc, int row0, int sq_, int i) __attribute__((always_inline)) {   // piece i of this wave's rows; row0 = first row of the block
+    const int row = (wave * QDMA + i) * RPD + d_row;
+    const int grow = min(row0 + row, sq_ - 1);
+    const int c = d_pc ^ k_swz_w<D>(row);
+    lds_dma_16B(qsrc + (int64_t)grow * p.q_rs + c * 8, lds + Q_OFF + (wave * QDMA + i) * 1024);
+  };
   auto dma_q = [&](const Blk& k) __attribute__((always_inline)) {
-    const E* qsrc = (const E*)p.q + k.q_boff + k.q_row0 * p.q_rs + (int64_t)k.h * p.q_hs;
-    constexpr int QDMA = (BM * ROW_BYTES) / 1024 / NW;
+    const E* qsrc = q_base(k);
 #pragma unroll
-    for (int i = 0; i < QDMA; ++i) {
-      const int row = (wave * QDMA + i) * RPD + d_row;
-      const int grow = min(k.m_block * BM + row, k.sq - 1);
-      const int c = d_pc ^ k_swz_w<D>(row);
-      lds_dma_16B(qsrc + (int64_t)grow * p.q_rs + c * 8, lds + Q_OFF + (wave * QDMA + i) * 1024);
-    }
+    for (int i = 0; i < QDMA; ++i) dma_q_piece(qsrc, k.m_block * BM, k.sq, i);
   };
   int q_in_lds = -1;   // virtual block whose Q this wave has prefetched into the LDS Q region
 
   for (int vb = blockIdx.x, round = 0; vb < n_virtual; vb += gridDim.x, ++round) {
-#if FA_W64_ABL & 256
+#if FA_W64_ABL & (256 | 2048)
   const long long abl_tk = clock64();
+#endif
+#if FA_W64_ABL & 2048
+  int abl_st = 0, abl_n = 4;
+#define FA_W64_STAMP(idx_) do { const int sv_ = (int)(clock64() - abl_tk); abl_st = (lane == (idx_)) ? sv_ : abl_st; } while (0)
+#else
+#define FA_W64_STAMP(idx_) ((void)0)
 #endif
   Blk blk;
   if (!decode(vb, round, blk)) continue;   // (uniform over the workgroup: no barrier is skipped by part of it)
@@ -270,12 +279,21 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // ---- prologue.  The previous block's epilogue staged its O tile over the K/V buffers: nobody may refill them before every
   // wave is through with it.  Q: already prefetched by this wave during the previous block (its own rows, so its own
   // vmcnt wait at the tile barriers made them visible), else loaded now.  K_0 rides under the Q conversion.
+  // The first three tiles (K_0, V_0, K_1: everything iteration 0 and 1 read) are requested here, in front of the Q conversion,
+  // so that no iteration of the tile loop waits for a tile it has only just asked for.
   __syncthreads();
+  FA_W64_STAMP(0);
   if (q_in_lds != vb) dma_q(blk);
-  if (n_tiles > 0) dma_tile(ICw<0>{}, 0, 0);
-  if (q_in_lds != vb) {
-    if (n_tiles > 0) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+  if (n_tiles > 0) { dma_tile(ICw<0>{}, 0, 0); dma_tile(ICw<1>{}, 0, 0); }
+  if (n_tiles > 1) dma_tile(ICw<0>{}, 1, 1);
+  auto wait_pieces = [&](int tiles_left) __attribute__((always_inline)) {   // all but the last `tiles_left` tile requests have landed
+    if (tiles_left >= 2) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else if (tiles_left == 1) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else lds_dma_wait_all();
+  };
+  if (q_in_lds != vb) {   // Q was not prefetched (first block of this workgroup): its pieces were requested first
+    if (n_tiles > 1) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else wait_pieces(n_tiles > 0 ? 2 : 0);
   }
   // this wave's B-operand fragments of Q, pre-multiplied by softmax_scale*log2(e) and rounded once to the input dtype, into
   // accumulator registers for the whole block
@@ -297,18 +315,33 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     load_q_all(ICw<0>{});
     load_q_all(ICw<1>{});
   }
-  lds_dma_wait_all();   // K_0 (issued before the conversion)
+  FA_W64_STAMP(1);
+  wait_pieces(n_tiles > 1 ? 2 : n_tiles > 0 ? 1 : 0);   // K_0 (requested before the conversion); V_0 and K_1 may still be on their way
   __syncthreads();
-  {  // next block's Q rows of this wave -> LDS, under this block's tile loop (its first tile barrier waits for them)
+  FA_W64_STAMP(2);
+  // Next block's Q rows of this wave -> LDS under this block's tile loop, a few 1-KiB pieces per iteration (each iteration's
+  // tile barrier waits for the pieces requested in it).  All of them at once, as in round 2, put 64 KB per CU -- 16 MB across
+  // the chip, every workgroup at the same moment -- in front of the first tiles of the loop: 16k clocks to get the requests
+  // out and another 10k of iteration 0 waiting behind them (profiles/r03_fwd_w64_stamps.txt).
+  const E* qn_src = nullptr;
+  int qn_row0 = 0, qn_sq = 1, qn_done = QDMA, qn_per_iter = QDMA;
+  {
     Blk nxt;
     q_in_lds = -1;
     if (p.persist_total > 0 && decode(vb + (int)gridDim.x, round + 1, nxt)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the Q region have returned
-      dma_q(nxt);
-      if (n_tiles == 0) lds_dma_wait_all();                // no tile barrier will wait for it
+      qn_src = q_base(nxt); qn_row0 = nxt.m_block * BM; qn_sq = nxt.sq; qn_done = 0;
+      qn_per_iter = n_tiles >= QDMA ? 1 : n_tiles >= QDMA / 2 ? 2 : n_tiles >= QDMA / 4 ? 4 : QDMA;
+      if (n_tiles == 0) { dma_q(nxt); lds_dma_wait_all(); qn_done = QDMA; }   // no tile barrier will wait for it
       q_in_lds = vb + (int)gridDim.x;
     }
   }
+  auto q_trickle = [&]() __attribute__((always_inline)) {   // called once per iteration, outside the steps (M0 is theirs inside)
+    if (qn_done < QDMA) {
+      for (int j = 0; j < qn_per_iter; ++j) dma_q_piece(qn_src, qn_row0, qn_sq, qn_done + j);
+      qn_done += qn_per_iter;
+    }
+  };
 
   // per-lane LDS read bases: K fragment of k-step ks at ka[ks] (+ buffer / half offsets as immediates), V d-block db at va[db]
   const int kbase = qi * ROW_BYTES + ((hi ^ k_swz_w<D>(qi)) << 4);
@@ -325,12 +358,15 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   float m_run[QB], l_run[QB][2], o_lag[QB];
   float thr_l[QB];          // per-lane decision threshold: -inf until the row has seen a key (any finite score moves m), then rescale_thr
   bool lag_pending = false; // wave-uniform: some o_lag != 1 is waiting to be applied to O
-  f32x16 negm[QB];     // -m broadcast (0 while m = -inf): the C operand of every score chain's first MFMA
+  f32x16 negm[QB];     // the C operand of every score chain's first MFMA: -m broadcast (0 while m = -inf), and -inf in the elements the
+                       // mask hides in a step that straddles a mask boundary (prep_c) -- the matrix pipe applies the mask
+  float nbase[QB];     // the value the visible elements of negm hold
+  bool negm_masked = false;   // wave-uniform: negm currently carries a step's mask
   f32x16 sA[QB], sB[QB];
   u32x4 pfA[QB][2], pfB[QB][2];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    m_run[qb] = -INFINITY; l_run[qb][0] = 0.f; l_run[qb][1] = 0.f; o_lag[qb] = 1.f; thr_l[qb] = -INFINITY;
+    m_run[qb] = -INFINITY; l_run[qb][0] = 0.f; l_run[qb][1] = 0.f; o_lag[qb] = 1.f; thr_l[qb] = -INFINITY; nbase[qb] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { negm[qb][r] = 0.f; sA[qb][r] = 0.f; sB[qb][r] = 0.f; }
 #pragma unroll
@@ -338,14 +374,54 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   }
   bool have_cur = false, have_prev = false;
 
-  auto apply_mask = [&](f32x16& s, int qb, int i) __attribute__((always_inline)) {
-    const int k0 = key_base + 32 * i;
-    const int rel_hi = lim_hi[qb] - k0 - 4 * hi;
-    const int rel_lo = lim_lo[qb] - k0 - 4 * hi;
+  // C operand of the score chain of step i (called right before its first MFMA): a step that straddles a mask boundary gets
+  // -inf in its hidden elements, so the scores leave the matrix pipe masked (s + (-inf) = -inf: exp2 gives 0, the row maximum
+  // ignores it) and the masked step is otherwise the plain step; the first plain step after it puts the broadcast back.
+  // Element by element through tied asm operands, as in rescale(): the tuple must stay in its registers.
+  const bool two_sided = p.wl >= 0;
+  auto prep_c = [&](int i) __attribute__((always_inline)) {
+    if (step_needs_mask(i)) {
+      const int k0 = key_base + 32 * i;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int off = acc_row(r, 0);
-      s[r] = ((off <= rel_hi) && (off >= rel_lo)) ? s[r] : -INFINITY;
+      for (int qb = 0; qb < QB; ++qb) {
+        const int rel_hi = lim_hi[qb] - k0 - 4 * hi;
+        const int rel_lo = lim_lo[qb] - k0 - 4 * hi;
+        const float nb = nbase[qb];
+        float ninf = -INFINITY;
+        asm volatile("" : "+v"(ninf));   // a register: the lane-mask form of v_cndmask takes no literal
+        if (two_sided) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int off = acc_row(r, 0);
+            const unsigned long long vis = __builtin_amdgcn_ballot_w64((off <= rel_hi) && (off >= rel_lo));
+            float nv = negm[qb][r];
+            asm volatile("v_cndmask_b32 %0, %3, %1, %2" : "+v"(nv) : "v"(nb), "s"(vis), "v"(ninf));
+            negm[qb][r] = nv;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int off = acc_row(r, 0);
+            const unsigned long long vis = __builtin_amdgcn_ballot_w64(off <= rel_hi);
+            float nv = negm[qb][r];
+            asm volatile("v_cndmask_b32 %0, %3, %1, %2" : "+v"(nv) : "v"(nb), "s"(vis), "v"(ninf));
+            negm[qb][r] = nv;
+          }
+        }
+      }
+      negm_masked = true;
+    } else if (negm_masked) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const float nb = nbase[qb];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float nv = negm[qb][r];
+          asm volatile("v_mov_b32 %0, %1" : "+v"(nv) : "v"(nb));
+          negm[qb][r] = nv;
+        }
+      }
+      negm_masked = false;
     }
   };
   // Decision on the NEXT step's scores, held as s' = s - m_base (m_base = m, or 0 while m = -inf): the row moves its maximum
@@ -355,10 +431,10 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // (after P_i.V, computed at the old scale, has been accumulated) -- the lagged rescale of fa_fwd_il.hip.
   auto rescale = [&](auto qbc, bool grow, float tmax, f32x16& s_nxt) __attribute__((always_inline)) {
     constexpr int qb = decltype(qbc)::value;
-    const float m_upd = grow ? (tmax - negm[qb][0]) : m_run[qb];   // grow => tmax finite
+    const float m_upd = grow ? (tmax - nbase[qb]) : m_run[qb];   // grow => tmax finite
     const float m_safe = (m_upd == -INFINITY) ? 0.f : m_upd;
     const float alpha = grow ? fast_exp2(m_run[qb] - m_safe) : 1.f;
-    const float delta = m_safe + negm[qb][0];   // new base - old base (0 where the row did not move)
+    const float delta = m_safe + nbase[qb];   // new base - old base (0 where the row did not move)
     m_run[qb] = m_upd;
     thr_l[qb] = grow ? thr : thr_l[qb];
     l_run[qb][0] *= alpha;
@@ -366,8 +442,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     // in place, element by element through tied asm operands: a recomputed tuple would live in NEW registers and cost the
     // common path a 16-register copy at the join
     const float neg = -m_safe;
+    nbase[qb] = neg;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) {   // (writes the plain broadcast: a mask negm carried is dropped, see negm_masked below)
       float sv = s_nxt[r], nv = negm[qb][r];
       asm volatile("v_sub_f32 %0, %0, %2\n\tv_mov_b32 %1, %3" : "+v"(sv), "+v"(nv) : "v"(delta), "v"(neg));
       s_nxt[r] = sv;
@@ -389,6 +466,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       mfma_drain_acc();  // O is about to be read by the VALU
       rescale(ICw<0>{}, g0, tmax[0], s_nxt[0]);
       rescale(ICw<1>{}, g1, tmax[1], s_nxt[1]);
+      negm_masked = false;
       lag_pending = any_grow;
     }
   };
@@ -410,6 +488,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     const int koff = par * TILE_BYTES + half * 32 * ROW_BYTES;
     const int voff = (2 + (par ^ 1)) * TILE_BYTES + half * 32 * ROW_BYTES;
     if (do_qk) {
+      prep_c(i + 1);
       u32x4 kf_nxt = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[0] + koff);
       static_for<KS>([&](auto ksc) __attribute__((always_inline)) {
         constexpr int ks = decltype(ksc)::value;
@@ -458,10 +537,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       if (do_qk) {
         mfma_drain_v(s_nxt[0], s_nxt[1]);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-          if (step_needs_mask(i + 1)) apply_mask(s_nxt[qb], qb, i + 1);
-          tmax[qb] = row_max(s_nxt[qb]);
-        }
+        for (int qb = 0; qb < QB; ++qb) tmax[qb] = row_max(s_nxt[qb]);
       }
       decide_and_rescale(tmax, s_nxt);   // without fresh scores tmax = -inf never grows; a pending O factor is still applied
     }
@@ -489,11 +565,10 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   //   been issued, i.e. with nothing to hide behind).  The step's K or V tile DMA pieces sit in the odd gaps 1, 3, ...
   //   (DPW pieces: M0 is written with the first one and must survive until the last -- hipcc emits no M0 use in this kernel,
   //   checked in the ISA by tools/isa_blocks.py --m0).
-  auto fast_step = [&](auto parc, auto halfc, auto maskc, int i_nxt, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
+  auto fast_step = [&](auto parc, auto halfc, int i_nxt, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
                        const u32x4 (&pf_prev)[QB][2], u32x4 (&pf_cur)[QB][2], const u32x4& dma_srd, const unsigned (&dma_off)[DPW],
                        unsigned dma_toff, unsigned dma_dst) __attribute__((always_inline)) {
     constexpr int par = decltype(parc)::value, half = decltype(halfc)::value;
-    constexpr bool MASK = decltype(maskc)::value != 0;
     constexpr int QKG = 2 * KS, PVG = 4 * DB, NG = QKG + PVG;
     constexpr int KOFF = par * TILE_BYTES + half * 32 * ROW_BYTES;
     constexpr int VOFF = (2 + (par ^ 1)) * TILE_BYTES + half * 32 * ROW_BYTES;
@@ -525,16 +600,10 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     auto el_end = [](int x) constexpr { return x <= QKG ? (24 * x) / QKG : (24 + ((x - QKG) * 16) / PVG > 32 ? 32 : 24 + ((x - QKG) * 16) / PVG); };
     float pe[QB][16];   // P_i as scalars (writing them back into the score tuples makes hipcc copy whole 16-register tuples)
     float tmax[QB] = {-INFINITY, -INFINITY};
-    int rel_hi[QB] = {0, 0}, rel_lo[QB] = {0, 0};
-    if constexpr (MASK) {
-      const int k0 = key_base + 32 * i_nxt;
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) { rel_hi[qb] = lim_hi[qb] - k0 - 4 * hi; rel_lo[qb] = lim_lo[qb] - k0 - 4 * hi; }
-    }
+    prep_c(i_nxt);   // (a step that straddles a mask boundary: the mask goes into the chain's C operand; nothing else differs)
     // gap (inside the PV half) schedule of the row-max work of query block mq
     constexpr int UPG = PVG >= 16 ? 1 : 2;        // max3 units per gap
-    constexpr int MGAPS = PVG >= 16 ? 4 : 2;      // gaps the mask predicate takes (MASK only)
-    auto tree_g0 = [](int mq) constexpr { return 1 + mq + (MASK ? MGAPS : 0); };   // the chain of block mq retired at gap QKG - 2 + mq
+    auto tree_g0 = [](int mq) constexpr { return 1 + mq; };   // the chain of block mq retired at gap QKG - 2 + mq
     auto hm_gap = [&](int mq) constexpr { return tree_g0(mq) + 8 / UPG; };           // cross-half combine right after the tree
 #pragma unroll
     for (int f = 0; f < AH; ++f) rd_frag(f);
@@ -586,20 +655,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
           asm volatile("" : "+v"(pw));   // pinned to this gap (hipcc otherwise sinks the conversions into the next step's head)
           pf_cur[cq][t][m] = pw;
         }
-        // mask predicate on the fresh scores (only steps straddling a boundary), the row-max tree, the cross-half combine
+        // the row-max tree of the fresh scores, the cross-half combine
 #pragma unroll
         for (int mq = 0; mq < QB; ++mq) {
-          if constexpr (MASK) {
-            const int mg0 = 1 + mq;
-            constexpr int MPG = 16 / MGAPS;
-            if (y >= mg0 && y < mg0 + MGAPS) {
-#pragma unroll
-              for (int r = (y - mg0) * MPG; r < (y - mg0 + 1) * MPG; ++r) {
-                const int off = acc_row(r, 0);
-                s_nxt[mq][r] = ((off <= rel_hi[mq]) && (off >= rel_lo[mq])) ? s_nxt[mq][r] : -INFINITY;
-              }
-            }
-          }
           const int g0 = tree_g0(mq);
           if (y >= g0 && y < g0 + 8 / UPG && !(FA_W64_ABL & 8)) {
 #pragma unroll
@@ -615,7 +673,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     if (!(FA_W64_ABL & 1024)) {
 #pragma unroll
       for (int mq = 0; mq < QB; ++mq)
-        if (hm_gap(mq) >= PVG && !(FA_W64_ABL & 8)) tmax[mq] = vhalf_max(tmax[mq]);   // (head dim 64 masked steps: no gap left)
+        if (hm_gap(mq) >= PVG && !(FA_W64_ABL & 8)) tmax[mq] = vhalf_max(tmax[mq]);   // (no gap left for it)
       decide_and_rescale(tmax, s_nxt);
     }
   };
@@ -641,6 +699,8 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #endif
   auto iter_head = [&](int u) __attribute__((always_inline)) {
     if ((FA_W64_ABL & 32) && u > 1) return;
+    q_trickle();
+    if (u == 0) return;   // K_1 and V_0 were requested in the prologue
     const int par = u & 1;
     if (u + 1 < n_tiles) dma_tile(ICw<0>{}, par ^ 1, u + 1);
     if (u < n_tiles) dma_tile(ICw<1>{}, par, u);
@@ -649,6 +709,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     if (FA_W64_ABL & 512) return;
     lds_dma_wait_all();
     __syncthreads();
+#if FA_W64_ABL & 2048
+    if (abl_n < 62) { FA_W64_STAMP(abl_n); ++abl_n; }
+#endif
   };
   auto generic_iter = [&](int u) __attribute__((always_inline)) {
     iter_head(u);
@@ -659,41 +722,31 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #if FA_W64_ABL & 256
   const long long abl_t0 = clock64();
 #endif
+  FA_W64_STAMP(3);
   if (n_tiles > 0) {
     int u = 0;
     const int head_end = min(max(uf_lo, 0), n_tiles + 1);
     for (; u < head_end; ++u) generic_iter(u);
     const unsigned wave_dst = (unsigned)(wave * DPW * 1024);
-    auto fast_iter = [&](auto parc, auto maskc, int uu) __attribute__((always_inline)) {
+    auto fast_iter = [&](auto parc, int uu) __attribute__((always_inline)) {
       constexpr int par = decltype(parc)::value;
       // K_{u+1} rides in the first step, V_u in the second (full tiles only, see uf_hi; a K tile past the last one lands in
       // the buffer nobody reads again: rows past the end of the buffer descriptor are out of range, never a fault)
+      q_trickle();
       const unsigned toff_k = (unsigned)(n_min + uu + 1) * (unsigned)(BN * 2) * (unsigned)p.k_rs;
       const unsigned toff_v = (unsigned)(n_min + uu) * (unsigned)(BN * 2) * (unsigned)p.v_rs;
-      fast_step(parc, ICw<0>{}, maskc, 2 * uu, sA, sB, pfA, pfB, k_srd, koff_l, toff_k, __builtin_amdgcn_readfirstlane((unsigned)((par ^ 1) * TILE_BYTES) + wave_dst));
-      fast_step(parc, ICw<1>{}, maskc, 2 * uu + 1, sB, sA, pfB, pfA, v_srd, voff_l, toff_v, __builtin_amdgcn_readfirstlane((unsigned)((2 + par) * TILE_BYTES) + wave_dst));
+      fast_step(parc, ICw<0>{}, 2 * uu, sA, sB, pfA, pfB, k_srd, koff_l, toff_k, __builtin_amdgcn_readfirstlane((unsigned)((par ^ 1) * TILE_BYTES) + wave_dst));
+      fast_step(parc, ICw<1>{}, 2 * uu + 1, sB, sA, pfB, pfA, v_srd, voff_l, toff_v, __builtin_amdgcn_readfirstlane((unsigned)((2 + par) * TILE_BYTES) + wave_dst));
       have_prev = step_active(2 * uu);      // P_{2u} is packed and S_{2u+1} is pending -- what the generic steps that follow
       have_cur = step_active(2 * uu + 1);   // expect; past the wave's last scored step they are 0 / -inf and simply dropped
       iter_tail();
     };
-    int um_lo = uf_lo, um_hi = uf_hi;
-    {
-      const int f_lo = (w_full_lo - key_base + 31) >> 5;   // first step with no left-masked key
-      const int f_hi = (w_full_hi - 31 - key_base) >> 5;   // last step with no right-masked key
-      um_lo = max(uf_lo, (f_lo + 1) >> 1);
-      um_hi = min(uf_hi, (f_hi - 1) >> 1);
+    if (u <= uf_hi && (u & 1)) { fast_iter(ICw<1>{}, u); ++u; }
+    for (; u + 1 <= uf_hi; u += 2) {
+      fast_iter(ICw<0>{}, u);
+      fast_iter(ICw<1>{}, u + 1);
     }
-    auto fast_range = [&](auto maskc, int hi_incl) __attribute__((always_inline)) {
-      if (u <= hi_incl && (u & 1)) { fast_iter(ICw<1>{}, maskc, u); ++u; }
-      for (; u + 1 <= hi_incl; u += 2) {
-        fast_iter(ICw<0>{}, maskc, u);
-        fast_iter(ICw<1>{}, maskc, u + 1);
-      }
-      if (u <= hi_incl) { fast_iter(ICw<0>{}, maskc, u); ++u; }
-    };
-    fast_range(ICw<1>{}, min(uf_hi, um_lo - 1));
-    fast_range(ICw<0>{}, um_hi);
-    fast_range(ICw<1>{}, uf_hi);
+    if (u <= uf_hi) { fast_iter(ICw<0>{}, u); ++u; }
     for (; u <= n_tiles; ++u) generic_iter(u);
   }
 
@@ -725,6 +778,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       if (my_row < sq && hi == 0) {
         const int sel = my_row & 3;
         lsep[my_row] = sel == 0 ? abl_ticks : sel == 1 ? (float)(abl_t0 - abl_tk) : sel == 2 ? (float)(abl_t1 - abl_t0) : (float)(clock64() - abl_t1);
+      }
+#elif FA_W64_ABL & 2048
+      if (qb == QB - 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FA_W64_STAMP(62);
+        if (w_row0 + lane < sq) lsep[w_row0 + lane] = (float)abl_st;
       }
 #else
       if (my_row < sq && hi == 0) lsep[my_row] = dead ? INFINITY : (m_run[qb] * kLn2 + __logf(l_tot));

@@ -164,14 +164,19 @@ def _fwd_backward(ctx, dout, dlse, dp, drng):
 def _varlen_fwd_setup(ctx, inputs, output):
     (q, k, v, cu_q, cu_k, max_q, max_k, dropout_p, softmax_scale, causal, wl, wr, softcap, alibi_slopes, _, block_table,
      leftpad_k, seqused_k, zero_tensors) = inputs
-    if block_table is not None or leftpad_k is not None or seqused_k is not None:
-        raise RuntimeError("flash_attn_amd::_flash_attn_varlen_forward: no backward with block_table / leftpad_k / seqused_k")
     out, lse, _, rng_state = output
+    # paged / left-padded / partially used K has no backward: say so when (and only if) a gradient is actually asked for -- the
+    # forward itself (e.g. paged-KV inference without torch.no_grad()) must keep working
+    ctx.no_backward = block_table is not None or leftpad_k is not None or seqused_k is not None
+    if ctx.no_backward:
+        return
     ctx.save_for_backward(q, k, v, out, lse, rng_state, cu_q, cu_k, *([alibi_slopes] if alibi_slopes is not None else []))
     ctx.args = (max_q, max_k, dropout_p, softmax_scale, causal, wl, wr, softcap, alibi_slopes is not None)
 
 
 def _varlen_fwd_backward(ctx, dout, dlse, dp, drng):
+    if ctx.no_backward:
+        raise RuntimeError("flash_attn_amd::_flash_attn_varlen_forward: no backward with block_table / leftpad_k / seqused_k")
     q, k, v, out, lse, rng_state, cu_q, cu_k, *rest = ctx.saved_tensors
     max_q, max_k, dropout_p, softmax_scale, causal, wl, wr, softcap, has_alibi = ctx.args
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -256,18 +261,69 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wi
                          deterministic, return_attn_probs, torch.is_grad_enabled())
 
 
+class _PackedAttnFn(torch.autograd.Function):
+    """The four packed layouts -- qkv (B,S,3,H,D) / (total,3,H,D) and q + kv (B,Sk,2,Hk,D) / (total_k,2,Hk,D) -- behind one
+    Function (reference FlashAttnQKVPackedFunc :461-540, FlashAttnVarlenQKVPackedFunc :543-634, FlashAttnKVPackedFunc :637-722,
+    FlashAttnVarlenKVPackedFunc :724-825).  The packed axis is dim -3 in every layout, so `unbind(-3)` yields the strided q / k / v
+    views the kernels read in place, and the backward hands the kernels the same views of ONE freshly allocated packed gradient
+    (dq_ / dk_ / dv_ of the backend's bwd): no slice-backward temporaries, no zero fill, no adds."""
+
+    @staticmethod
+    def forward(ctx, q, packed, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal,
+                window_size, softcap, alibi_slopes, deterministic, return_softmax, is_grad_enabled):
+        needs_grad = is_grad_enabled and (packed.requires_grad or (q is not None and q.requires_grad))
+        parts = packed.unbind(dim=-3)
+        q_, k_, v_ = parts if q is None else (q, parts[0], parts[1])
+        if softmax_scale is None:
+            softmax_scale = q_.shape[-1] ** (-0.5)
+        d_orig = q_.shape[-1]
+        q_, k_, v_ = _pad_head_dim(q_, k_, v_)
+        if cu_seqlens_q is None:
+            out_p, lse, s_dmask, rng_state = _flash_attn_forward(
+                q_, k_, v_, dropout_p, softmax_scale, causal, window_size[0], window_size[1], softcap, alibi_slopes,
+                return_softmax and dropout_p > 0)
+        else:
+            out_p, lse, s_dmask, rng_state = _flash_attn_varlen_forward(
+                q_, k_, v_, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal,
+                window_size[0], window_size[1], softcap, alibi_slopes, return_softmax and dropout_p > 0, None)
+        if needs_grad:
+            ctx.save_for_backward(q_, k_, v_, out_p, lse, rng_state, *([] if cu_seqlens_q is None else [cu_seqlens_q, cu_seqlens_k]))
+            ctx.cfg = (q is None, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                       deterministic, d_orig)
+        out = out_p[..., :d_orig]
+        return out if not return_softmax else (out, lse, s_dmask)
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        q, k, v, out, lse, rng_state, *cu = ctx.saved_tensors
+        qkv_packed, mq, mk, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic, d_orig = ctx.cfg
+        # one packed gradient (head dim as the kernels saw it, i.e. padded to a multiple of 8), its slices are the kernels' outputs
+        n = 3 if qkv_packed else 2
+        dpacked = torch.empty(k.shape[:-2] + (n,) + k.shape[-2:], dtype=k.dtype, device=k.device)
+        dparts = dpacked.unbind(dim=-3)
+        dq, dk, dv = dparts if qkv_packed else (torch.empty_like(q), dparts[0], dparts[1])
+        (dout_p,) = _pad_head_dim(dout) if dout.shape[-1] % 8 else (dout,)
+        if not cu:
+            _flash_attn_backward(dout_p, q, k, v, out, lse, dq, dk, dv, dropout_p, softmax_scale, causal, window_size[0],
+                                 window_size[1], softcap, alibi_slopes, deterministic, rng_state)
+        else:
+            _flash_attn_varlen_backward(dout_p, q, k, v, out, lse, dq, dk, dv, cu[0], cu[1], mq, mk, dropout_p, softmax_scale,
+                                        causal, window_size[0], window_size[1], softcap, alibi_slopes, deterministic, rng_state)
+        return (None if qkv_packed else dq[..., :d_orig], dpacked[..., :d_orig]) + (None,) * 13
+
+
 def flash_attn_kvpacked_func(q, kv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                              alibi_slopes=None, deterministic=False, return_attn_probs=False):
-    """kv (B,Sk,2,Hk,D): strided views are passed straight to the kernels (no copy)."""
-    return flash_attn_func(q, kv[:, :, 0], kv[:, :, 1], dropout_p, softmax_scale, causal, window_size, softcap,
-                           alibi_slopes, deterministic, return_attn_probs)
+    """q (B,Sq,H,D), kv (B,Sk,2,Hk,D): the k / v slices are read in place; the backward writes one packed dkv."""
+    return _PackedAttnFn.apply(q, kv, None, None, 0, 0, dropout_p, softmax_scale, causal, tuple(window_size), softcap,
+                               alibi_slopes, deterministic, return_attn_probs, torch.is_grad_enabled())
 
 
 def flash_attn_qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                               alibi_slopes=None, deterministic=False, return_attn_probs=False):
-    """qkv (B,S,3,H,D)."""
-    return flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p, softmax_scale, causal, window_size,
-                           softcap, alibi_slopes, deterministic, return_attn_probs)
+    """qkv (B,S,3,H,D): read in place; the backward writes one packed dqkv (no concatenation of separate gradients)."""
+    return _PackedAttnFn.apply(None, qkv, None, None, 0, 0, dropout_p, softmax_scale, causal, tuple(window_size), softcap,
+                               alibi_slopes, deterministic, return_attn_probs, torch.is_grad_enabled())
 
 
 def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
@@ -283,19 +339,17 @@ def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, ma
 def flash_attn_varlen_kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
                                     softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,
                                     alibi_slopes=None, deterministic=False, return_attn_probs=False):
-    """kv (total_k,2,Hk,D)."""
-    return flash_attn_varlen_func(q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
-                                  dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
-                                  return_attn_probs)
+    """q (total_q,H,D), kv (total_k,2,Hk,D)."""
+    return _PackedAttnFn.apply(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale, causal,
+                               tuple(window_size), softcap, alibi_slopes, deterministic, return_attn_probs, torch.is_grad_enabled())
 
 
 def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
                                      window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
                                      return_attn_probs=False):
     """qkv (total,3,H,D)."""
-    return flash_attn_varlen_func(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, cu_seqlens, max_seqlen, max_seqlen,
-                                  dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
-                                  return_attn_probs)
+    return _PackedAttnFn.apply(None, qkv, cu_seqlens, cu_seqlens, max_seqlen, max_seqlen, dropout_p, softmax_scale, causal,
+                               tuple(window_size), softcap, alibi_slopes, deterministic, return_attn_probs, torch.is_grad_enabled())
 
 
 def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None, rotary_sin=None, cache_seqlens=None,

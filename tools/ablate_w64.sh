@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 PKG=flash-attention_amd
-MASKS="${MASKS:-0 1 2 4 8 16 32 64 3 15 31 63}"
+MASKS="${MASKS:-0 1 2 4 8 16 32 64 3 15 31 63}"   # 256: clocks per MFMA (tools/w64_time.py), 2048: per-iteration stamps (tools/w64_stamps.py)
 if [ "$1" != "run" ]; then
   mkdir -p gpurun_abl
   for m in $MASKS; do
