@@ -37,6 +37,17 @@
                       // 1024 no decision (row-max finish + branch), 2048 LSE output = this wave's clock stamps (lane i = stamp i: 0 prologue
                       // barrier passed, 1 Q converted, 2 K_0 landed, 3 tile loop starts, 4+u iteration u done, 62 O stored), tools/w64_stamps.py
 
+// Gaps of a step that carry its LDS-DMA pieces (first gap, stride): where a piece is issued prices it between ~30 and ~180 clocks
+// (MI355X_MICROARCH.md "LDS-DMA piece issue cost"; profiles/r03_fwd_w64_dma_placement.txt)
+#ifndef FA_W64_KDMA_G0
+#define FA_W64_KDMA_G0 1
+#define FA_W64_KDMA_GS 2
+#endif
+#ifndef FA_W64_VDMA_G0
+#define FA_W64_VDMA_G0 1
+#define FA_W64_VDMA_GS 2
+#endif
+
 namespace fa {
 
 template <int D> FA_DEVINL constexpr int k_swz_w(int row) { return D == 128 ? (row & 15) : ((row >> 1) & 7); }
@@ -137,18 +148,33 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     return k.m_block * BM < k.sq;
   };
   // this wave's 64 rows of a block's Q -> its rows of the LDS Q region (coalesced DMA, K-style swizzle on the source chunk)
-  constexpr int QDMA = (BM * ROW_BYTES) / 1024 / NW;   // 1-KiB pieces of a block's Q per wave
-  auto q_base = [&](const Blk& k) __attribute__((always_inline)) { return (const E*)p.q + k.q_boff + k.q_row0 * p.q_rs + (int64_t)k.h * p.q_hs; };
-  auto dma_q_piece = [&](const E* qsrc, int row0, int sq_, int i) __attribute__((always_inline)) {   // piece i of this wave's rows; row0 = first row of the block
-    const int row = (wave * QDMA + i) * RPD + d_row;
-    const int grow = min(row0 + row, sq_ - 1);
-    const int c = d_pc ^ k_swz_w<D>(row);
-    lds_dma_16B(qsrc + (int64_t)grow * p.q_rs + c * 8, lds + Q_OFF + (wave * QDMA + i) * 1024);
+  // Q block -> LDS Q region (K-style swizzle on the source chunk), 1-KiB pieces through a buffer descriptor of the block's rows: rows
+  // past the sequence end are outside it and arrive as zeros.  Pieces are addressed by a RUN-TIME index with 32-bit offsets: with
+  // compile-time indices hipcc hoists sixteen 64-bit per-lane addresses out of the persistent loop and spills them.
+  constexpr int QDMA = (BM * ROW_BYTES) / 1024 / NW;   // pieces per wave
+  auto q_srd_of = [&](const Blk& k) __attribute__((always_inline)) {
+    const E* base = (const E*)p.q + k.q_boff + (k.q_row0 + (int64_t)k.m_block * BM) * p.q_rs + (int64_t)k.h * p.q_hs;
+    const int rows = min(BM, k.sq - k.m_block * BM);
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned nrec = rows > 0 ? (unsigned)(((unsigned long long)(rows - 1) * (unsigned long long)p.q_rs + D) * 2ull) : 0u;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi16 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;
+    const unsigned nr = __builtin_amdgcn_readfirstlane(nrec);
+    u32x4 srd = {lo, hi16, nr, 0x00020000u};
+    return srd;
   };
-  auto dma_q = [&](const Blk& k) __attribute__((always_inline)) {
-    const E* qsrc = q_base(k);
-#pragma unroll
-    for (int i = 0; i < QDMA; ++i) dma_q_piece(qsrc, k.m_block * BM, k.sq, i);
+  auto dma_q_piece = [&](const u32x4& srd, int i) __attribute__((always_inline)) {   // piece i (0 .. QDMA-1) of this wave's rows
+    const int pc = wave * QDMA + i;
+    const int row = pc * RPD + d_row;
+    const unsigned vo = (unsigned)(row * (int)p.q_rs + ((d_pc ^ k_swz_w<D>(row)) << 3)) * 2u;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(Q_OFF + pc * 1024));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(dst), "s"(srd) : "memory");
+  };
+  auto dma_q = [&](const u32x4& srd) __attribute__((always_inline)) {
+#pragma unroll 1
+    for (int i = 0; i < QDMA; ++i) dma_q_piece(srd, i);
   };
   int q_in_lds = -1;   // virtual block whose Q this wave has prefetched into the LDS Q region
 
@@ -158,6 +184,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #endif
 #if FA_W64_ABL & 2048
   int abl_st = 0, abl_n = 4;
+  const long long abl_rt = wall_clock64();   // constant 100 MHz: lane 63 of the stamps = the block's duration in 10 ns units
 #define FA_W64_STAMP(idx_) do { const int sv_ = (int)(clock64() - abl_tk); abl_st = (lane == (idx_)) ? sv_ : abl_st; } while (0)
 #else
 #define FA_W64_STAMP(idx_) ((void)0)
@@ -201,10 +228,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   }
   const float thr = p.rescale_thr;
 
-  auto step_active = [&](int i) __attribute__((always_inline)) {
-    const int k0 = key_base + 32 * i;
-    return wave_valid && (i >= 0) && (i < n_steps) && (k0 <= w_kmax) && (k0 + 31 >= w_kmin);
-  };
   auto step_needs_mask = [&](int i) __attribute__((always_inline)) {
     const int k0 = key_base + 32 * i;
     return (k0 + 31 > w_full_hi) || (k0 < w_full_lo);
@@ -235,6 +258,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     return s;
   };
   const u32x4 k_srd = make_srd(kp, p.k_rs), v_srd = make_srd(vp, p.v_rs);
+  // Lanes whose offset lies outside a descriptor's range write ZEROS into LDS (tools/ubench/lds_dma_oob.hip): the rows of a partial
+  // last tile past the last key need no clamping (finite data, and the key-length mask hides them), and a descriptor of zero
+  // records zero-fills a whole tile without touching memory -- tiles past the last one, and the V tile the pipeline's first two
+  // steps multiply by P = 0, are "loaded" that way.
+  const u32x4 null_srd = {k_srd[0], k_srd[1], 0u, k_srd[3]};
   auto dma_pieces = [&](const u32x4& srd, const unsigned (&vo)[DPW], unsigned lds_dst) __attribute__((always_inline)) {
     unsigned keep;
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
@@ -254,46 +282,29 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
                    : "=&s"(keep) : "v"(vo[0]), "v"(vo[DPW - 1]), "s"(dst), "s"(srd) : "memory");
     }
   };
-  auto dma_tile = [&](auto isvc, int buf, int t) __attribute__((always_inline)) {  // t relative to n_min
+  auto dma_tile = [&](auto isvc, int buf, int t) __attribute__((always_inline)) {  // t relative to n_min; t < 0 or >= n_tiles: zero fill
     constexpr bool ISV = decltype(isvc)::value != 0;
-    const int n = n_min + t;
+    const bool real = t >= 0 && t < n_tiles;
     const int64_t rs = ISV ? p.v_rs : p.k_rs;
     const unsigned lds_dst = (unsigned)((ISV ? 2 + buf : buf) * TILE_BYTES + wave * DPW * 1024);
+    const unsigned toff = real ? (unsigned)(n_min + t) * (unsigned)(BN * 2) * (unsigned)rs : 0u;
     unsigned vo[DPW];
-    if (n * BN + BN <= sk) {
-      const unsigned toff = (unsigned)n * (unsigned)(BN * 2) * (unsigned)rs;
 #pragma unroll
-      for (int i = 0; i < DPW; ++i) vo[i] = (ISV ? voff_l[i] : koff_l[i]) + toff;
-    } else {  // last, partial tile
-#pragma unroll
-      for (int i = 0; i < DPW; ++i) {
-        const int row = (wave * DPW + i) * RPD + d_row;
-        const int grow = min(n * BN + row, sk - 1);
-        const int c = ISV ? ((((d_pc >> 2) ^ v_swz_w<D>(row)) << 2) | (d_pc & 3)) : (d_pc ^ k_swz_w<D>(row));
-        vo[i] = ((unsigned)grow * (unsigned)rs + (unsigned)(c * 8)) * 2u - (unsigned)(i * 1024);
-      }
-    }
-    dma_pieces(ISV ? v_srd : k_srd, vo, lds_dst);
+    for (int i = 0; i < DPW; ++i) vo[i] = (ISV ? voff_l[i] : koff_l[i]) + toff;
+    dma_pieces(real ? (ISV ? v_srd : k_srd) : null_srd, vo, lds_dst);
   };
 
   // ---- prologue.  The previous block's epilogue staged its O tile over the K/V buffers: nobody may refill them before every
   // wave is through with it.  Q: already prefetched by this wave during the previous block (its own rows, so its own
   // vmcnt wait at the tile barriers made them visible), else loaded now.  K_0 rides under the Q conversion.
-  // The first three tiles (K_0, V_0, K_1: everything iteration 0 and 1 read) are requested here, in front of the Q conversion,
-  // so that no iteration of the tile loop waits for a tile it has only just asked for.
+  // K_0 rides under the Q conversion; V buffer 1 -- which the first two steps of the pipeline multiply by P = 0 -- is zero-filled.
   __syncthreads();
   FA_W64_STAMP(0);
-  if (q_in_lds != vb) dma_q(blk);
-  if (n_tiles > 0) { dma_tile(ICw<0>{}, 0, 0); dma_tile(ICw<1>{}, 0, 0); }
-  if (n_tiles > 1) dma_tile(ICw<0>{}, 1, 1);
-  auto wait_pieces = [&](int tiles_left) __attribute__((always_inline)) {   // all but the last `tiles_left` tile requests have landed
-    if (tiles_left >= 2) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-    else if (tiles_left == 1) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-    else lds_dma_wait_all();
-  };
+  if (q_in_lds != vb) dma_q(q_srd_of(blk));
+  if (n_tiles > 0) { dma_tile(ICw<0>{}, 0, 0); dma_tile(ICw<1>{}, 1, -1); }
   if (q_in_lds != vb) {   // Q was not prefetched (first block of this workgroup): its pieces were requested first
-    if (n_tiles > 1) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-    else wait_pieces(n_tiles > 0 ? 2 : 0);
+    if (n_tiles > 0) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else lds_dma_wait_all();
   }
   // this wave's B-operand fragments of Q, pre-multiplied by softmax_scale*log2(e) and rounded once to the input dtype, into
   // accumulator registers for the whole block
@@ -316,29 +327,30 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     load_q_all(ICw<1>{});
   }
   FA_W64_STAMP(1);
-  wait_pieces(n_tiles > 1 ? 2 : n_tiles > 0 ? 1 : 0);   // K_0 (requested before the conversion); V_0 and K_1 may still be on their way
+  lds_dma_wait_all();   // K_0 (requested before the conversion)
   __syncthreads();
   FA_W64_STAMP(2);
   // Next block's Q rows of this wave -> LDS under this block's tile loop, a few 1-KiB pieces per iteration (each iteration's
   // tile barrier waits for the pieces requested in it).  All of them at once, as in round 2, put 64 KB per CU -- 16 MB across
   // the chip, every workgroup at the same moment -- in front of the first tiles of the loop: 16k clocks to get the requests
   // out and another 10k of iteration 0 waiting behind them (profiles/r03_fwd_w64_stamps.txt).
-  const E* qn_src = nullptr;
-  int qn_row0 = 0, qn_sq = 1, qn_done = QDMA, qn_per_iter = QDMA;
+  u32x4 qn_srd = null_srd;
+  int qn_done = QDMA, qn_per_iter = QDMA;
   {
     Blk nxt;
     q_in_lds = -1;
     if (p.persist_total > 0 && decode(vb + (int)gridDim.x, round + 1, nxt)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the Q region have returned
-      qn_src = q_base(nxt); qn_row0 = nxt.m_block * BM; qn_sq = nxt.sq; qn_done = 0;
+      qn_srd = q_srd_of(nxt); qn_done = 0;
       qn_per_iter = n_tiles >= QDMA ? 1 : n_tiles >= QDMA / 2 ? 2 : n_tiles >= QDMA / 4 ? 4 : QDMA;
-      if (n_tiles == 0) { dma_q(nxt); lds_dma_wait_all(); qn_done = QDMA; }   // no tile barrier will wait for it
+      if (n_tiles == 0) { dma_q(qn_srd); lds_dma_wait_all(); qn_done = QDMA; }   // no tile barrier will wait for it
       q_in_lds = vb + (int)gridDim.x;
     }
   }
   auto q_trickle = [&]() __attribute__((always_inline)) {   // called once per iteration, outside the steps (M0 is theirs inside)
     if (qn_done < QDMA) {
-      for (int j = 0; j < qn_per_iter; ++j) dma_q_piece(qn_src, qn_row0, qn_sq, qn_done + j);
+#pragma unroll 1
+      for (int j = 0; j < qn_per_iter; ++j) dma_q_piece(qn_srd, qn_done + j);
       qn_done += qn_per_iter;
     }
   };
@@ -348,80 +360,57 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   const int tr_i = lane & 15, tr_half = (lane >> 4) & 1;
   const int tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
   const int vbase = (4 * hi + tr_rr) * ROW_BYTES + (v_swz_w<D>(tr_rr) << 6) + tr_half * 32 + tr_cc * 8;
+  // The bases carry the buffer parity of the iteration (iteration u reads K buffer u & 1 and V buffer (u - 1) & 1) and are toggled
+  // at the end of every iteration: one body serves both parities (two copies of it were 60 KB of a 240 KB kernel that did not
+  // fit the instruction cache any more, profiles/r03_fwd_w64_stamps.txt).
   int ka[KS], va[DB];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) ka[ks] = kbase ^ (ks << 5);
 #pragma unroll
-  for (int db = 0; db < DB; ++db) va[db] = vbase ^ (db << 6);
+  for (int db = 0; db < DB; ++db) va[db] = (vbase ^ (db << 6)) + TILE_BYTES;
+  auto toggle_parity = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ka[ks] ^= TILE_BYTES;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) va[db] ^= TILE_BYTES;
+  };
 
   acc_zero_range<0>(std::make_integer_sequence<int, 32 * DB>{});   // O = 2*DB tuples: a[0 : 32*DB) (query block qb, d-block db at tuple qb*DB + db)
   float m_run[QB], l_run[QB][2], o_lag[QB];
   float thr_l[QB];          // per-lane decision threshold: -inf until the row has seen a key (any finite score moves m), then rescale_thr
-  bool lag_pending = false; // wave-uniform: some o_lag != 1 is waiting to be applied to O
-  f32x16 negm[QB];     // the C operand of every score chain's first MFMA: -m broadcast (0 while m = -inf), and -inf in the elements the
-                       // mask hides in a step that straddles a mask boundary (prep_c) -- the matrix pipe applies the mask
-  float nbase[QB];     // the value the visible elements of negm hold
-  bool negm_masked = false;   // wave-uniform: negm currently carries a step's mask
+  unsigned long long lag_mask = 0ull;   // wave-uniform, all ones or zero: some o_lag != 1 is waiting to be applied to O
+  f32x16 negm[QB];     // the C operand of every plain score chain's first MFMA: -m broadcast (0 while m = -inf).  A step that straddles a
+                       // mask boundary starts its chain from the score tuple itself, pre-loaded with -m or -inf (masked_c): the matrix
+                       // pipe applies the mask
   f32x16 sA[QB], sB[QB];
   u32x4 pfA[QB][2], pfB[QB][2];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    m_run[qb] = -INFINITY; l_run[qb][0] = 0.f; l_run[qb][1] = 0.f; o_lag[qb] = 1.f; thr_l[qb] = -INFINITY; nbase[qb] = 0.f;
+    m_run[qb] = -INFINITY; l_run[qb][0] = 0.f; l_run[qb][1] = 0.f; o_lag[qb] = 1.f; thr_l[qb] = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { negm[qb][r] = 0.f; sA[qb][r] = 0.f; sB[qb][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { negm[qb][r] = 0.f; sA[qb][r] = -INFINITY; sB[qb][r] = -INFINITY; }   // S_{-1} = -inf: P_{-1} = 0
 #pragma unroll
     for (int t = 0; t < 2; ++t) { pfA[qb][t] = u32x4{0u, 0u, 0u, 0u}; pfB[qb][t] = u32x4{0u, 0u, 0u, 0u}; }
   }
-  bool have_cur = false, have_prev = false;
 
-  // C operand of the score chain of step i (called right before its first MFMA): a step that straddles a mask boundary gets
-  // -inf in its hidden elements, so the scores leave the matrix pipe masked (s + (-inf) = -inf: exp2 gives 0, the row maximum
-  // ignores it) and the masked step is otherwise the plain step; the first plain step after it puts the broadcast back.
-  // Element by element through tied asm operands, as in rescale(): the tuple must stay in its registers.
+  // Start value of the score chain of a step that straddles a mask boundary: -m in the visible elements, -inf in the hidden ones, written
+  // into the (dead) score tuple itself, from which the chain then accumulates -- so the scores leave the matrix pipe masked
+  // (s + (-inf) = -inf: exp2 gives 0, the row maximum ignores it) and the masked step is otherwise the plain step.  negm is only
+  // read here: modifying it under a branch makes hipcc copy both tuples at every join (measured: 16 v_mov_b64 per plain step).
   const bool two_sided = p.wl >= 0;
-  auto prep_c = [&](int i) __attribute__((always_inline)) {
-    if (step_needs_mask(i)) {
-      const int k0 = key_base + 32 * i;
+  auto masked_c = [&](int i, f32x16 (&s_nxt)[QB]) __attribute__((always_inline)) {
+    const int k0 = key_base + 32 * i;
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        const int rel_hi = lim_hi[qb] - k0 - 4 * hi;
-        const int rel_lo = lim_lo[qb] - k0 - 4 * hi;
-        const float nb = nbase[qb];
-        float ninf = -INFINITY;
-        asm volatile("" : "+v"(ninf));   // a register: the lane-mask form of v_cndmask takes no literal
-        if (two_sided) {
+    for (int qb = 0; qb < QB; ++qb) {
+      const int rel_hi = lim_hi[qb] - k0 - 4 * hi;
+      const int rel_lo = lim_lo[qb] - k0 - 4 * hi;
+      if (two_sided) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int off = acc_row(r, 0);
-            const unsigned long long vis = __builtin_amdgcn_ballot_w64((off <= rel_hi) && (off >= rel_lo));
-            float nv = negm[qb][r];
-            asm volatile("v_cndmask_b32 %0, %3, %1, %2" : "+v"(nv) : "v"(nb), "s"(vis), "v"(ninf));
-            negm[qb][r] = nv;
-          }
-        } else {
+        for (int r = 0; r < 16; ++r) { const int off = acc_row(r, 0); s_nxt[qb][r] = ((off <= rel_hi) && (off >= rel_lo)) ? negm[qb][r] : -INFINITY; }
+      } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int off = acc_row(r, 0);
-            const unsigned long long vis = __builtin_amdgcn_ballot_w64(off <= rel_hi);
-            float nv = negm[qb][r];
-            asm volatile("v_cndmask_b32 %0, %3, %1, %2" : "+v"(nv) : "v"(nb), "s"(vis), "v"(ninf));
-            negm[qb][r] = nv;
-          }
-        }
+        for (int r = 0; r < 16; ++r) { const int off = acc_row(r, 0); s_nxt[qb][r] = (off <= rel_hi) ? negm[qb][r] : -INFINITY; }
       }
-      negm_masked = true;
-    } else if (negm_masked) {
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        const float nb = nbase[qb];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float nv = negm[qb][r];
-          asm volatile("v_mov_b32 %0, %1" : "+v"(nv) : "v"(nb));
-          negm[qb][r] = nv;
-        }
-      }
-      negm_masked = false;
     }
   };
   // Decision on the NEXT step's scores, held as s' = s - m_base (m_base = m, or 0 while m = -inf): the row moves its maximum
@@ -431,10 +420,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // (after P_i.V, computed at the old scale, has been accumulated) -- the lagged rescale of fa_fwd_il.hip.
   auto rescale = [&](auto qbc, bool grow, float tmax, f32x16& s_nxt) __attribute__((always_inline)) {
     constexpr int qb = decltype(qbc)::value;
-    const float m_upd = grow ? (tmax - nbase[qb]) : m_run[qb];   // grow => tmax finite
+    const float m_upd = grow ? (tmax - negm[qb][0]) : m_run[qb];   // grow => tmax finite
     const float m_safe = (m_upd == -INFINITY) ? 0.f : m_upd;
-    const float alpha = grow ? fast_exp2(m_run[qb] - m_safe) : 1.f;
-    const float delta = m_safe + nbase[qb];   // new base - old base (0 where the row did not move)
+    // (a row that sees its first key -- m = -inf -- has O = 0 and l = 0: its factor is 1, so the first decision of a block, which moves
+    // every row, leaves nothing to apply to O one step later)
+    const float alpha = (grow && m_run[qb] != -INFINITY) ? fast_exp2(m_run[qb] - m_safe) : 1.f;
+    const float delta = m_safe + negm[qb][0];   // new base - old base (0 where the row did not move)
     m_run[qb] = m_upd;
     thr_l[qb] = grow ? thr : thr_l[qb];
     l_run[qb][0] *= alpha;
@@ -442,120 +433,34 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     // in place, element by element through tied asm operands: a recomputed tuple would live in NEW registers and cost the
     // common path a 16-register copy at the join
     const float neg = -m_safe;
-    nbase[qb] = neg;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {   // (writes the plain broadcast: a mask negm carried is dropped, see negm_masked below)
+    for (int r = 0; r < 16; ++r) {
       float sv = s_nxt[r], nv = negm[qb][r];
       asm volatile("v_sub_f32 %0, %0, %2\n\tv_mov_b32 %1, %3" : "+v"(sv), "+v"(nv) : "v"(delta), "v"(neg));
       s_nxt[r] = sv;
       negm[qb][r] = nv;
     }
-    // O of this query block (accumulator registers 16*DB*qb ..): one register at a time through one temporary; skipped when
-    // no factor is pending (the first decision of every block: m = -inf -> finite, O still 0)
-    if (lag_pending) acc_scale_range<16 * DB * qb>(o_lag[qb], std::make_integer_sequence<int, 16 * DB>{});
+    // O of this query block (accumulator registers 16*DB*qb ..), two registers at a time; skipped when no factor is pending
+    if (lag_mask != 0ull) acc_scale_range<16 * DB * qb>(o_lag[qb], std::make_integer_sequence<int, 16 * DB>{});
     o_lag[qb] = alpha;
   };
   // tmax = row maxima of s' (already combined across the lane halves)
   auto decide_and_rescale = [&](const float (&tmax)[QB], f32x16 (&s_nxt)[QB]) __attribute__((always_inline)) {
-    const bool g0 = tmax[0] > thr_l[0], g1 = tmax[1] > thr_l[1];
-    const bool any_grow = __builtin_amdgcn_ballot_w64(g0 || g1) != 0ull;
+    // (the two compares and the OR in one statement: hipcc's own rendering of "any lane" is 10 instructions at every step boundary)
+    unsigned long long grow_mask;
+    asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cmp_gt_f32 %0, %3, %4\n\ts_or_b64 %0, %0, vcc"
+                 : "=&s"(grow_mask) : "v"(tmax[0]), "v"(thr_l[0]), "v"(tmax[1]), "v"(thr_l[1]) : "vcc");
     // cold: ~4 KB of straight-line code per call site.  Left in line it sat between the steps of the tile loop and every
     // step paid an instruction-fetch miss jumping over it (18 of 63 clocks per MFMA, profiles/r02_w64_ablations.txt);
     // __builtin_expect moves it behind the loop.
-    if (__builtin_expect(any_grow || lag_pending, 0)) {
+    if (__builtin_expect((grow_mask | lag_mask) != 0ull, 0)) {
+      const bool g0 = tmax[0] > thr_l[0], g1 = tmax[1] > thr_l[1];
       mfma_drain_acc();  // O is about to be read by the VALU
       rescale(ICw<0>{}, g0, tmax[0], s_nxt[0]);
       rescale(ICw<1>{}, g1, tmax[1], s_nxt[1]);
-      negm_masked = false;
-      lag_pending = any_grow;
+      lag_mask = __builtin_amdgcn_ballot_w64(o_lag[0] != 1.f || o_lag[1] != 1.f) != 0ull ? ~0ull : 0ull;
     }
   };
-  auto row_max = [&](const f32x16& s) __attribute__((always_inline)) {
-    float t = vmax3(s[0], s[1], s[2]);
-#pragma unroll
-    for (int r = 3; r < 15; r += 2) t = vmax3(t, s[r], s[r + 1]);
-    t = vmax2(t, s[15]);
-    return vhalf_max(t);
-  };
-
-  // ---- generic (head / tail) step: compiler-ordered, drains the matrix pipe before the VALU touches MFMA results ------
-  auto generic_step = [&](int par, auto halfc, int i, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB], const u32x4 (&pf_prev)[QB][2],
-                          u32x4 (&pf_cur)[QB][2]) __attribute__((always_inline)) {
-    constexpr int half = decltype(halfc)::value;
-    const bool do_qk = step_active(i + 1);
-    const bool do_sm = have_cur;
-    const bool do_pv = have_prev;
-    const int koff = par * TILE_BYTES + half * 32 * ROW_BYTES;
-    const int voff = (2 + (par ^ 1)) * TILE_BYTES + half * 32 * ROW_BYTES;
-    if (do_qk) {
-      prep_c(i + 1);
-      u32x4 kf_nxt = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[0] + koff);
-      static_for<KS>([&](auto ksc) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ksc)::value;
-        const u32x4 kf = kf_nxt;
-        if constexpr (ks + 1 < KS) kf_nxt = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[ks + 1] + koff);
-        if constexpr (ks == 0) {
-          mfma_s_first<E, 0>(s_nxt[0], kf, negm[0]);
-          mfma_s_first<E, KS>(s_nxt[1], kf, negm[1]);
-        } else {
-          mfma_s_acc<E, ks>(s_nxt[0], kf);
-          mfma_s_acc<E, KS + ks>(s_nxt[1], kf);
-        }
-      });
-    }
-    if (do_sm) {  // s_cur is at least one whole step old: safe to read
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float p0 = fast_exp2(s_cur[qb][r]), p1 = fast_exp2(s_cur[qb][r + 1]);
-          s_cur[qb][r] = p0; s_cur[qb][r + 1] = p1;
-          ps0 += p0; ps1 += p1;
-        }
-        l_run[qb][0] += ps0;
-        l_run[qb][1] += ps1;
-      }
-    }
-    if (do_pv) {
-      auto rd_v = [&](int g) __attribute__((always_inline)) {
-        const char FA_LDS* a0 = (const char FA_LDS*)(unsigned long)(unsigned)(va[g % DB] + voff + (16 * (g / DB)) * ROW_BYTES);
-        const s16x4 vlo = lds_read_tr16(a0), vhi = lds_read_tr16(a0 + 8 * ROW_BYTES);
-        return __builtin_bit_cast(u32x4, combine_tr<V8>(vlo, vhi));
-      };
-      u32x4 vf_nxt = rd_v(0);
-      static_for<2 * DB>([&](auto gc) __attribute__((always_inline)) {
-        constexpr int g = decltype(gc)::value;
-        const u32x4 vf = vf_nxt;
-        if constexpr (g + 1 < 2 * DB) vf_nxt = rd_v(g + 1);
-        mfma_o_acc<E, g % DB>(vf, pf_prev[0][g / DB]);
-        mfma_o_acc<E, DB + g % DB>(vf, pf_prev[1][g / DB]);
-      });
-    }
-    {
-      float tmax[QB] = {-INFINITY, -INFINITY};
-      if (do_qk) {
-        mfma_drain_v(s_nxt[0], s_nxt[1]);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) tmax[qb] = row_max(s_nxt[qb]);
-      }
-      decide_and_rescale(tmax, s_nxt);   // without fresh scores tmax = -inf never grows; a pending O factor is still applied
-    }
-    if (do_sm) {
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          V8 x;
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) x[jj] = (E)s_cur[qb][8 * t + jj];
-          pf_cur[qb][t] = __builtin_bit_cast(u32x4, x);
-        }
-    }
-    have_prev = do_sm;
-    have_cur = do_qk;
-  };
-
   // ---- steady-state step: NG MFMA gaps, everything else hand-assigned to a gap ---------------------------------------
   //   gaps 0 .. 2KS-1      : S_{i+1}[qb] chain, k-step g/2 (the K fragment read once, used by both query blocks)
   //   gaps 2KS .. NG-1     : O[qb][db] += V^T.P_{i-1}[qb], op (g - 2KS)/2 (the V fragment read once, used by both)
@@ -565,13 +470,14 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   //   been issued, i.e. with nothing to hide behind).  The step's K or V tile DMA pieces sit in the odd gaps 1, 3, ...
   //   (DPW pieces: M0 is written with the first one and must survive until the last -- hipcc emits no M0 use in this kernel,
   //   checked in the ISA by tools/isa_blocks.py --m0).
-  auto fast_step = [&](auto parc, auto halfc, int i_nxt, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
+  auto fast_step = [&](auto halfc, auto maskc, int i_nxt, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
                        const u32x4 (&pf_prev)[QB][2], u32x4 (&pf_cur)[QB][2], const u32x4& dma_srd, const unsigned (&dma_off)[DPW],
                        unsigned dma_toff, unsigned dma_dst) __attribute__((always_inline)) {
-    constexpr int par = decltype(parc)::value, half = decltype(halfc)::value;
+    constexpr int half = decltype(halfc)::value;
+    constexpr bool MASK = decltype(maskc)::value != 0;
     constexpr int QKG = 2 * KS, PVG = 4 * DB, NG = QKG + PVG;
-    constexpr int KOFF = par * TILE_BYTES + half * 32 * ROW_BYTES;
-    constexpr int VOFF = (2 + (par ^ 1)) * TILE_BYTES + half * 32 * ROW_BYTES;
+    constexpr int KOFF = half * 32 * ROW_BYTES;                    // (+ the buffer parity carried by ka / va)
+    constexpr int VOFF = 2 * TILE_BYTES + half * 32 * ROW_BYTES;
     constexpr int AH = 2, RING = AH + 1;  // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
     constexpr int NF = KS + 2 * DB;       // fragment slots per step: KS K fragments, then 2*DB V fragments
     u32x4 kfr[RING];
@@ -599,8 +505,8 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     // element e of P_i (e = 16*qb + r): done-by-gap schedule
     auto el_end = [](int x) constexpr { return x <= QKG ? (24 * x) / QKG : (24 + ((x - QKG) * 16) / PVG > 32 ? 32 : 24 + ((x - QKG) * 16) / PVG); };
     float pe[QB][16];   // P_i as scalars (writing them back into the score tuples makes hipcc copy whole 16-register tuples)
-    float tmax[QB] = {-INFINITY, -INFINITY};
-    prep_c(i_nxt);   // (a step that straddles a mask boundary: the mask goes into the chain's C operand; nothing else differs)
+    float tmax[QB] = {-INFINITY, -INFINITY}, tcopy[QB] = {0.f, 0.f};
+    if constexpr (MASK) masked_c(i_nxt, s_nxt);   // (a step that straddles a mask boundary: the mask goes into the chain's start value; nothing else differs)
     // gap (inside the PV half) schedule of the row-max work of query block mq
     constexpr int UPG = PVG >= 16 ? 1 : 2;        // max3 units per gap
     auto tree_g0 = [](int mq) constexpr { return 1 + mq; };   // the chain of block mq retired at gap QKG - 2 + mq
@@ -613,21 +519,22 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       constexpr int f = x / 2, qb = x & 1;
       if constexpr (qb == 0) rd_frag(f + AH);
       if constexpr (x < QKG) {
-        if constexpr (f == 0) mfma_s_first<E, qb * KS>(s_nxt[qb], kfr[f % RING], negm[qb]);
+        if constexpr (f == 0 && !MASK) mfma_s_first<E, qb * KS>(s_nxt[qb], kfr[f % RING], negm[qb]);
         else mfma_s_acc<E, qb * KS + f>(s_nxt[qb], kfr[f % RING]);
       } else {
         constexpr int op = f - KS;
         const u32x4 vf = __builtin_bit_cast(u32x4, combine_tr<V8>(vlo[f % RING], vhi[f % RING]));
         mfma_o_acc<E, qb * DB + op % DB>(vf, pf_prev[qb][op / DB]);
       }
-      // this step's DMA pieces (K_{u+1} in the first step of an iteration, V_u in the second): odd gaps 1, 3, ..
-      if constexpr ((x & 1) && (x / 2) < DPW && !(FA_W64_ABL & 32)) {
-        constexpr int pc = x / 2;
-        const unsigned vo = dma_off[pc] + dma_toff;
+      // this step's DMA pieces (K_{u+1} in the first step of an iteration, V_u in the second): gaps G0, G0 + GS, ..
+      constexpr int G0 = half == 0 ? FA_W64_KDMA_G0 : FA_W64_VDMA_G0, GS = half == 0 ? FA_W64_KDMA_GS : FA_W64_VDMA_GS;
+      if constexpr (x >= G0 && (x - G0) % GS == 0 && (x - G0) / GS < DPW && !(FA_W64_ABL & 32)) {
+        constexpr int pc = (x - G0) / GS;
+        // (the tile's byte offset rides in the scalar-offset operand; the range check accounts for it: tools/ubench/lds_dma_oob.hip)
         if constexpr (pc == 0)
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(vo), "s"(dma_dst), "s"(dma_srd) : "memory");
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
         else
-          asm volatile("buffer_load_dwordx4 %0, %1, 0 offen offset:%c2 lds" : : "v"(vo), "s"(dma_srd), "i"(1024 * pc) : "memory");
+          asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2 lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
       }
       // exp2 + row sums (two running sums per query block, carried across steps)
 #pragma unroll
@@ -665,7 +572,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
               tmax[mq] = u == 0 ? vmax3(s_nxt[mq][0], s_nxt[mq][1], s_nxt[mq][2])
                                 : u < 7 ? vmax3(tmax[mq], s_nxt[mq][2 * u + 1], s_nxt[mq][2 * u + 2]) : vmax2(tmax[mq], s_nxt[mq][15]);
           }
-          if (y == hm_gap(mq) && !(FA_W64_ABL & (8 | 1024))) tmax[mq] = vhalf_max(tmax[mq]);
+          // cross-half combine in two statements a gap apart: the copy, then swap + max (v_permlane32_swap wants two wait states
+          // after the write of its operand: the gap's other instructions provide them, no s_nop)
+          if (y == hm_gap(mq) - 1 && !(FA_W64_ABL & (8 | 1024))) asm volatile("v_mov_b32 %0, %1" : "=v"(tcopy[mq]) : "v"(tmax[mq]));
+          if (y == hm_gap(mq) && !(FA_W64_ABL & (8 | 1024)))
+            asm volatile("v_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(tmax[mq]), "+v"(tcopy[mq]));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -678,76 +589,86 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     }
   };
 
-  // iteration u (0..n_tiles): steps 2u-1 and 2u read K_u (kbuf[u&1]) and V_{u-1} (vbuf[(u-1)&1]); K_{u+1} and V_u are
-  // DMA'd during the iteration into the buffers it does not read.  Head / steady-state / tail split as in fa_fwd_il.hip.
-  // (A wave's two drain steps after its last scored step -- {exp2 + P.V}, {P.V} -- stay on the generic path.  Tried and
-  // measured slower or wrong: running them as MASKED steady-state steps, whose discarded score chains cost more than the
-  // generic step saves (config 3: 949 -> 858 TFLOP/s); compile-time variants of the steady-state step without the score
-  // chain, which were right one at a time and wrong -- rows without any visible key -- when both were instantiated.)
-  int uf_lo = 1, uf_hi = 0;
+  // Iteration u (0 .. n_tiles) = two steps: 2u-1 and 2u score K_u (K buffer u & 1) and multiply by V_{u-1} (V buffer (u - 1) & 1);
+  // K_{u+1} and V_u are DMA'd during it into the buffers it does not read.  ONE body runs every iteration a wave takes part in,
+  // pipeline fill and drain included: a chain that scores no real key (step < 0 side of the fill never occurs -- the fill's first
+  // chain is step 0; steps past the wave's last key, past the last tile) gets C = -inf in every element (prep_c), its scores are
+  // -inf, its P is 0 and it never moves a maximum; the fill multiplies P = 0 by the zero tile the prologue put into V buffer 1.
+  // That wastes four half-steps of MFMA work per wave and block, and replaces the compiler-ordered "generic" fill / drain steps of
+  // round 2 -- which, with their own copies of the cold rescale code, made the kernel 240 KB and every once-per-block path an
+  // instruction-cache miss stream (12-17k clocks for iteration 0 against 3.2k for a steady-state iteration).
+  // Waves outside their range (rows past the sequence end, the early-finishing waves of a block under a causal mask, windows) only
+  // issue their share of the tile DMAs and meet the barriers.
+  // Per wave the iterations 0 .. n_tiles fall into five consecutive ranges -- idle | masked | plain | masked | idle -- walked by three
+  // tight loops (one per kind, entered from a five-round phase loop): the plain loop's body is nothing but the two plain steps.
+  // (With the kinds as branches inside ONE loop hipcc joins the score tuples of the variants at every iteration and copies 32
+  // registers between every two steps.)
+  int u_first = n_tiles + 1, u_last = n_tiles, p_lo = n_tiles + 1, p_hi = n_tiles;   // all idle
   if (wave_valid && n_tiles > 0) {
-    const int a_lo = max(0, (w_kmin - key_base) >> 5);
+    const int a_lo = max(0, (w_kmin - key_base) >> 5);               // first / last step with a key this wave can see
     const int a_hi = min(n_steps - 1, (w_kmax - key_base) >> 5);
-    uf_lo = (a_lo + 3) >> 1;
-    uf_hi = (a_hi - 1) >> 1;
-    // the steady-state iteration u DMAs the tiles n_min+u+1 (K) and n_min+u (V) with unclamped row addresses: keep the
-    // partial last tile of a sequence (sk % 64 != 0) out of it -- the generic iterations clamp its rows
-    if (sk % BN != 0) uf_hi = min(uf_hi, sk / BN - n_min - 2);
+    if (a_hi >= a_lo) {
+      u_first = a_lo >> 1; u_last = min(n_tiles, (a_hi + 2) >> 1);
+      const int f_lo = max(0, (w_full_lo - key_base + 31) >> 5);     // first step with no left-masked key
+      const int f_hi = (w_full_hi - 31 - key_base) >> 5;             // last step with no right-masked key (< n_steps: w_full_hi < sk)
+      p_lo = max(u_first, (f_lo + 1) >> 1);
+      p_hi = min(u_last, (f_hi - 1) >> 1);
+      if (p_hi < p_lo) { p_lo = u_last + 1; p_hi = u_last; }         // no plain iteration: one masked range
+    }
   }
-#ifdef FA_W64_NOFAST   // debugging: every iteration through the generic step
-  uf_lo = 1; uf_hi = 0;
-#endif
-  auto iter_head = [&](int u) __attribute__((always_inline)) {
-    if ((FA_W64_ABL & 32) && u > 1) return;
-    q_trickle();
-    if (u == 0) return;   // K_1 and V_0 were requested in the prologue
-    const int par = u & 1;
-    if (u + 1 < n_tiles) dma_tile(ICw<0>{}, par ^ 1, u + 1);
-    if (u < n_tiles) dma_tile(ICw<1>{}, par, u);
-  };
-  auto iter_tail = [&]() __attribute__((always_inline)) {
-    if (FA_W64_ABL & 512) return;
-    lds_dma_wait_all();
-    __syncthreads();
-#if FA_W64_ABL & 2048
-    if (abl_n < 62) { FA_W64_STAMP(abl_n); ++abl_n; }
-#endif
-  };
-  auto generic_iter = [&](int u) __attribute__((always_inline)) {
-    iter_head(u);
-    generic_step(u & 1, ICw<0>{}, 2 * u - 1, sA, sB, pfA, pfB);
-    generic_step(u & 1, ICw<1>{}, 2 * u, sB, sA, pfB, pfA);
-    iter_tail();
-  };
+  const unsigned wave_dst = (unsigned)(wave * DPW * 1024);
 #if FA_W64_ABL & 256
   const long long abl_t0 = clock64();
 #endif
   FA_W64_STAMP(3);
+  auto iter_end = [&]() __attribute__((always_inline)) {
+    if (!(FA_W64_ABL & 512)) {
+      lds_dma_wait_all();
+      __syncthreads();
+    }
+#if FA_W64_ABL & 2048
+    if (abl_n < 62) { FA_W64_STAMP(abl_n); ++abl_n; }
+#endif
+    toggle_parity();
+  };
+  auto step_pair = [&](auto maskc, int u) __attribute__((always_inline)) {
+    // K_{u+1} rides in the first step, V_u in the second; tiles past the last one: the null descriptor (zero fill, no traffic)
+    const int par = u & 1;
+    q_trickle();
+    const bool k_real = u + 1 < n_tiles, v_real = u < n_tiles;
+    const unsigned toff_k = k_real ? (unsigned)(n_min + u + 1) * (unsigned)(BN * 2) * (unsigned)p.k_rs : 0u;
+    const unsigned toff_v = v_real ? (unsigned)(n_min + u) * (unsigned)(BN * 2) * (unsigned)p.v_rs : 0u;
+    const u32x4 srd_k = k_real ? k_srd : null_srd, srd_v = v_real ? v_srd : null_srd;
+    const unsigned dst_k = __builtin_amdgcn_readfirstlane((unsigned)((par ^ 1) * TILE_BYTES) + wave_dst);
+    unsigned dst_v = __builtin_amdgcn_readfirstlane((unsigned)((2 + par) * TILE_BYTES) + wave_dst);
+    // (computed HERE: left to itself hipcc sinks these scalar selects and multiplies into the steps' MFMA gaps)
+    u32x4 sk_ = srd_k, sv_ = srd_v;
+    unsigned tk_ = toff_k, tv_ = toff_v;
+    asm volatile("" : "+s"(sk_), "+s"(sv_), "+s"(tk_), "+s"(tv_), "+s"(dst_v));
+    fast_step(ICw<0>{}, maskc, 2 * u, sA, sB, pfA, pfB, sk_, koff_l, tk_, dst_k);
+    fast_step(ICw<1>{}, maskc, 2 * u + 1, sB, sA, pfB, pfA, sv_, voff_l, tv_, dst_v);
+    iter_end();
+  };
   if (n_tiles > 0) {
     int u = 0;
-    const int head_end = min(max(uf_lo, 0), n_tiles + 1);
-    for (; u < head_end; ++u) generic_iter(u);
-    const unsigned wave_dst = (unsigned)(wave * DPW * 1024);
-    auto fast_iter = [&](auto parc, int uu) __attribute__((always_inline)) {
-      constexpr int par = decltype(parc)::value;
-      // K_{u+1} rides in the first step, V_u in the second (full tiles only, see uf_hi; a K tile past the last one lands in
-      // the buffer nobody reads again: rows past the end of the buffer descriptor are out of range, never a fault)
-      q_trickle();
-      const unsigned toff_k = (unsigned)(n_min + uu + 1) * (unsigned)(BN * 2) * (unsigned)p.k_rs;
-      const unsigned toff_v = (unsigned)(n_min + uu) * (unsigned)(BN * 2) * (unsigned)p.v_rs;
-      fast_step(parc, ICw<0>{}, 2 * uu, sA, sB, pfA, pfB, k_srd, koff_l, toff_k, __builtin_amdgcn_readfirstlane((unsigned)((par ^ 1) * TILE_BYTES) + wave_dst));
-      fast_step(parc, ICw<1>{}, 2 * uu + 1, sB, sA, pfB, pfA, v_srd, voff_l, toff_v, __builtin_amdgcn_readfirstlane((unsigned)((2 + par) * TILE_BYTES) + wave_dst));
-      have_prev = step_active(2 * uu);      // P_{2u} is packed and S_{2u+1} is pending -- what the generic steps that follow
-      have_cur = step_active(2 * uu + 1);   // expect; past the wave's last scored step they are 0 / -inf and simply dropped
-      iter_tail();
-    };
-    if (u <= uf_hi && (u & 1)) { fast_iter(ICw<1>{}, u); ++u; }
-    for (; u + 1 <= uf_hi; u += 2) {
-      fast_iter(ICw<0>{}, u);
-      fast_iter(ICw<1>{}, u + 1);
+#pragma unroll 1
+    for (int phase = 0; phase < 5; ++phase) {
+      const int end = phase == 0 ? u_first : phase == 1 ? p_lo : phase == 2 ? p_hi + 1 : phase == 3 ? u_last + 1 : n_tiles + 1;
+      if (phase == 2) {
+#pragma unroll 1
+        for (; u < end; ++u) step_pair(ICw<0>{}, u);
+      } else if (phase == 1 || phase == 3) {
+#pragma unroll 1
+        for (; u < end; ++u) step_pair(ICw<1>{}, u);
+      } else {
+#pragma unroll 1
+        for (; u < end; ++u) {
+          q_trickle();
+          if (!(FA_W64_ABL & 32) || u <= 1) { dma_tile(ICw<0>{}, (u & 1) ^ 1, u + 1); dma_tile(ICw<1>{}, u & 1, u); }
+          iter_end();
+        }
+      }
     }
-    if (u <= uf_hi) { fast_iter(ICw<0>{}, u); ++u; }
-    for (; u <= n_tiles; ++u) generic_iter(u);
   }
 
 #if FA_W64_ABL & 256
@@ -756,6 +677,15 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #endif
   if (wave_valid) {
   mfma_drain_acc();
+  u32x4 o_srd;
+  {
+    const int rows = min(BM, sq - m0);
+    const unsigned long long a = (unsigned long long)(op + (int64_t)m0 * p.o_rs);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi16 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;
+    const unsigned nr = __builtin_amdgcn_readfirstlane((unsigned)(((unsigned long long)(rows - 1) * (unsigned long long)p.o_rs + D) * 2ull));
+    o_srd = u32x4{lo, hi16, nr, 0x00020000u};
+  }
   // O tile through LDS (the K/V buffers are free after the last tile barrier; the Q region may already hold the next block's
   // rows and is not touched): whole-row stores
   static_for<QB>([&](auto qbc) __attribute__((always_inline)) {
@@ -772,7 +702,32 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     const float inv = dead ? 1.f : 1.f / l_tot;
     const int row0 = w_row0 + 32 * qb;
     if (row0 < sq) {
-      store_tile_via_lds<E, D>(lds + (wave * 64 + qb * 32) * (ROW_BYTES + 16), o_v, inv, op + (int64_t)row0 * p.o_rs, p.o_rs, sq - row0, lane);
+      // 32 rows through this wave's staging rows, then whole-row stores through the block's O descriptor: rows past the sequence
+      // end are outside it and dropped; one 32-bit lane offset (laundered: as a loop invariant of the persistent loop hipcc would
+      // keep sixteen 64-bit store addresses alive across the tile loop and spill them) + a scalar offset per store
+      {
+        using V4 = typename T::v4;
+        constexpr int RS = ROW_BYTES + 16, RPI = 64 / CPR;
+        char FA_LDS* stage = lds + (wave * 64 + qb * 32) * RS;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            V4 ov;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) ov[jj] = (E)(o_v[db][4 * g + jj] * inv);
+            *reinterpret_cast<V4 FA_LDS*>(stage + qi * RS + (32 * db + 8 * g + 4 * hi) * 2) = ov;
+          }
+        unsigned lane_off = (unsigned)(((wave * 64 + lane / CPR) * (int)p.o_rs + (lane % CPR) * 8) * 2);
+        asm volatile("" : "+v"(lane_off));
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+          const u32x4 x = *reinterpret_cast<const u32x4 FA_LDS*>(stage + (i * RPI + lane / CPR) * RS + (lane % CPR) * 16);
+          const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((qb * 32 + i * RPI) * (int)p.o_rs * 2));
+          asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" : : "v"(x), "v"(lane_off), "s"(o_srd), "s"(soff) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging rows are rewritten by the next query block
+      }
       const int my_row = row0 + qi;
 #if FA_W64_ABL & 256   // rows = 0 mod 4: clocks per MFMA of the tile loop; 1: prologue clocks; 2: tile-loop clocks; 3: epilogue clocks so far
       if (my_row < sq && hi == 0) {
@@ -783,6 +738,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       if (qb == QB - 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FA_W64_STAMP(62);
+        abl_st = (lane == 63) ? (int)(wall_clock64() - abl_rt) : abl_st;
         if (w_row0 + lane < sq) lsep[w_row0 + lane] = (float)abl_st;
       }
 #else

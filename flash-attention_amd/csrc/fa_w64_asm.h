@@ -32,7 +32,18 @@ template <int N> FA_DEVINL void acc_scale(float f) {
   float t;
   asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\ts_nop 0\n\tv_accvgpr_write_b32 a[%c2], %0" : "=&v"(t) : "v"(f), "i"(N) : FA_W64_CLOB);
 }
-template <int N0, int... I> FA_DEVINL void acc_scale_range(float f, std::integer_sequence<int, I...>) { (acc_scale<N0 + I>(f), ...); }
+// two registers per statement, their instructions interleaved: no instruction consumes its predecessor's result, so no pads
+// (3 instructions per register instead of 5 -- this is cold code, but two copies of 128 registers' worth sit in the tile loop's body)
+template <int N> FA_DEVINL void acc_scale2(float f) {
+  float t, u;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c3]\n\tv_accvgpr_read_b32 %1, a[%c4]\n\tv_mul_f32 %0, %0, %2\n\tv_mul_f32 %1, %1, %2\n\t"
+               "v_accvgpr_write_b32 a[%c3], %0\n\tv_accvgpr_write_b32 a[%c4], %1"
+               : "=&v"(t), "=&v"(u) : "v"(f), "i"(N), "i"(N + 1) : FA_W64_CLOB);
+}
+template <int N0, int... I> FA_DEVINL void acc_scale_range(float f, std::integer_sequence<int, I...>) {
+  static_assert(sizeof...(I) % 2 == 0, "even register count");
+  ((I % 2 == 0 ? acc_scale2<N0 + I>(f) : (void)0), ...);
+}
 template <int N0, int... I> FA_DEVINL void acc_zero_range(std::integer_sequence<int, I...>) { (acc_write<N0 + I>(0.f), ...); }
 // (elements are copied to scalars first: __builtin_bit_cast applied directly to an ext_vector element lvalue reads element 0)
 template <int N0> FA_DEVINL void acc_read_tuple(f32x16& x) {
