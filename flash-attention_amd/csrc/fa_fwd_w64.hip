@@ -39,6 +39,9 @@
 
 // Gaps of a step that carry its LDS-DMA pieces (first gap, stride): where a piece is issued prices it between ~30 and ~180 clocks
 // (MI355X_MICROARCH.md "LDS-DMA piece issue cost"; profiles/r03_fwd_w64_dma_placement.txt)
+#ifndef FA_W64_AH
+#define FA_W64_AH 2   // LDS operand reads run this many fragment slots (2 gaps each) ahead of their MFMAs
+#endif
 #ifndef FA_W64_KDMA_G0
 #define FA_W64_KDMA_G0 1
 #define FA_W64_KDMA_GS 2
@@ -116,7 +119,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   struct Blk { int b, h, m_block, sq, sk; int64_t q_row0, k_row0, q_boff, k_boff, v_boff, o_boff; };
   const int n_virtual = p.persist_total > 0 ? p.persist_total : (int)gridDim.x;
   const bool snake = p.persist_total > 0 && p.wr >= 0 && p.unit_size > 1 && ((int)(gridDim.x / 8) % p.unit_size) == 0;
-  auto decode = [&](int vb, int round, Blk& k) __attribute__((always_inline)) -> bool {
+  // decode_id: virtual block -> (batch, head, query block): the divisions, done ONCE per block (the id of the next block is carried
+  // over from the Q prefetch); fill_blk: lengths and offsets of a block, cheap
+  auto decode_id = [&](int vb, int round, Blk& k) __attribute__((always_inline)) -> bool {
     if (vb >= n_virtual) return false;
     if (p.work_list) {  // varlen: non-empty blocks only, heaviest first (fa_varlen_schedule_kernel)
       if (!work_list_item(p.work_list, vb, p.h, p.h_k, k.b, k.h, k.m_block)) return false;
@@ -134,6 +139,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       k.b = bh / p.h;
       k.h = bh - k.b * p.h;
     }
+    return true;
+  };
+  auto fill_blk = [&](Blk& k) __attribute__((always_inline)) -> bool {
     k.sq = p.sq; k.sk = p.sk; k.q_row0 = 0; k.k_row0 = 0;
     const int bkv = p.kv_batch_idx ? p.kv_batch_idx[k.b] : k.b;
     k.q_boff = (int64_t)k.b * p.q_bs; k.k_boff = (int64_t)bkv * p.k_bs; k.v_boff = (int64_t)bkv * p.v_bs; k.o_boff = (int64_t)k.b * p.o_bs;
@@ -178,6 +186,24 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   };
   int q_in_lds = -1;   // virtual block whose Q this wave has prefetched into the LDS Q region
 
+  // ---- per-lane constants of every block: DMA source offsets of this lane's K / V pieces, LDS read bases
+  constexpr int NDMA = TILE_BYTES / 1024;          // DMA instructions per tile
+  constexpr int DPW = NDMA / NW;                   // per wave: 4 (D = 128) or 2 (D = 64)
+  unsigned koff_l[DPW], voff_l[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int row = (wave * DPW + i) * RPD + d_row;
+    const int kc = d_pc ^ k_swz_w<D>(row);
+    const int vc = ((((d_pc >> 2) ^ v_swz_w<D>(row)) << 2) | (d_pc & 3));
+    koff_l[i] = (unsigned)(row * (int)p.k_rs + kc * 8) * 2u - (unsigned)(i * 1024);
+    voff_l[i] = (unsigned)(row * (int)p.v_rs + vc * 8) * 2u - (unsigned)(i * 1024);
+  }
+  const float thr = p.rescale_thr;
+  const bool two_sided = p.wl >= 0;
+
+  Blk cur_id;
+  cur_id.b = 0; cur_id.h = 0; cur_id.m_block = 0;
+  bool cur_ok = decode_id((int)blockIdx.x, 0, cur_id);
   for (int vb = blockIdx.x, round = 0; vb < n_virtual; vb += gridDim.x, ++round) {
 #if FA_W64_ABL & (256 | 2048)
   const long long abl_tk = clock64();
@@ -189,8 +215,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #else
 #define FA_W64_STAMP(idx_) ((void)0)
 #endif
-  Blk blk;
-  if (!decode(vb, round, blk)) continue;   // (uniform over the workgroup: no barrier is skipped by part of it)
+  Blk blk = cur_id, nxt;
+  const bool blk_ok = cur_ok && fill_blk(blk);
+  nxt.b = 0; nxt.h = 0; nxt.m_block = 0;
+  const bool nxt_id_ok = p.persist_total > 0 && decode_id(vb + (int)gridDim.x, round + 1, nxt);
+  cur_id = nxt; cur_ok = nxt_id_ok;
+  if (!blk_ok) continue;   // (uniform over the workgroup: no barrier is skipped by part of it)
   const int b = blk.b, h = blk.h, m_block = blk.m_block, sq = blk.sq, sk = blk.sk;
   const int hk = h / p.hk_ratio;
   const int64_t q_row0 = blk.q_row0, k_row0 = blk.k_row0, q_boff = blk.q_boff, k_boff = blk.k_boff, v_boff = blk.v_boff, o_boff = blk.o_boff;
@@ -226,8 +256,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     lim_hi[qb] = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
     lim_lo[qb] = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
   }
-  const float thr = p.rescale_thr;
-
   auto step_needs_mask = [&](int i) __attribute__((always_inline)) {
     const int k0 = key_base + 32 * i;
     return (k0 + 31 > w_full_hi) || (k0 < w_full_lo);
@@ -237,17 +265,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // are applied to the per-lane SOURCE chunk.  A wave issues its DPW pieces of a tile from ONE statement: M0 = LDS base
   // of piece 0, pieces 1.. by the instruction offset (added to the LDS AND the memory address, hence the -1024*i folded
   // into each piece's lane offset).  Rows past the last key are clamped to the last key (finite data, masked to -inf).
-  constexpr int NDMA = TILE_BYTES / 1024;          // DMA instructions per tile
-  constexpr int DPW = NDMA / NW;                   // per wave: 4 (D = 128) or 2 (D = 64)
-  unsigned koff_l[DPW], voff_l[DPW];
-#pragma unroll
-  for (int i = 0; i < DPW; ++i) {
-    const int row = (wave * DPW + i) * RPD + d_row;
-    const int kc = d_pc ^ k_swz_w<D>(row);
-    const int vc = ((((d_pc >> 2) ^ v_swz_w<D>(row)) << 2) | (d_pc & 3));
-    koff_l[i] = (unsigned)(row * (int)p.k_rs + kc * 8) * 2u - (unsigned)(i * 1024);
-    voff_l[i] = (unsigned)(row * (int)p.v_rs + vc * 8) * 2u - (unsigned)(i * 1024);
-  }
   auto make_srd = [&](const void* base, int64_t row_stride) __attribute__((always_inline)) {
     const unsigned long long a = (unsigned long long)base;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
@@ -310,10 +327,18 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // accumulator registers for the whole block
   {
     const float cq = p.scale_log2;
+    // (all reads of a query block first: read -> convert -> write one fragment at a time exposes the LDS latency sixteen times)
+    u32x4 qraw[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int qbase = Q_OFF + (wave * 64 + qb * 32 + qi) * ROW_BYTES + ((hi ^ k_swz_w<D>(qi)) << 4);
+        qraw[qb][ks] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(qbase ^ (ks << 5));
+      }
     auto load_q = [&](auto qbc, auto ksc) __attribute__((always_inline)) {
       constexpr int qb = decltype(qbc)::value, ks = decltype(ksc)::value;
-      const int qbase = Q_OFF + (wave * 64 + qb * 32 + qi) * ROW_BYTES + ((hi ^ k_swz_w<D>(qi)) << 4);
-      const V8 raw = bitcast_u32x4<V8>(*(const u32x4 FA_LDS*)(unsigned long)(unsigned)(qbase ^ (ks << 5)));
+      const V8 raw = bitcast_u32x4<V8>(qraw[qb][ks]);
       V8 sc;
 #pragma unroll
       for (int j = 0; j < 8; ++j) sc[j] = (E)((float)raw[j] * cq);
@@ -337,9 +362,8 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   u32x4 qn_srd = null_srd;
   int qn_done = QDMA, qn_per_iter = QDMA;
   {
-    Blk nxt;
     q_in_lds = -1;
-    if (p.persist_total > 0 && decode(vb + (int)gridDim.x, round + 1, nxt)) {
+    if (nxt_id_ok && fill_blk(nxt)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the Q region have returned
       qn_srd = q_srd_of(nxt); qn_done = 0;
       qn_per_iter = n_tiles >= QDMA ? 1 : n_tiles >= QDMA / 2 ? 2 : n_tiles >= QDMA / 4 ? 4 : QDMA;
@@ -397,7 +421,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // into the (dead) score tuple itself, from which the chain then accumulates -- so the scores leave the matrix pipe masked
   // (s + (-inf) = -inf: exp2 gives 0, the row maximum ignores it) and the masked step is otherwise the plain step.  negm is only
   // read here: modifying it under a branch makes hipcc copy both tuples at every join (measured: 16 v_mov_b64 per plain step).
-  const bool two_sided = p.wl >= 0;
   auto masked_c = [&](int i, f32x16 (&s_nxt)[QB]) __attribute__((always_inline)) {
     const int k0 = key_base + 32 * i;
 #pragma unroll
@@ -478,7 +501,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     constexpr int QKG = 2 * KS, PVG = 4 * DB, NG = QKG + PVG;
     constexpr int KOFF = half * 32 * ROW_BYTES;                    // (+ the buffer parity carried by ka / va)
     constexpr int VOFF = 2 * TILE_BYTES + half * 32 * ROW_BYTES;
-    constexpr int AH = 2, RING = AH + 1;  // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
+    constexpr int AH = FA_W64_AH, RING = AH + 1;  // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
     constexpr int NF = KS + 2 * DB;       // fragment slots per step: KS K fragments, then 2*DB V fragments
     u32x4 kfr[RING];
     s16x4 vlo[RING], vhi[RING];
