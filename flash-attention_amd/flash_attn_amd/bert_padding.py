@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-__all__ = ["index_first_axis", "index_put_first_axis", "unpad_input", "pad_input"]
+__all__ = ["index_first_axis", "index_put_first_axis", "unpad_input", "unpad_input_for_concatenated_sequences", "pad_input"]
 
 
 def index_first_axis(x: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
@@ -39,6 +39,26 @@ def unpad_input(hidden_states: torch.Tensor, attention_mask: torch.Tensor, unuse
     cu_seqlens = F.pad(torch.cumsum(seqlens, dim=0, dtype=torch.int32), (1, 0))
     flat = hidden_states.reshape((-1,) + tuple(hidden_states.shape[2:]))
     return index_first_axis(flat, indices), indices, cu_seqlens, max_seqlen, seqused
+
+
+def unpad_input_for_concatenated_sequences(hidden_states: torch.Tensor, attention_mask_in_length: torch.Tensor):
+    """Several short samples concatenated inside one row of the padded batch (reference :131-201).
+
+    ``attention_mask_in_length`` (batch, seqlen) int: row b lists the lengths of the samples packed into row b, left-aligned and
+    zero-filled -- e.g. ``[2, 3, 0, 0, 0, 0]`` = a 2-token and a 3-token sample occupying the first 5 slots of a 6-slot row.  Every
+    listed sample becomes its own sequence of the varlen batch, so attention never crosses a sample boundary.
+    Returns (packed (total, ...), indices (total,), cu_seqlens int32 (n_samples+1,), max_seqlen_in_batch: int).
+    """
+    seqlen = attention_mask_in_length.shape[-1]
+    used = attention_mask_in_length.sum(dim=-1)                                         # occupied slots per row
+    slot = torch.arange(seqlen, device=used.device, dtype=used.dtype)
+    indices = torch.nonzero((slot[None, :] < used[:, None]).flatten(), as_tuple=False).flatten()
+    lengths = attention_mask_in_length.flatten()
+    lengths = lengths[torch.nonzero(lengths, as_tuple=False).flatten()]                 # the samples, in (row, position) order
+    max_seqlen = int(lengths.max().item()) if lengths.numel() else 0
+    cu_seqlens = F.pad(torch.cumsum(lengths, dim=0, dtype=torch.int32), (1, 0))
+    flat = hidden_states.reshape((-1,) + tuple(hidden_states.shape[2:]))
+    return index_first_axis(flat, indices), indices, cu_seqlens, max_seqlen
 
 
 def pad_input(hidden_states: torch.Tensor, indices: torch.Tensor, batch: int, seqlen: int) -> torch.Tensor:

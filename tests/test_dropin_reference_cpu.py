@@ -1,0 +1,59 @@
+"""The part of the literal drop-in a box WITHOUT a GPU can check: when the reference tree is readable (this build container; not the
+driver's GPU box), its Python package imports on top of the in-tree `flash_attn_2_cuda` and binds the five backend functions with the
+positional arities its call sites use (flash_attn/flash_attn_interface.py:13-23 import, :95-110 fwd, :181-205 varlen_fwd, :278-300 bwd,
+:381-410 varlen_bwd, :1595-1620 fwd_kvcache).  Runs in a subprocess: it re-points `flash_attn` in sys.modules."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "flash-attention_amd")
+
+_SCRIPT = r"""
+import importlib, os, re, sys
+root, pkg = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root); sys.path.insert(0, pkg)
+import flash_attn_2_cuda as ext
+assert os.path.dirname(ext.__file__) == pkg, ext.__file__
+fa = importlib.import_module("flash_attn")
+assert os.path.realpath(fa.__file__).startswith(os.path.realpath(root)), fa.__file__
+iface = importlib.import_module("flash_attn.flash_attn_interface")
+assert iface.flash_attn_gpu is ext, "the reference package did not bind the in-tree backend module"
+want = {"fwd": 13, "varlen_fwd": 21, "bwd": 19, "varlen_bwd": 24, "fwd_kvcache": 20}
+for name, n in want.items():
+    fn = getattr(ext, name)
+    sig = fn.__doc__.split("\n")[0]
+    inner = sig[sig.index("(") + 1: sig.rindex(") ->")]
+    params, depth, cur = [], 0, ""
+    for ch in inner:
+        depth += ch in "[(" ; depth -= ch in "])"
+        if ch == "," and depth == 0: params.append(cur); cur = ""
+        else: cur += ch
+    params.append(cur)
+    required = sum("=" not in p_ for p_ in params)
+    assert required <= n <= len(params), (name, required, len(params), n, sig)   # the reference's call passes n positional arguments
+for name in ("flash_attn_func", "flash_attn_varlen_func", "flash_attn_qkvpacked_func", "flash_attn_kvpacked_func",
+             "flash_attn_varlen_qkvpacked_func", "flash_attn_varlen_kvpacked_func", "flash_attn_with_kvcache"):
+    assert callable(getattr(fa, name)), name
+print("DROPIN_OK")
+"""
+
+
+def _reference_root():
+    for cand in (os.environ.get("FLASH_ATTN_REF"), "/root/reference", os.path.join(ROOT, "_ref_tmp")):
+        if cand and os.path.exists(os.path.join(cand, "flash_attn", "flash_attn_interface.py")):
+            return cand
+    return None
+
+
+def test_reference_package_binds_the_in_tree_backend_module():
+    root = _reference_root()
+    if root is None:
+        pytest.skip("reference flash_attn package not readable on this box (set FLASH_ATTN_REF)")
+    if not os.path.exists(os.path.join(PKG, "libfa_gfx950.so")):
+        subprocess.check_call([sys.executable, os.path.join(PKG, "build.py")])
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")   # never write __pycache__ into the read-only reference tree
+    r = subprocess.run([sys.executable, "-c", _SCRIPT, root, PKG], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "DROPIN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

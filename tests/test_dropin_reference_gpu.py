@@ -99,3 +99,44 @@ def test_reference_flash_attn_with_kvcache_on_our_backend(ref_flash_attn):
         o_ref, _ = orc.attention_fwd(q[b:b + 1], kk, vv, None, False)
         assert _close(out[b:b + 1], o_ref, 2e-2), b
         assert torch.equal(kc[b, n], kn[b, 0]) and torch.equal(vc[b, n], vn[b, 0])
+
+
+def test_reference_mha_modules_on_our_backend(ref_flash_attn):
+    """The reference's own attention modules (flash_attn/modules/mha.py:53-131 FlashSelfAttention -- packed QKV, fixed and cu_seqlens, dropout in
+    training -- and :133-225 FlashCrossAttention -- q + packed KV) imported from the reference tree, running on the in-tree backend module."""
+    from oracle import attention_oracle as orc
+    from flash_attn.modules.mha import FlashCrossAttention, FlashSelfAttention
+    torch.manual_seed(3)
+    B, S, H, D = 2, 257, 4, 64
+    qkv = torch.randn(B, S, 3, H, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    sa = FlashSelfAttention(causal=True, attention_dropout=0.0).cuda()
+    out = sa(qkv)
+    g = torch.randn_like(out)
+    (dqkv,) = torch.autograd.grad(out, qkv, g)
+    q, k, v = qkv.unbind(2)
+    o_ref, _ = orc.attention_fwd(q, k, v, None, True)
+    gr = orc.attention_bwd(g, q, k, v, None, None, None, True)
+    assert _close(out, o_ref, 2e-2)
+    for i in range(3):
+        assert _close(dqkv[:, :, i], gr[i], 6e-2), i
+    # cu_seqlens form
+    lens = [100, 1, 156]
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    qkv_p = torch.randn(sum(lens), 3, H, D, device="cuda", dtype=torch.bfloat16)
+    out_p = sa(qkv_p, cu_seqlens=cu, max_seqlen=max(lens))
+    o_ref, _ = orc.varlen_fwd(qkv_p[:, 0], qkv_p[:, 1], qkv_p[:, 2], cu.cpu().numpy(), cu.cpu().numpy(), None, True)
+    assert _close(out_p, o_ref, 2e-2)
+    # dropout in training mode runs (mask statistics are tested through our own interface, tests/test_dropout_gpu.py)
+    sa_d = FlashSelfAttention(causal=False, attention_dropout=0.2).cuda().train()
+    out_d = sa_d(qkv)
+    assert out_d.shape == out.shape and torch.isfinite(out_d.float()).all()
+    # cross attention: q (B,Sq,H,D) + kv (B,Sk,2,Hk,D)
+    ca = FlashCrossAttention(causal=False).cuda()
+    qx = torch.randn(B, 77, H, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    kv = torch.randn(B, 300, 2, H, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    ox = ca(qx, kv)
+    gx = torch.randn_like(ox)
+    dqx, dkv = torch.autograd.grad(ox, (qx, kv), gx)
+    o_ref, _ = orc.attention_fwd(qx, kv[:, :, 0], kv[:, :, 1], None, False)
+    gr = orc.attention_bwd(gx, qx, kv[:, :, 0], kv[:, :, 1], None, None, None, False)
+    assert _close(ox, o_ref, 2e-2) and _close(dqx, gr[0], 6e-2) and _close(dkv[:, :, 0], gr[1], 6e-2) and _close(dkv[:, :, 1], gr[2], 6e-2)

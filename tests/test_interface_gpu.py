@@ -217,3 +217,53 @@ print("threads ok")
 ''' % (root, os.path.join(root, "flash-attention_amd"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "threads ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("varlen", [False, True])
+@pytest.mark.parametrize("d", [64, 80, 59])
+def test_packed_backward_writes_one_packed_gradient(fi, varlen, d):
+    """The four packed entry points (reference FlashAttn{,Varlen}{QKV,KV}PackedFunc, flash_attn_interface.py:461-825): gradients equal those of
+    the unpacked call bit for bit, come back as ONE packed tensor (dq / dk / dv are views of it), and the backward allocates the packed
+    gradient and nothing of its size beside it -- no slice-backward temporaries (three zero-filled packed tensors + adds)."""
+    torch.manual_seed(5)
+    H, Hk = 4, 4
+    if varlen:
+        lens = [70, 1, 333, 128]
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+        qkv = torch.randn(sum(lens), 3, H, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+        call_p = lambda x: fi.flash_attn_varlen_qkvpacked_func(x, cu, max(lens), causal=True)
+        call_u = lambda q, k, v: fi.flash_attn_varlen_func(q, k, v, cu, cu, max(lens), max(lens), causal=True)
+        call_kv = lambda q, kv: fi.flash_attn_varlen_kvpacked_func(q, kv, cu, cu, max(lens), max(lens), causal=True)
+    else:
+        qkv = torch.randn(2, 300, 3, H, d, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+        call_p = lambda x: fi.flash_attn_qkvpacked_func(x, causal=True)
+        call_u = lambda q, k, v: fi.flash_attn_func(q, k, v, causal=True)
+        call_kv = lambda q, kv: fi.flash_attn_kvpacked_func(q, kv, causal=True)
+    out = call_p(qkv)
+    g = torch.randn_like(out)
+    (dqkv,) = torch.autograd.grad(out, qkv, g)
+    assert dqkv.shape == qkv.shape
+    q, k, v = (t.detach().clone().requires_grad_() for t in qkv.unbind(-3))
+    out_u = call_u(q, k, v)
+    dq, dk, dv = torch.autograd.grad(out_u, (q, k, v), g)
+    assert torch.equal(out, out_u)
+    for i, t in enumerate((dq, dk, dv)):
+        assert torch.equal(dqkv.select(-3, i), t)
+    # kv-packed: dq separate, dkv one tensor
+    qs = qkv.detach().select(-3, 0).clone().requires_grad_()
+    kv = qkv.detach()[..., 1:, :, :].clone().requires_grad_()
+    out_kv = call_kv(qs, kv)
+    dq2, dkv = torch.autograd.grad(out_kv, (qs, kv), g)
+    assert torch.equal(out_kv, out) and torch.equal(dq2, dq) and torch.equal(dkv.select(-3, 0), dk) and torch.equal(dkv.select(-3, 1), dv)
+    # memory: the backward's peak above its starting point is the packed gradient (+ softmax_d, + padded copies only for head dims that
+    # are not a built size) -- far below the 3 extra packed tensors of the slice-backward path
+    if d == 64:
+        out = call_p(qkv)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        (dqkv,) = torch.autograd.grad(out, qkv, g)
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base
+        packed_bytes = qkv.numel() * qkv.element_size()
+        assert peak < 1.5 * packed_bytes + (1 << 20), (peak, packed_bytes)
