@@ -340,9 +340,12 @@ int bwd_dq_schedule(const FaBwdParams* a) {
 }
 
 // dK/dV schedule (fa_launch.h Knobs::bwd_dkdv)
+#ifndef FA_EXPERIMENTS
+#define FA_EXPERIMENTS 0   // build.py --experiments: the 64-keys-per-wave dK/dV kernel (FA_BWD_DKDV=64) and the dS-spill backward (FA_BWD_MODE=2)
+#endif                     // -- both measured and not faster (profiles/r02_bwd_schedules.txt) -- are built and dispatchable
 int bwd_dkdv_schedule(const FaBwdParams* a) {
   const int knob = fa::knobs().bwd_dkdv;
-  if (knob == 8 || knob == 64) return knob;
+  if (FA_EXPERIMENTS && (knob == 8 || knob == 64)) return knob;
   return 8;
 }
 
@@ -403,7 +406,7 @@ void bwd_list_entries(const FaBwdParams* a, int64_t& q_entries, int64_t& k_entri
 // and read once (4.3 GB at config 3), which costs the HBM about what the two saved contractions cost the matrix pipe
 // (profiles/r02_bwd_5_vs_7_contractions.txt) -- and it needs O(S^2) scratch, so the default keeps the scratch-free 7.
 int64_t bwd_ds_bytes(const FaBwdParams* a) {
-  if (fa::knobs().bwd_mode != 2 || a->cu_seqlens_q || a->cu_seqlens_k || (a->d != 128 && a->d != 64)) return 0;
+  if (!FA_EXPERIMENTS || fa::knobs().bwd_mode != 2 || a->cu_seqlens_q || a->cu_seqlens_k || (a->d != 128 && a->d != 64)) return 0;
   if (a->seqlen_q <= 0 || a->seqlen_k <= 0) return 0;
   const int64_t bytes = (int64_t)a->b * a->h * ((a->seqlen_q + 31) / 32) * ((a->seqlen_k + 31) / 32) * 2048;
   return bytes > ((int64_t)fa::knobs().bwd_ds_cap_mb << 20) ? 0 : bytes;
@@ -453,7 +456,11 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   int rc = fa::launch_bwd_delta(k, bf, a->d, s);
   if (rc == 0) {
     int dkdv_nw = 64;
+#if FA_EXPERIMENTS
     rc = bwd_dkdv_schedule(a) == 64 ? fa::launch_bwd_dkdv_w64(k, bf, a->d, s) : -2;
+#else
+    rc = -2;
+#endif
     if (rc == -2) { dkdv_nw = a->d > 128 ? 4 : 8; rc = fa::launch_bwd_dkdv(k, bf, a->d, s); }
     fa::last_schedule().bwd_dkdv_nw = dkdv_nw;
   }

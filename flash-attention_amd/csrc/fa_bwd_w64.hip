@@ -542,6 +542,10 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   });
 }
 
+#ifndef FA_EXPERIMENTS
+#define FA_EXPERIMENTS 0   // build.py --experiments: also build the measured-and-not-faster variants (dS-spill dQ kernel here; fa_bwd_dkdv64.hip)
+#endif
+#if FA_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------------------------------
 // dQ from spilled dS (BwdK::ds_ws): dQ^T[d][query] = sum_key K^T[d][key] . dS^T[key][query] -- ONE contraction instead of the
 // three of the recomputing kernels.  8 waves x 32 query rows; K tiles (64 keys) shared through LDS, each wave's dS
@@ -702,6 +706,10 @@ int launch_bwd_dq_ds(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   }
   return -2;
 }
+
+#else
+int launch_bwd_dq_ds(const BwdK&, int, int, hipStream_t) { return -2; }   // not in the default build
+#endif
 
 template <typename E, int D>
 static int launch_bwd_dq_w64_t(const BwdK& p, hipStream_t stream) {

@@ -54,11 +54,12 @@ def ref_fwd_bwd(q, k, v, do, causal, window, upcast):
 
 def lse_tolerance(sched, dtype, lse_abs_max=0.0):
     """LSE is not pinned by the reference's tests; ours: 2e-3 absolute -- except bf16 through the 64-rows-per-wave kernel,
-    which multiplies Q by softmax_scale*log2(e) ONCE and rounds it to bf16: 2^-9 RELATIVE on every score, the same size as
-    the bf16 rounding the PyTorch baseline applies to q*scale.  LSE of a row dominated by few keys inherits that relative
-    error: <= ~6e-3 for N(0,1) data, 2^-8 |LSE| in general (FA_STRICT=1 keeps the exact-scale kernels)."""
+    which multiplies Q by softmax_scale*log2(e) ONCE and rounds it to bf16: 2^-9 RELATIVE on every element of q, the same size as
+    the bf16 rounding the PyTorch baseline applies to q*scale.  Measured at the BASELINE shapes (profiles/r03_numerics_default_vs_strict.txt):
+    max 3.9e-3 / 4.4e-3 at configs 3 / 4 against 8.8e-3 / 6.5e-3 for PyTorch computing in bf16 and 1.9e-6 for FA_STRICT=1; the bound is
+    6e-3 for N(0,1) data (2^-9 |LSE| when LSE itself is large: spiked keys)."""
     if sched["fwd_kernel"] == 3 and dtype == torch.bfloat16:
-        return max(1e-2, 2.0 ** -8 * lse_abs_max)
+        return max(6e-3, 2.0 ** -9 * lse_abs_max)
     return 2e-3
 
 

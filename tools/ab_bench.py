@@ -20,6 +20,9 @@ def main():
     variants = sys.argv[1].split(",") if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else ["4", "8", "16"]
     if "--sweep-shapes" in sys.argv:
         shapes_override = [(16384 // S, S, 16, 128, c) for c in (False, True) for S in (512, 1024, 2048, 4096, 8192)] + [(8, 2048, 32, 128, True), (4, 4096, 32, 128, True), (2, 8192, 32, 128, True)]
+    elif "--d64-shapes" in sys.argv:
+        shapes_override = [(8, 2048, 16, 64, False), (32, 512, 16, 64, False), (16, 1024, 16, 64, False), (4, 4096, 16, 64, False), (2, 8192, 16, 64, False),
+                           (1, 16384, 16, 64, False), (16, 1024, 16, 64, True), (8, 2048, 16, 64, True), (4, 4096, 32, 64, True), (2, 8192, 32, 64, True), (1, 16384, 16, 64, True)]
     else:
         shapes_override = None
     shapes = [(4, 4096, 32, 128, True), (4, 4096, 32, 128, False), (1, 16384, 16, 128, True), (1, 16384, 16, 128, False),
