@@ -81,9 +81,10 @@ namespace {
 // variants of the 64 / 128 / 256 kernels (fa_fwd.hip: same LDS pitch, fewer k-steps and output blocks) on the lock-step schedules.
 bool head_dim_trimmed(int d) { return d == 32 || d == 96 || d == 192; }
 bool head_dim_native(int d) { return d == 64 || d == 128 || d == 256 || head_dim_trimmed(d); }
-// kernel head dim a forward call runs on: the next built size.  A head dim between the built sizes (a multiple of 8) runs the forward
-// with a run-time column bound (FwdK::d_chunks: the chunks behind the head dim read as zeros, lock-step kernel); the backward has
-// no such bound -- the binders pad training tensors to a built size, and only the KV-cache path sends in-between sizes.
+// kernel head dim a call runs on: the next built size.  A head dim between the built sizes (a multiple of 8: 40, 72, 80, 104, 160, 224, ..)
+// runs with a run-time column bound (FwdK / BwdK::d_chunks: the chunks behind the head dim read as zeros and are never stored; lock-step
+// forward, 4-wave dQ kernel, dK/dV kernel, delta pre-pass) -- the reference rounds internally and masks columns the same way
+// (flash_api.cpp:458,872, Is_even_K); no padded copies anywhere.
 int head_dim_kernel(int d) { for (int n : {32, 64, 96, 128, 192}) if (d <= n) return n; return 256; }
 int head_dim_pitch(int d) { return d <= 64 ? 64 : d <= 128 ? 128 : 256; }  // row pitch of tiles and of split-KV partial rows
 
@@ -161,7 +162,8 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
   //   steady state is 15-20 % faster than the pipelined kernels (1.19-1.26 vs 1.02-1.05 PFLOP/s at S = 16k); shorter loops
   //   stay on the 4-wave pipelined kernel (Q fragments in registers, two workgroups per CU hide each other's prologue /
   //   epilogue).  FA_STRICT keeps the pipelined kernels (fp32 scaling of every score).  D = 64 has half the MFMA work per
-  //   softmax element and prefers 4-wave pipelined workgroups throughout.
+  //   softmax element: the 64-rows-per-wave kernel wins from 64 key tiles on average (non-causal S >= 4096, causal S >= 8192;
+  //   profiles/r03_fwd_schedules.txt), the 4-wave pipelined kernel below.
   //   K/V views whose key range spans >= 4 GiB (w64_span_ok) fall back from the 64-rows-per-wave kernel to the pipelined one,
   //   which addresses tile by tile.
   int nw = fa::knobs().fwd_nw;
@@ -171,6 +173,7 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
     const long span = (wl >= 0) ? std::min<long>(avg_keys, wl + (wr >= 0 ? wr : a->seqlen_k) + 256) : avg_keys;
     const long tiles = span / 64;
     if (a->d == 128) nw = (tiles >= 32 && a->seqlen_q >= 512) ? (fa::knobs().strict ? (tiles >= 48 ? 38 : 34) : 64) : (a->seqlen_q > 128 ? 34 : 4);
+    else if (a->d == 64) nw = (tiles >= 64 && a->seqlen_q >= 512 && !fa::knobs().strict) ? 64 : (a->seqlen_q > 128 ? 34 : 4);   // r03_fwd_schedules.txt: +6..18 % from 64 tiles
     else nw = (a->seqlen_q > 128) ? 34 : 4;
   }
   if (nw == 64 && !w64_span_ok(a)) nw = 38;
@@ -200,8 +203,6 @@ int check_common(int b, int h, int h_k, int d, int dtype, float softcap, bool fo
     return fail(FA_ERR_INVALID_ARGUMENT, "head dimension must be a multiple of 8 and at most 256");
   if (dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_BF16)
     return fail(FA_ERR_INVALID_ARGUMENT, "FlashAttention only supports fp16 and bf16 data type");
-  if (!head_dim_native(d) && !forward)
-    return fail(FA_ERR_UNSUPPORTED, "libfa_gfx950: head dimension %d is not built natively (32, 64, 96, 128, 192, 256); pad to the next one on the host", d);
   if (softcap < 0.f) return fail(FA_ERR_INVALID_ARGUMENT, "softcap must be non-negative");
   return FA_OK;
 }
@@ -330,9 +331,9 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
 // kernel wins from ~2k keys at head dim 128 (config 3: dQ 955 vs 997 us, S = 16k non-causal 1383 vs 1584 us) and loses on
 // short sequences, where its 256-row blocks leave CUs idle.
 int bwd_dq_schedule(const FaBwdParams* a) {
-  // trimmed head dims (32 / 96 / 192) and head dim 256 only have the 4-wave, 128-row dQ kernel (fa_bwd.hip: launch_dq_f): the
-  // block size fill_bwd / bwd_list_entries derive from the schedule has to be that kernel's, whatever the knob says
-  if (head_dim_trimmed(a->d) || a->d > 128) return 4;
+  // trimmed head dims (32 / 96 / 192), head dims between the built sizes and head dim 256 only have the 4-wave, 128-row dQ kernel
+  // (fa_bwd.hip: launch_dq_f): the block size fill_bwd / bwd_list_entries derive from the schedule has to be that kernel's, whatever the knob says
+  if (head_dim_trimmed(head_dim_kernel(a->d)) || !head_dim_native(a->d) || a->d > 128) return 4;
   const int knob = fa::knobs().bwd_dq_nw;
   if (knob == 4 || knob == 8 || knob == 64) return knob;
   const bool plain = a->softcap <= 0.f && !a->alibi_slopes && a->p_dropout <= 0.f;
@@ -382,6 +383,7 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   if (int rc = check_dropout(a->p_dropout, a->rng_state)) return rc;
   fill_dropout(k, a->p_dropout, a->rng_state, a->seqlen_k);
   k.dq_nw = bwd_dq_schedule(a);
+  if (!head_dim_native(a->d)) k.d_chunks = a->d / 8;   // run-time column bound of the next built size's kernels
   const int bwd_bm = a->d > 128 ? 128 : fa::bwd_block_m(k.dq_nw);
   k.nmb = (a->seqlen_q + bwd_bm - 1) / bwd_bm;
   k.nnb = (a->seqlen_k + fa::bwd_block_n(a->d) - 1) / fa::bwd_block_n(a->d);
@@ -453,7 +455,8 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   // Nothing to differentiate: the caller's dq/dk/dv hold no rows (Sq == 0 / Sk == 0 with fixed
   // shapes are handled by the binder, which zero-fills as flash_api.cpp:992-999 does).
   if (a->seqlen_q == 0 || a->seqlen_k == 0 || a->total_q == 0 || a->total_k == 0) return FA_OK;
-  int rc = fa::launch_bwd_delta(k, bf, a->d, s);
+  const int dk_ = head_dim_kernel(a->d);   // kernel head dim (!= a->d: BwdK::d_chunks)
+  int rc = fa::launch_bwd_delta(k, bf, dk_, s);
   if (rc == 0) {
     int dkdv_nw = 64;
 #if FA_EXPERIMENTS
@@ -461,10 +464,10 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
 #else
     rc = -2;
 #endif
-    if (rc == -2) { dkdv_nw = a->d > 128 ? 4 : 8; rc = fa::launch_bwd_dkdv(k, bf, a->d, s); }
+    if (rc == -2) { dkdv_nw = a->d > 128 ? 4 : 8; rc = fa::launch_bwd_dkdv(k, bf, dk_, s); }
     fa::last_schedule().bwd_dkdv_nw = dkdv_nw;
   }
-  if (rc == 0) rc = k.ds_ws ? fa::launch_bwd_dq_ds(k, bf, a->d, s) : fa::launch_bwd_dq(k, bf, a->d, s);
+  if (rc == 0) rc = k.ds_ws ? fa::launch_bwd_dq_ds(k, bf, a->d, s) : fa::launch_bwd_dq(k, bf, dk_, s);
   if (rc == 0) { fa::last_schedule().bwd_spill = k.ds_ws != nullptr; fa::last_schedule().bwd_list = (k.q_list != nullptr) + 2 * (k.k_list != nullptr); }
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no backward kernel for head dim %d", a->d);
   if (rc != 0) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));

@@ -59,6 +59,8 @@
 namespace fa {
 
 constexpr float kLog2e = 1.4426950408889634f;
+// 16 bytes of zeros in global memory: where a load / DMA lane fetches from when its chunk lies behind the head dim (BwdK::d_chunks)
+static __device__ const uint4 fa_zero_chunk_bwd = {0u, 0u, 0u, 0u};
 
 // ------------------------------------------------------------------------------------------------
 // delta[b,h,i] = sum_d dO[i,d] * O[i,d]   (reference flash_bwd_preprocess_kernel.h:24-51, dropout off)
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
   const int row = blockIdx.x * ROWS + threadIdx.x / LPR;
   const int c = threadIdx.x % LPR;
   float acc = 0.f;
-  if (row < sq && c < DV / 8) {
+  if (row < sq && c < (p.d_chunks > 0 ? p.d_chunks : DV / 8)) {
     const E* dop = (const E*)p.dout + do_boff + (row0 + row) * p.do_rs + (int64_t)h * p.do_hs + c * 8;
     const E* op = (const E*)p.o + o_boff + (row0 + row) * p.o_rs + (int64_t)h * p.o_hs + c * 8;
     const V8 a = bitcast_u32x4<V8>(*reinterpret_cast<const u32x4*>(dop));
@@ -180,12 +182,17 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   const int my_key = wk0 + ki;
   const bool key_valid = my_key < sk;
 
+  // head dims between the built sizes (BwdK::d_chunks): the chunks behind the head dim read as zeros (K / V by predicate, the streamed
+  // Q / dO tiles from a page of zeros) and are not stored
+  const int cvr = p.d_chunks > 0 ? p.d_chunks : CV;
+  const bool bounded = cvr < CV;
+  const E* zsrc = (const E*)&fa_zero_chunk_bwd;
   // K fragments (B operand of S = Q.K^T): lane = key, 8 consecutive d per k-step
   V8 kf[KS];
   {
     const E* krow = kp + (int64_t)my_key * p.k_rs + 8 * hi;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf[ks] = bitcast_u32x4<V8>(ld_global_16B(krow + 16 * ks, key_valid));
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = bitcast_u32x4<V8>(ld_global_16B(krow + 16 * ks, key_valid && 2 * ks + hi < cvr));
     if constexpr (PRE) {  // K <- K * softmax_scale * log2(e), rounded once to the input dtype (see PRE above)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
@@ -200,7 +207,7 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
     for (int i = 0; i < LDV; ++i) {
       const int idx = tid + i * NT;
       const int row = idx / CPR, ch = idx % CPR;
-      const u32x4 x = ld_global_16B(vp + (int64_t)(n0 + row) * p.v_rs + ch * 8, n0 + row < sk && (DV == D || ch < CV));
+      const u32x4 x = ld_global_16B(vp + (int64_t)(n0 + row) * p.v_rs + ch * 8, n0 + row < sk && ch < cvr);
       *(u32x4 FA_LDS*)(lds + OFF_V + tile_off<D>(row, ch)) = x;
     }
   }
@@ -243,6 +250,7 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
       if (DV < D) c = c < CV ? c : 0;  // columns past the head dimension are never read from LDS: fetch something that exists
       const E* qsrc = qp + (int64_t)grow * p.q_rs + c * 8;
       const E* dsrc = dop + (int64_t)grow * p.do_rs + c * 8;
+      if (bounded && c >= cvr) { qsrc = zsrc; dsrc = zsrc; }
       lds_dma_16B(qsrc, lds + OFF_Q + buf * QT_BYTES + idx * 1024);
       lds_dma_16B(dsrc, lds + OFF_DO + buf * QT_BYTES + idx * 1024);
     }
@@ -560,8 +568,8 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   E* dktile = (E*)p.dk + dk_boff + (k_row0 + wk0) * p.dk_rs + (int64_t)hk * p.dk_hs;
   E* dvtile = (E*)p.dv + dv_boff + (k_row0 + wk0) * p.dv_rs + (int64_t)hk * p.dv_hs;
   char FA_LDS* stage = lds + wave * 32 * (ROW_BYTES + 16);
-  store_tile_via_lds<E, D, DV>(stage, dk_acc, p.scale, dktile, p.dk_rs, sk - wk0, lane);
-  store_tile_via_lds<E, D, DV>(stage, dv_acc, dv_scale, dvtile, p.dv_rs, sk - wk0, lane);
+  store_tile_via_lds<E, D, DV>(stage, dk_acc, p.scale, dktile, p.dk_rs, sk - wk0, lane, cvr);
+  store_tile_via_lds<E, D, DV>(stage, dv_acc, dv_scale, dvtile, p.dv_rs, sk - wk0, lane, cvr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -640,6 +648,9 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   const bool drop = F_DROP && (FEAT != FEAT_ALL || p.rng != nullptr);
   const uint32_t drop_key = drop ? drop_bh_key(p.rng, b * p.h + h) : 0u;
 
+  const int cvr = p.d_chunks > 0 ? p.d_chunks : CV;   // head dims between the built sizes: see the dK/dV kernel
+  const bool bounded = cvr < CV;
+  const E* zsrc = (const E*)&fa_zero_chunk_bwd;
   // Q and dO fragments (B operands), LSE and delta (lane-local scalars).  The fragments are staged through the (still
   // idle) LDS by coalesced DMA -- each wave its own 32 rows -- instead of 16-byte loads at row stride.
   V8 qf[KS], dof[KS];
@@ -656,8 +667,9 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
         int c = (lane % CPR) ^ swz16<D>(row);
         if (DV < D) c = c < CV ? c : 0;
         const int grow = min(m0 + row, sq - 1);
-        const E* src = which ? (dosrc + (int64_t)grow * p.do_rs) : (qsrc + (int64_t)grow * p.q_rs);
-        lds_dma_16B(src + c * 8, lds + (wave * QDPW + i) * 1024);
+        const E* src = (which ? (dosrc + (int64_t)grow * p.do_rs) : (qsrc + (int64_t)grow * p.q_rs)) + c * 8;
+        if (bounded && c >= cvr) src = zsrc;
+        lds_dma_16B(src, lds + (wave * QDPW + i) * 1024);
       }
       lds_dma_wait_all();
 #pragma unroll
@@ -687,8 +699,11 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
       int c = (lane % CPR) ^ swz16<D>(row);
       if (DV < D) c = c < CV ? c : 0;
       const int key = min(n * BN + row, sk - 1);
-      lds_dma_16B(kp + (int64_t)key * p.k_rs + c * 8, lds + buf * TILE_BYTES + idx * 1024);
-      lds_dma_16B(vp + (int64_t)key * p.v_rs + c * 8, lds + (2 + buf) * TILE_BYTES + idx * 1024);
+      const E* ks_ = kp + (int64_t)key * p.k_rs + c * 8;
+      const E* vs_ = vp + (int64_t)key * p.v_rs + c * 8;
+      if (bounded && c >= cvr) { ks_ = zsrc; vs_ = zsrc; }
+      lds_dma_16B(ks_, lds + buf * TILE_BYTES + idx * 1024);
+      lds_dma_16B(vs_, lds + (2 + buf) * TILE_BYTES + idx * 1024);
     }
   };
 
@@ -838,7 +853,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   if (!wave_valid) return;
   // dQ tile through the freed K/V buffers: whole-row stores (fa_device.h store_tile_via_lds)
   E* dqtile = (E*)p.dq + dq_boff + (q_row0 + w_row0) * p.dq_rs + (int64_t)h * p.dq_hs;
-  store_tile_via_lds<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), dq_acc, p.scale, dqtile, p.dq_rs, sq - w_row0, lane);
+  store_tile_via_lds<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), dq_acc, p.scale, dqtile, p.dq_rs, sq - w_row0, lane, cvr);
 }
 
 // ------------------------------------------------------------------------------------------------

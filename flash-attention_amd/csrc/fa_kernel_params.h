@@ -101,6 +101,9 @@ struct BwdK {
   // input dtype) here and the dQ pass is one contraction dS.K; NULL = the dQ kernel recomputes S, dP and dS (7 contractions)
   void* ds_ws;               // [b][h][ds_nq32][ds_nk32][2 KB]
   int32_t ds_nq32, ds_nk32;  // 32-row / 32-key blocks per sequence
+  int32_t d_chunks;          // > 0 => only the first d_chunks 16-byte chunks of a row exist in memory (head dim = 8 * d_chunks < the kernels' DV, a head
+                             // dim between the built sizes): the chunks behind them are read as zeros and never stored (as FwdK::d_chunks); the
+                             // 4-wave dQ kernel, the dK/dV kernel and the delta pre-pass take it
   int32_t dq_nw;             // dQ schedule: 4 / 8 waves x 32 rows, 64 = 4 waves x 64 rows (nmb and the query work list are sized for it)
 };
 

@@ -37,12 +37,12 @@ int dtype_code(const Tensor& q) {
   return q.dtype() == at::kBFloat16 ? FA_DTYPE_BF16 : FA_DTYPE_FP16;
 }
 
-// next head dim with its own kernels (the reference's set, static_switch.h:92-110): tensors whose head dim is one of these go to
-// the kernels as they are, no padded copies
+// Head dim the tensors go to the kernels with: their own.  Every multiple of 8 up to 256 is taken as it is -- the six built sizes directly,
+// the sizes in between through the kernels' run-time column bound (FaFwdParams / FaBwdParams::d, fa_api.cpp: head_dim_kernel) -- so the
+// padded-copy path below (pad_d) is dead for every head dim this module accepts; it stays for a library built without that bound.
 int native_head_dim(int64_t d) {
   TORCH_CHECK(d <= 256, "FlashAttention only supports head dimension at most 256");
-  for (int n : {32, 64, 96, 128, 192}) if (d <= n) return n;
-  return 256;
+  return (int)d;
 }
 
 Tensor pad_d(const Tensor& x, int64_t d_to) {

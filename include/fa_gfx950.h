@@ -28,6 +28,10 @@
  *     rows without any visible key give out = 0, lse = +inf (reference softmax.h:179-180);
  *   - window_left / window_right < 0 mean unbounded; is_causal forces window_right = 0; masks are
  *     aligned to the bottom-right corner (reference flash_attn_interface.py:1175-1189);
+ *   - head dim d: any multiple of 8 up to 256, forward and backward.  Kernels are built for 32 / 64 / 96 / 128 / 192 / 256 (the reference's
+ *     set, static_switch.h:92-110); a size in between runs the next built size's kernels with a run-time column bound: the 16-byte chunks
+ *     behind d are read as zeros and never stored, so q / k / v / out / gradients keep their own row pitch -- no padded copies (the reference
+ *     rounds internally the same way, flash_api.cpp:458,872);
  *   - return value 0 = enqueued; negative = FA_ERR_* (message via fa_last_error()).
  */
 #ifndef FA_GFX950_H_

@@ -57,9 +57,11 @@ def test_cabi_rejects_bad_arguments_without_touching_the_gpu(built):
     assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"non-NULL" in lib.fa_last_error()
     a.d = 60
     assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"multiple of 8" in lib.fa_last_error()
-    g = _cabi.FaBwdParams()   # the backward is built for 32 / 64 / 96 / 128 / 192 / 256 only
+    g = _cabi.FaBwdParams()   # the backward takes any multiple of 8 too (run-time column bound of the next built size's kernels)
     g.b, g.h, g.h_k, g.d, g.dtype = 1, 2, 1, 72, _cabi.FA_DTYPE_BF16
-    assert lib.fa_bwd(ctypes.byref(g), None) == _cabi.FA_ERR_UNSUPPORTED and b"72" in lib.fa_last_error()
+    assert lib.fa_bwd(ctypes.byref(g), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"non-NULL" in lib.fa_last_error()
+    g.d = 260
+    assert lib.fa_bwd(ctypes.byref(g), None) == _cabi.FA_ERR_INVALID_ARGUMENT and b"multiple of 8" in lib.fa_last_error()
     a.d, a.dtype = 128, 7
     assert lib.fa_fwd(ctypes.byref(a), None) == _cabi.FA_ERR_INVALID_ARGUMENT
     a.dtype = _cabi.FA_DTYPE_FP16

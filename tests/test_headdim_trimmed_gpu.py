@@ -261,3 +261,74 @@ def test_kvcache_head_dims_between_the_built_sizes(binder, d, sq, causal, num_sp
         assert torch.isfinite(out[b]).all()
         assert max_abs(out[b:b + 1].float().cpu(), torch.from_numpy(o_ref).float()) < 2e-2
         assert max_abs(lse[b:b + 1].cpu(), torch.from_numpy(l_ref).float()) < 2e-3
+
+
+BETWEEN = [40, 72, 80, 104, 160, 224]
+
+
+@pytest.mark.parametrize("d", BETWEEN)
+@pytest.mark.parametrize("mode", ["full", "causal", "local"])
+def test_training_head_dims_between_the_built_sizes_without_copies(be, d, mode):
+    """Head dims between the built sizes TRAIN without padded copies (round 3): the next built size's kernels run with a run-time column bound
+    (FwdK / BwdK::d_chunks) in the forward, the delta pre-pass, the dK/dV kernel and the 4-wave dQ kernel -- the reference rounds internally
+    the same way (flash_api.cpp:458,872; Is_even_K).  Inputs are strided views with NaN right behind every head's d columns, the gradients
+    are written into NaN-guarded buffers: a kernel that read a column >= d into its arithmetic, or stored one, would show it; results equal
+    those on contiguous tensors bit for bit and meet the 2x / 3x rule against fp32."""
+    import flash_attn_2_cuda as ext
+    torch.manual_seed(3)
+    B, sq, sk, h, hk = 2, 200, 333, 4, 2
+    dtype = torch.bfloat16
+    causal = mode == "causal"
+    window = (37, 50) if mode == "local" else (-1, -1)
+    _, q = _guarded((B, sq, h, d), d, dtype)
+    _, k = _guarded((B, sk, hk, d), d, dtype)
+    _, v = _guarded((B, sk, hk, d), d, dtype)
+    _, do = _guarded((B, sq, h, d), d, dtype)
+    scale = d ** -0.5
+    ob, out = _guarded((B, sq, h, d), d, dtype)
+    out_r, lse = ext.fwd(q, k, v, out, None, 0.0, scale, causal, window[0], window[1], 0.0, False, None)[:2]
+    assert out_r.data_ptr() == out.data_ptr() and torch.isfinite(out).all() and torch.isnan(ob[..., d:]).all()
+    oc, lc = ext.fwd(q.contiguous(), k.contiguous(), v.contiguous(), None, None, 0.0, scale, causal, window[0], window[1], 0.0, False, None)[:2]
+    assert torch.equal(out, oc) and torch.equal(lse, lc)
+    dqb, dq = _guarded((B, sq, h, d), d, dtype)
+    dkb, dk = _guarded((B, sk, hk, d), d, dtype)
+    dvb, dv = _guarded((B, sk, hk, d), d, dtype)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base_mem = torch.cuda.memory_allocated()
+    ext.bwd(do, q, k, v, out, lse, dq, dk, dv, None, 0.0, scale, causal, window[0], window[1], 0.0, False, None, None)
+    torch.cuda.synchronize()
+    # no padded copies of dout / q / k / v / out and no padded gradient buffers: the call allocates softmax_d (+ nothing of tensor size)
+    assert torch.cuda.max_memory_allocated() - base_mem < q.numel() * 2 // 2, torch.cuda.max_memory_allocated() - base_mem
+    for base, view in ((dqb, dq), (dkb, dk), (dvb, dv)):
+        assert torch.isfinite(view).all()
+        assert torch.isnan(base[..., d:]).all()   # nothing was stored past the head dim
+    c = ext.bwd(do.contiguous(), q.contiguous(), k.contiguous(), v.contiguous(), out.contiguous(), lse, None, None, None, None, 0.0, scale, causal,
+                window[0], window[1], 0.0, False, None, None)
+    assert torch.equal(dq, c[0]) and torch.equal(dk, c[1]) and torch.equal(dv, c[2])
+    _check(out.contiguous(), lse, (dq.contiguous(), dk.contiguous(), dv.contiguous()), q.contiguous(), k.contiguous(), v.contiguous(), do.contiguous(), causal, window)
+
+
+@pytest.mark.parametrize("d", [40, 160])
+def test_between_head_dims_varlen_and_features(be, d):
+    """Same head dims through the varlen entry points with softcap + ALiBi + dropout replay (the run-time-checked all-features kernels)."""
+    from oracle import attention_oracle as orc
+    torch.manual_seed(4)
+    H, Hk = 4, 2
+    lens_q, lens_k = [70, 1, 200, 33], [90, 64, 200, 257]
+    cq = torch.tensor([0] + list(np.cumsum(lens_q)), dtype=torch.int32, device="cuda")
+    ck = torch.tensor([0] + list(np.cumsum(lens_k)), dtype=torch.int32, device="cuda")
+    q = torch.randn(sum(lens_q), H, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(sum(lens_k), Hk, d, device="cuda", dtype=torch.bfloat16)
+    v, do = torch.randn_like(k), torch.randn_like(q)
+    scale = d ** -0.5
+    alibi = torch.rand(H, device="cuda") * 0.3
+    out, lse = be.varlen_fwd(q, k, v, None, cq, ck, None, None, None, alibi, max(lens_q), max(lens_k), 0.0, scale, False, True, -1, -1, 15.0,
+                             False, None)[:2]
+    dq, dk, dv, _ = be.varlen_bwd(do, q, k, v, out, lse, None, None, None, cq, ck, alibi, max(lens_q), max(lens_k), 0.0, scale, False, True,
+                                  -1, -1, 15.0, False, None, None)
+    o_ref, _ = orc.varlen_fwd(q, k, v, cq.cpu().numpy(), ck.cpu().numpy(), scale, True, (-1, -1), 15.0, alibi.cpu().numpy())
+    g_ref = orc.varlen_bwd(do, q, k, v, cq.cpu().numpy(), ck.cpu().numpy(), scale, True, (-1, -1), 15.0, alibi.cpu().numpy())
+    assert float(np.abs(out.float().cpu().numpy() - o_ref).max()) < 2e-2
+    for got, ref in zip((dq, dk, dv), g_ref[:3]):
+        assert float(np.abs(got.float().cpu().numpy() - ref).max()) < 6e-2
