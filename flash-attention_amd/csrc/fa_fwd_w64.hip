@@ -219,7 +219,8 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   const bool blk_ok = cur_ok && fill_blk(blk);
   nxt.b = 0; nxt.h = 0; nxt.m_block = 0;
   const bool nxt_id_ok = p.persist_total > 0 && decode_id(vb + (int)gridDim.x, round + 1, nxt);
-  cur_id = nxt; cur_ok = nxt_id_ok;
+  cur_id.b = __builtin_amdgcn_readfirstlane(nxt.b); cur_id.h = __builtin_amdgcn_readfirstlane(nxt.h); cur_id.m_block = __builtin_amdgcn_readfirstlane(nxt.m_block);
+  cur_ok = nxt_id_ok;   // (scalar on purpose: carried in vector registers the three values end up in scratch)
   if (!blk_ok) continue;   // (uniform over the workgroup: no barrier is skipped by part of it)
   const int b = blk.b, h = blk.h, m_block = blk.m_block, sq = blk.sq, sk = blk.sk;
   const int hk = h / p.hk_ratio;
