@@ -18,6 +18,18 @@
 // Workgroup = 4 waves x 64 rows = 256 query rows; registers allow one workgroup per CU, so LDS is spent freely:
 // K/V double buffers (64 KB) + the staged Q block (64 KB).  K/V tiles arrive by LDS-DMA through a buffer descriptor
 // (buffer_load_dwordx4 ... lds: one M0 write per four 1-KiB pieces, immediate offsets walk both LDS and memory).
+//
+// Round 3: ONE code path.  With one wave per SIMD nothing overlaps a wave's once-per-block code, which runs at ~5 clocks per instruction,
+// and round 2's kernel had a lot of it (241 KB: four copies of the hand-placed iteration, compiler-ordered "generic" steps for the pipeline
+// fill / drain, masked step variants, twelve copies of the cold rescale code; per block 23k clocks of prologue, 10-17k for iteration 0,
+// 5.3k instead of 3.2k for every iteration with a masked or draining wave -- profiles/r03_fwd_w64_stamps.txt).  Now (50 KB):
+//   * one iteration body = two hand-placed steps, run-time K/V buffer parity carried by the LDS read bases (toggled per iteration);
+//   * the same body fills and drains the pipeline: chains that score no real key read a zero-filled tile (a buffer descriptor of zero
+//     records "loads" zeros into LDS without touching memory; so do the rows of a partial last tile past the last key) and are masked;
+//   * masks live in the step's cold exit (the one of the rescale decision): in-place -inf + a second row-max tree, taken only by the
+//     iterations that straddle a mask boundary; the plain step carries one scalar OR for it;
+//   * Q / O through buffer descriptors with 32-bit lane offsets (hoisted 64-bit addresses were spilled: a scratch reload waits on vmcnt(0),
+//     i.e. on every tile DMA in flight), the next block's Q trickled in a piece per iteration, block id carried from that prefetch.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -257,6 +269,17 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     lim_hi[qb] = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
     lim_lo[qb] = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
   }
+  // per query block of this wave (32 rows against the 32 keys of a step): the steps whose keys are ALL visible to all of its rows, and the
+  // steps with ANY visible key -- what the cold mask path looks at instead of row / key arithmetic
+  int qb_all_lo[QB], qb_all_hi[QB], qb_any_lo[QB], qb_any_hi[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int r0 = w_row0 + 32 * qb, r1 = r0 + 31;
+    const int hi0 = (p.wr >= 0) ? min(sk - 1, r0 + shift + p.wr) : sk - 1, hi1 = (p.wr >= 0) ? min(sk - 1, r1 + shift + p.wr) : sk - 1;
+    const int lo0 = (p.wl >= 0) ? (r0 + shift - p.wl) : 0, lo1 = (p.wl >= 0) ? (r1 + shift - p.wl) : 0;
+    qb_all_lo[qb] = (lo1 - key_base + 31) >> 5;  qb_all_hi[qb] = (hi0 - 31 - key_base) >> 5;   // k0 >= lo1 and k0 + 31 <= hi0
+    qb_any_lo[qb] = (lo0 - 31 - key_base + 31) >> 5;  qb_any_hi[qb] = (hi1 - key_base) >> 5;   // k0 + 31 >= lo0 and k0 <= hi1
+  }
   auto step_needs_mask = [&](int i) __attribute__((always_inline)) {
     const int k0 = key_base + 32 * i;
     return (k0 + 31 > w_full_hi) || (k0 < w_full_lo);
@@ -404,9 +427,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   float m_run[QB], l_run[QB][2], o_lag[QB];
   float thr_l[QB];          // per-lane decision threshold: -inf until the row has seen a key (any finite score moves m), then rescale_thr
   unsigned long long lag_mask = 0ull;   // wave-uniform, all ones or zero: some o_lag != 1 is waiting to be applied to O
-  f32x16 negm[QB];     // the C operand of every plain score chain's first MFMA: -m broadcast (0 while m = -inf).  A step that straddles a
-                       // mask boundary starts its chain from the score tuple itself, pre-loaded with -m or -inf (masked_c): the matrix
-                       // pipe applies the mask
+  f32x16 negm[QB];     // the C operand of every score chain's first MFMA: -m broadcast (0 while m = -inf)
   f32x16 sA[QB], sB[QB];
   u32x4 pfA[QB][2], pfB[QB][2];
 #pragma unroll
@@ -418,25 +439,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     for (int t = 0; t < 2; ++t) { pfA[qb][t] = u32x4{0u, 0u, 0u, 0u}; pfB[qb][t] = u32x4{0u, 0u, 0u, 0u}; }
   }
 
-  // Start value of the score chain of a step that straddles a mask boundary: -m in the visible elements, -inf in the hidden ones, written
-  // into the (dead) score tuple itself, from which the chain then accumulates -- so the scores leave the matrix pipe masked
-  // (s + (-inf) = -inf: exp2 gives 0, the row maximum ignores it) and the masked step is otherwise the plain step.  negm is only
-  // read here: modifying it under a branch makes hipcc copy both tuples at every join (measured: 16 v_mov_b64 per plain step).
-  auto masked_c = [&](int i, f32x16 (&s_nxt)[QB]) __attribute__((always_inline)) {
-    const int k0 = key_base + 32 * i;
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      const int rel_hi = lim_hi[qb] - k0 - 4 * hi;
-      const int rel_lo = lim_lo[qb] - k0 - 4 * hi;
-      if (two_sided) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const int off = acc_row(r, 0); s_nxt[qb][r] = ((off <= rel_hi) && (off >= rel_lo)) ? negm[qb][r] : -INFINITY; }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const int off = acc_row(r, 0); s_nxt[qb][r] = (off <= rel_hi) ? negm[qb][r] : -INFINITY; }
-      }
-    }
-  };
   // Decision on the NEXT step's scores, held as s' = s - m_base (m_base = m, or 0 while m = -inf): the row moves its maximum
   // when max(s') > thr_l, i.e. when it grew by more than rescale_thr -- or, for a row that has not seen a key yet (thr_l = -inf),
   // as soon as any score is finite (same rule as fa_fwd_il.hip: (m_new - m_run) > thr with m_new = max(m_run, max s)).
@@ -469,20 +471,78 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     o_lag[qb] = alpha;
   };
   // tmax = row maxima of s' (already combined across the lane halves)
-  auto decide_and_rescale = [&](const float (&tmax)[QB], f32x16 (&s_nxt)[QB]) __attribute__((always_inline)) {
+  auto decide_and_rescale = [&](const float (&tmax_in)[QB], f32x16 (&s_nxt)[QB], unsigned long long mask_step = 0ull, int i_step = 0) __attribute__((always_inline)) {
     // (the two compares and the OR in one statement: hipcc's own rendering of "any lane" is 10 instructions at every step boundary)
     unsigned long long grow_mask;
     asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cmp_gt_f32 %0, %3, %4\n\ts_or_b64 %0, %0, vcc"
-                 : "=&s"(grow_mask) : "v"(tmax[0]), "v"(thr_l[0]), "v"(tmax[1]), "v"(thr_l[1]) : "vcc");
+                 : "=&s"(grow_mask) : "v"(tmax_in[0]), "v"(thr_l[0]), "v"(tmax_in[1]), "v"(thr_l[1]) : "vcc");
+    float tmax[QB] = {tmax_in[0], tmax_in[1]};
+    if (__builtin_expect((grow_mask | lag_mask | mask_step) != 0ull, 0)) {   // the step's one cold exit
+    if (mask_step != 0ull) {
+      // This step straddles a mask boundary (a wave's diagonal tile, window edges, the partial last tile, the empty chains of the drain): its
+      // scores left the pipe unmasked and the tree in the gaps took their maxima.  Mask them now, in place (tied asm operands, as in
+      // rescale()), and take the maxima again.  The matrix pipe idles for these 30-110 instructions -- a wave's last two iterations of a
+      // block under a causal mask -- and the plain step carries no trace of the mask but one scalar OR.  (Round 2 built masked step
+      // VARIANTS, round 3 first a pre-loaded chain start value in separate loops: either way the variants' score tuples met at joins and
+      // hipcc copied 32 registers per step or per loop change; the last five iterations of a block under a causal mask: 30k clocks with the
+      // separate loops, 26k this way, 17.6k if nothing were masked (profiles/r03_fwd_w64_stamps.txt).  What is left is mostly hipcc copying
+      // a touched tuple into fresh registers and back around these tied operands; the instruction count of the mask itself barely shows.)
+      mfma_drain_v(s_nxt[0], s_nxt[1]);
+      const int k0m = key_base + 32 * i_step;
+      float ninf = -INFINITY;
+      asm volatile("" : "+v"(ninf));
+      static_for<QB>([&](auto mqc) __attribute__((always_inline)) {
+        constexpr int mq = decltype(mqc)::value;
+        if (FA_W64_ABL & 8192) return;   // (timing only: take the cold exit, mask nothing)
+        // the 32 rows of this query block against the 32 keys of the step: all visible (nothing to do: the tree's maximum stands), none
+        // (the drain's empty chains, the upper query block past a wave's diagonal: -inf without looking), or element by element
+        // (step ranges computed once per block: qb_all / qb_any)
+        if (i_step >= qb_all_lo[mq] && i_step <= qb_all_hi[mq]) return;
+        if (i_step > qb_any_hi[mq] || i_step < qb_any_lo[mq]) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float sv = s_nxt[mq][r];
+            asm volatile("v_mov_b32 %0, %1" : "+v"(sv) : "v"(ninf));
+            s_nxt[mq][r] = sv;
+          }
+          tmax[mq] = -INFINITY;
+          return;
+        }
+        const int rel_hi = lim_hi[mq] - k0m - 4 * hi, rel_lo = lim_lo[mq] - k0m - 4 * hi;
+        if (two_sided) {   // (the branch OUTSIDE the element loop: inside it hipcc emits two jumps per element)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int off = acc_row(r, 0);
+            float sv = s_nxt[mq][r];
+            const unsigned long long vis = __builtin_amdgcn_ballot_w64((off <= rel_hi) && (off >= rel_lo));
+            asm volatile("v_cndmask_b32 %0, %2, %0, %1" : "+v"(sv) : "s"(vis), "v"(ninf));
+            s_nxt[mq][r] = sv;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float sv = s_nxt[mq][r];
+            asm volatile("v_cmp_le_i32 vcc, %c2, %1\n\tv_cndmask_b32 %0, %3, %0, vcc" : "+v"(sv) : "v"(rel_hi), "i"(acc_row(r, 0)), "v"(ninf) : "vcc");
+            s_nxt[mq][r] = sv;
+          }
+        }
+        float t = vmax3(s_nxt[mq][0], s_nxt[mq][1], s_nxt[mq][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) t = vmax3(t, s_nxt[mq][r], s_nxt[mq][r + 1]);
+        tmax[mq] = vhalf_max(vmax2(t, s_nxt[mq][15]));
+      });
+      grow_mask = __builtin_amdgcn_ballot_w64(tmax[0] > thr_l[0] || tmax[1] > thr_l[1]);
+    }
     // cold: ~4 KB of straight-line code per call site.  Left in line it sat between the steps of the tile loop and every
     // step paid an instruction-fetch miss jumping over it (18 of 63 clocks per MFMA, profiles/r02_w64_ablations.txt);
     // __builtin_expect moves it behind the loop.
-    if (__builtin_expect((grow_mask | lag_mask) != 0ull, 0)) {
+    if ((grow_mask | lag_mask) != 0ull) {
       const bool g0 = tmax[0] > thr_l[0], g1 = tmax[1] > thr_l[1];
       mfma_drain_acc();  // O is about to be read by the VALU
       rescale(ICw<0>{}, g0, tmax[0], s_nxt[0]);
       rescale(ICw<1>{}, g1, tmax[1], s_nxt[1]);
       lag_mask = __builtin_amdgcn_ballot_w64(o_lag[0] != 1.f || o_lag[1] != 1.f) != 0ull ? ~0ull : 0ull;
+    }
     }
   };
   // ---- steady-state step: NG MFMA gaps, everything else hand-assigned to a gap ---------------------------------------
@@ -494,11 +554,10 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   //   been issued, i.e. with nothing to hide behind).  The step's K or V tile DMA pieces sit in the odd gaps 1, 3, ...
   //   (DPW pieces: M0 is written with the first one and must survive until the last -- hipcc emits no M0 use in this kernel,
   //   checked in the ISA by tools/isa_blocks.py --m0).
-  auto fast_step = [&](auto halfc, auto maskc, int i_nxt, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
+  auto fast_step = [&](auto halfc, int i_nxt, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
                        const u32x4 (&pf_prev)[QB][2], u32x4 (&pf_cur)[QB][2], const u32x4& dma_srd, const unsigned (&dma_off)[DPW],
-                       unsigned dma_toff, unsigned dma_dst) __attribute__((always_inline)) {
+                       unsigned dma_toff, unsigned dma_dst, unsigned long long iter_mask = 0ull) __attribute__((always_inline)) {
     constexpr int half = decltype(halfc)::value;
-    constexpr bool MASK = decltype(maskc)::value != 0;
     constexpr int QKG = 2 * KS, PVG = 4 * DB, NG = QKG + PVG;
     constexpr int KOFF = half * 32 * ROW_BYTES;                    // (+ the buffer parity carried by ka / va)
     constexpr int VOFF = 2 * TILE_BYTES + half * 32 * ROW_BYTES;
@@ -530,7 +589,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     auto el_end = [](int x) constexpr { return x <= QKG ? (24 * x) / QKG : (24 + ((x - QKG) * 16) / PVG > 32 ? 32 : 24 + ((x - QKG) * 16) / PVG); };
     float pe[QB][16];   // P_i as scalars (writing them back into the score tuples makes hipcc copy whole 16-register tuples)
     float tmax[QB] = {-INFINITY, -INFINITY}, tcopy[QB] = {0.f, 0.f};
-    if constexpr (MASK) masked_c(i_nxt, s_nxt);   // (a step that straddles a mask boundary: the mask goes into the chain's start value; nothing else differs)
     // gap (inside the PV half) schedule of the row-max work of query block mq
     constexpr int UPG = PVG >= 16 ? 1 : 2;        // max3 units per gap
     auto tree_g0 = [](int mq) constexpr { return 1 + mq; };   // the chain of block mq retired at gap QKG - 2 + mq
@@ -543,7 +601,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       constexpr int f = x / 2, qb = x & 1;
       if constexpr (qb == 0) rd_frag(f + AH);
       if constexpr (x < QKG) {
-        if constexpr (f == 0 && !MASK) mfma_s_first<E, qb * KS>(s_nxt[qb], kfr[f % RING], negm[qb]);
+        if constexpr (f == 0) mfma_s_first<E, qb * KS>(s_nxt[qb], kfr[f % RING], negm[qb]);
         else mfma_s_acc<E, qb * KS + f>(s_nxt[qb], kfr[f % RING]);
       } else {
         constexpr int op = f - KS;
@@ -609,7 +667,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #pragma unroll
       for (int mq = 0; mq < QB; ++mq)
         if (hm_gap(mq) >= PVG && !(FA_W64_ABL & 8)) tmax[mq] = vhalf_max(tmax[mq]);   // (no gap left for it)
-      decide_and_rescale(tmax, s_nxt);
+      decide_and_rescale(tmax, s_nxt, iter_mask, i_nxt);
     }
   };
 
@@ -623,10 +681,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // instruction-cache miss stream (12-17k clocks for iteration 0 against 3.2k for a steady-state iteration).
   // Waves outside their range (rows past the sequence end, the early-finishing waves of a block under a causal mask, windows) only
   // issue their share of the tile DMAs and meet the barriers.
-  // Per wave the iterations 0 .. n_tiles fall into five consecutive ranges -- idle | masked | plain | masked | idle -- walked by three
-  // tight loops (one per kind, entered from a five-round phase loop): the plain loop's body is nothing but the two plain steps.
-  // (With the kinds as branches inside ONE loop hipcc joins the score tuples of the variants at every iteration and copies 32
-  // registers between every two steps.)
+  // Per wave the iterations 0 .. n_tiles fall into three consecutive ranges -- idle | active | idle -- walked by two tight loops (entered
+  // from a three-round phase loop); inside the active range the iterations outside [p_lo, p_hi] hold a step that straddles a mask
+  // boundary: their steps take the cold exit of decide_and_rescale.
   int u_first = n_tiles + 1, u_last = n_tiles, p_lo = n_tiles + 1, p_hi = n_tiles;   // all idle
   if (wave_valid && n_tiles > 0) {
     const int a_lo = max(0, (w_kmin - key_base) >> 5);               // first / last step with a key this wave can see
@@ -655,7 +712,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #endif
     toggle_parity();
   };
-  auto step_pair = [&](auto maskc, int u) __attribute__((always_inline)) {
+  auto step_pair = [&](int u) __attribute__((always_inline)) {
     // K_{u+1} rides in the first step, V_u in the second; tiles past the last one: the null descriptor (zero fill, no traffic)
     const int par = u & 1;
     q_trickle();
@@ -668,22 +725,22 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     // (computed HERE: left to itself hipcc sinks these scalar selects and multiplies into the steps' MFMA gaps)
     u32x4 sk_ = srd_k, sv_ = srd_v;
     unsigned tk_ = toff_k, tv_ = toff_v;
-    asm volatile("" : "+s"(sk_), "+s"(sv_), "+s"(tk_), "+s"(tv_), "+s"(dst_v));
-    fast_step(ICw<0>{}, maskc, 2 * u, sA, sB, pfA, pfB, sk_, koff_l, tk_, dst_k);
-    fast_step(ICw<1>{}, maskc, 2 * u + 1, sB, sA, pfB, pfA, sv_, voff_l, tv_, dst_v);
+    // iterations outside [p_lo, p_hi] hold a step that straddles a mask boundary: both of their steps take the cold exit
+    int im32 = __builtin_amdgcn_readfirstlane((!(FA_W64_ABL & 4096) && (u < p_lo || u > p_hi)) ? -1 : 0);   // (ABL 4096: never mask -- timing only)
+    asm volatile("" : "+s"(sk_), "+s"(sv_), "+s"(tk_), "+s"(tv_), "+s"(dst_v), "+s"(im32));
+    const unsigned long long imask = (unsigned long long)(long long)im32;
+    fast_step(ICw<0>{}, 2 * u, sA, sB, pfA, pfB, sk_, koff_l, tk_, dst_k, imask);
+    fast_step(ICw<1>{}, 2 * u + 1, sB, sA, pfB, pfA, sv_, voff_l, tv_, dst_v, imask);
     iter_end();
   };
   if (n_tiles > 0) {
     int u = 0;
 #pragma unroll 1
-    for (int phase = 0; phase < 5; ++phase) {
-      const int end = phase == 0 ? u_first : phase == 1 ? p_lo : phase == 2 ? p_hi + 1 : phase == 3 ? u_last + 1 : n_tiles + 1;
-      if (phase == 2) {
+    for (int phase = 0; phase < 3; ++phase) {
+      const int end = phase == 0 ? u_first : phase == 1 ? u_last + 1 : n_tiles + 1;
+      if (phase == 1) {
 #pragma unroll 1
-        for (; u < end; ++u) step_pair(ICw<0>{}, u);
-      } else if (phase == 1 || phase == 3) {
-#pragma unroll 1
-        for (; u < end; ++u) step_pair(ICw<1>{}, u);
+        for (; u < end; ++u) step_pair(u);
       } else {
 #pragma unroll 1
         for (; u < end; ++u) {
