@@ -25,7 +25,7 @@ if [ "$1" != "run" ]; then
   wait
   ls -la gpurun_abl
 else
-  for rep in 1 2; do
+  for rep in $(seq 1 ${REPS-2}); do
     for v in $LIST; do
       [ -z "$v" ] && continue
       name="${v%%:*}"
