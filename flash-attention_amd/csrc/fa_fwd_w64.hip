@@ -62,6 +62,12 @@
 #define FA_W64_VDMA_G0 1
 #define FA_W64_VDMA_GS 2
 #endif
+#ifndef FA_W64_STAG
+#define FA_W64_STAG 0      // 1: slot s of a step belongs to wave s % 4 (piece s / 4), 2: to wave s / pieces-per-wave
+#endif
+#ifndef FA_W64_STAG_GS
+#define FA_W64_STAG_GS 1
+#endif
 
 namespace fa {
 
@@ -408,20 +414,15 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   const int tr_i = lane & 15, tr_half = (lane >> 4) & 1;
   const int tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
   const int vbase = (4 * hi + tr_rr) * ROW_BYTES + (v_swz_w<D>(tr_rr) << 6) + tr_half * 32 + tr_cc * 8;
-  // The bases carry the buffer parity of the iteration (iteration u reads K buffer u & 1 and V buffer (u - 1) & 1) and are toggled
-  // at the end of every iteration: one body serves both parities (two copies of it were 60 KB of a 240 KB kernel that did not
-  // fit the instruction cache any more, profiles/r03_fwd_w64_stamps.txt).
+  // The buffer parity of an iteration (iteration u reads K buffer u & 1 and V buffer (u - 1) & 1) is a compile-time constant of the step: the
+  // tile loop's body holds an even and an odd iteration, so the parity rides in the reads' immediate offsets (a run-time parity carried by the
+  // bases cost twelve v_xor per iteration -- and at one wave per SIMD every instruction of the loop costs its ~4.7 clocks,
+  // profiles/r03_fwd_w64_ablations.txt).
   int ka[KS], va[DB];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) ka[ks] = kbase ^ (ks << 5);
 #pragma unroll
-  for (int db = 0; db < DB; ++db) va[db] = (vbase ^ (db << 6)) + TILE_BYTES;
-  auto toggle_parity = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) ka[ks] ^= TILE_BYTES;
-#pragma unroll
-    for (int db = 0; db < DB; ++db) va[db] ^= TILE_BYTES;
-  };
+  for (int db = 0; db < DB; ++db) va[db] = vbase ^ (db << 6);
 
   acc_zero_range<0>(std::make_integer_sequence<int, 32 * DB>{});   // O = 2*DB tuples: a[0 : 32*DB) (query block qb, d-block db at tuple qb*DB + db)
   float m_run[QB], l_run[QB][2], o_lag[QB];
@@ -446,12 +447,14 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // (after P_i.V, computed at the old scale, has been accumulated) -- the lagged rescale of fa_fwd_il.hip.
   auto rescale = [&](auto qbc, bool grow, float tmax, f32x16& s_nxt) __attribute__((always_inline)) {
     constexpr int qb = decltype(qbc)::value;
-    const float m_upd = grow ? (tmax - negm[qb][0]) : m_run[qb];   // grow => tmax finite
+    // (the base the pending scores are held against, recomputed from m: a masked step's C broadcast carries -inf in its masked elements)
+    const float m_base = (m_run[qb] == -INFINITY) ? 0.f : m_run[qb];
+    const float m_upd = grow ? (tmax + m_base) : m_run[qb];   // grow => tmax finite
     const float m_safe = (m_upd == -INFINITY) ? 0.f : m_upd;
     // (a row that sees its first key -- m = -inf -- has O = 0 and l = 0: its factor is 1, so the first decision of a block, which moves
     // every row, leaves nothing to apply to O one step later)
     const float alpha = (grow && m_run[qb] != -INFINITY) ? fast_exp2(m_run[qb] - m_safe) : 1.f;
-    const float delta = m_safe + negm[qb][0];   // new base - old base (0 where the row did not move)
+    const float delta = m_safe - m_base;   // new base - old base (0 where the row did not move)
     m_run[qb] = m_upd;
     thr_l[qb] = grow ? thr : thr_l[qb];
     l_run[qb][0] *= alpha;
@@ -471,79 +474,68 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     o_lag[qb] = alpha;
   };
   // tmax = row maxima of s' (already combined across the lane halves)
-  auto decide_and_rescale = [&](const float (&tmax_in)[QB], f32x16 (&s_nxt)[QB], unsigned long long mask_step = 0ull, int i_step = 0) __attribute__((always_inline)) {
+  auto decide_and_rescale = [&](const float (&tmax)[QB], f32x16 (&s_nxt)[QB]) __attribute__((always_inline)) {
     // (the two compares and the OR in one statement: hipcc's own rendering of "any lane" is 10 instructions at every step boundary)
     unsigned long long grow_mask;
     asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cmp_gt_f32 %0, %3, %4\n\ts_or_b64 %0, %0, vcc"
-                 : "=&s"(grow_mask) : "v"(tmax_in[0]), "v"(thr_l[0]), "v"(tmax_in[1]), "v"(thr_l[1]) : "vcc");
-    float tmax[QB] = {tmax_in[0], tmax_in[1]};
-    if (__builtin_expect((grow_mask | lag_mask | mask_step) != 0ull, 0)) {   // the step's one cold exit
-    if (mask_step != 0ull) {
-      // This step straddles a mask boundary (a wave's diagonal tile, window edges, the partial last tile, the empty chains of the drain): its
-      // scores left the pipe unmasked and the tree in the gaps took their maxima.  Mask them now, in place (tied asm operands, as in
-      // rescale()), and take the maxima again.  The matrix pipe idles for these 30-110 instructions -- a wave's last two iterations of a
-      // block under a causal mask -- and the plain step carries no trace of the mask but one scalar OR.  (Round 2 built masked step
-      // VARIANTS, round 3 first a pre-loaded chain start value in separate loops: either way the variants' score tuples met at joins and
-      // hipcc copied 32 registers per step or per loop change; the last five iterations of a block under a causal mask: 30k clocks with the
-      // separate loops, 26k this way, 17.6k if nothing were masked (profiles/r03_fwd_w64_stamps.txt).  What is left is mostly hipcc copying
-      // a touched tuple into fresh registers and back around these tied operands; the instruction count of the mask itself barely shows.)
-      mfma_drain_v(s_nxt[0], s_nxt[1]);
-      const int k0m = key_base + 32 * i_step;
-      float ninf = -INFINITY;
-      asm volatile("" : "+v"(ninf));
-      static_for<QB>([&](auto mqc) __attribute__((always_inline)) {
-        constexpr int mq = decltype(mqc)::value;
-        if (FA_W64_ABL & 8192) return;   // (timing only: take the cold exit, mask nothing)
-        // the 32 rows of this query block against the 32 keys of the step: all visible (nothing to do: the tree's maximum stands), none
-        // (the drain's empty chains, the upper query block past a wave's diagonal: -inf without looking), or element by element
-        // (step ranges computed once per block: qb_all / qb_any)
-        if (i_step >= qb_all_lo[mq] && i_step <= qb_all_hi[mq]) return;
-        if (i_step > qb_any_hi[mq] || i_step < qb_any_lo[mq]) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float sv = s_nxt[mq][r];
-            asm volatile("v_mov_b32 %0, %1" : "+v"(sv) : "v"(ninf));
-            s_nxt[mq][r] = sv;
-          }
-          tmax[mq] = -INFINITY;
-          return;
-        }
-        const int rel_hi = lim_hi[mq] - k0m - 4 * hi, rel_lo = lim_lo[mq] - k0m - 4 * hi;
-        if (two_sided) {   // (the branch OUTSIDE the element loop: inside it hipcc emits two jumps per element)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int off = acc_row(r, 0);
-            float sv = s_nxt[mq][r];
-            const unsigned long long vis = __builtin_amdgcn_ballot_w64((off <= rel_hi) && (off >= rel_lo));
-            asm volatile("v_cndmask_b32 %0, %2, %0, %1" : "+v"(sv) : "s"(vis), "v"(ninf));
-            s_nxt[mq][r] = sv;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float sv = s_nxt[mq][r];
-            asm volatile("v_cmp_le_i32 vcc, %c2, %1\n\tv_cndmask_b32 %0, %3, %0, vcc" : "+v"(sv) : "v"(rel_hi), "i"(acc_row(r, 0)), "v"(ninf) : "vcc");
-            s_nxt[mq][r] = sv;
-          }
-        }
-        float t = vmax3(s_nxt[mq][0], s_nxt[mq][1], s_nxt[mq][2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) t = vmax3(t, s_nxt[mq][r], s_nxt[mq][r + 1]);
-        tmax[mq] = vhalf_max(vmax2(t, s_nxt[mq][15]));
-      });
-      grow_mask = __builtin_amdgcn_ballot_w64(tmax[0] > thr_l[0] || tmax[1] > thr_l[1]);
-    }
+                 : "=&s"(grow_mask) : "v"(tmax[0]), "v"(thr_l[0]), "v"(tmax[1]), "v"(thr_l[1]) : "vcc");
     // cold: ~4 KB of straight-line code per call site.  Left in line it sat between the steps of the tile loop and every
-    // step paid an instruction-fetch miss jumping over it (18 of 63 clocks per MFMA, profiles/r02_w64_ablations.txt);
+    // step paid an instruction-fetch miss jumping over it (18 of 63 clocks per MFMA, profiles/r03_fwd_w64_ablations.txt);
     // __builtin_expect moves it behind the loop.
-    if ((grow_mask | lag_mask) != 0ull) {
+    if (__builtin_expect((grow_mask | lag_mask) != 0ull, 0)) {   // the step's one cold exit
       const bool g0 = tmax[0] > thr_l[0], g1 = tmax[1] > thr_l[1];
       mfma_drain_acc();  // O is about to be read by the VALU
       rescale(ICw<0>{}, g0, tmax[0], s_nxt[0]);
       rescale(ICw<1>{}, g1, tmax[1], s_nxt[1]);
       lag_mask = __builtin_amdgcn_ballot_w64(o_lag[0] != 1.f || o_lag[1] != 1.f) != 0ull ? ~0ull : 0ull;
     }
-    }
+  };
+  // Masks ride in the C operand of a score chain's first MFMA: the broadcast -m (negm) gets -inf in the elements of masked (row, key) pairs, the
+  // scores leave the matrix pipe as -inf there, and the step -- its row-max tree, its exp2, its decision -- runs unchanged.  set_mask(i) rewrites the
+  // two broadcasts for step i (32 rows of a query block against 32 keys: all visible / none / element by element, from the step ranges computed once
+  // per block), clear_mask() restores them; both run between steps, only in the iterations that straddle a mask boundary (a wave's diagonal tile,
+  // window edges, the partial last tile, the drain's empty chains).  (Rounds 2-3 tried masked step VARIANTS, a pre-loaded chain start in separate
+  // loops, and masking the finished scores in the step's cold exit + a second row-max tree: 30k / 30k / 26k clocks for the last five iterations
+  // of a block under a causal mask against 17.6k with nothing masked, profiles/r03_fwd_w64_stamps.txt.)
+  // Straight-line on purpose, one path for every case (all visible / none / element by element fall out of the per-lane bounds): with a branch
+  // per case the rewritten broadcasts of the cases meet at joins and hipcc copies 32 registers per call.
+  auto set_mask = [&](int i_step) __attribute__((always_inline)) {
+    const int k0m = key_base + 32 * i_step;
+    float ninf = -INFINITY;
+    asm volatile("" : "+v"(ninf));
+    static_for<QB>([&](auto mqc) __attribute__((always_inline)) {
+      constexpr int mq = decltype(mqc)::value;
+      float nb = (m_run[mq] == -INFINITY) ? 0.f : -m_run[mq];
+      // element r of this lane scores key k0m + 4*hi + acc_row(r, 0): the lane's visibility bitmap over those offsets, then two instructions per
+      // element (sign-extended bit -> select mask -> bit-field insert)
+      const int rel_hi = min(lim_hi[mq] - k0m - 4 * hi, 31), rel_lo = max(lim_lo[mq] - k0m - 4 * hi, 0);
+      const unsigned ones = (rel_hi - rel_lo >= 31) ? 0xffffffffu : ((2u << ((rel_hi - rel_lo) & 31)) - 1u);
+      unsigned bits = (rel_hi >= rel_lo) ? (ones << rel_lo) : 0u;
+      asm volatile("" : "+v"(nb), "+v"(bits));
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) {
+        float n0 = negm[mq][r], n1 = negm[mq][r + 1], n2 = negm[mq][r + 2], n3 = negm[mq][r + 3];
+        unsigned t0, t1;
+        asm volatile("v_bfe_i32 %4, %6, %c9, 1\n\tv_bfe_i32 %5, %6, %c10, 1\n\tv_bfi_b32 %0, %4, %7, %8\n\tv_bfi_b32 %1, %5, %7, %8\n\t"
+                     "v_bfe_i32 %4, %6, %c11, 1\n\tv_bfe_i32 %5, %6, %c12, 1\n\tv_bfi_b32 %2, %4, %7, %8\n\tv_bfi_b32 %3, %5, %7, %8"
+                     : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "=&v"(t0), "=&v"(t1)
+                     : "v"(bits), "v"(nb), "v"(ninf), "i"(acc_row(r, 0)), "i"(acc_row(r + 1, 0)), "i"(acc_row(r + 2, 0)), "i"(acc_row(r + 3, 0)));
+        negm[mq][r] = n0; negm[mq][r + 1] = n1; negm[mq][r + 2] = n2; negm[mq][r + 3] = n3;
+      }
+    });
+  };
+  auto clear_mask = [&]() __attribute__((always_inline)) {
+    static_for<QB>([&](auto mqc) __attribute__((always_inline)) {
+      constexpr int mq = decltype(mqc)::value;
+      float nb = (m_run[mq] == -INFINITY) ? 0.f : -m_run[mq];
+      asm volatile("" : "+v"(nb));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float nv = negm[mq][r];
+        asm volatile("v_mov_b32 %0, %1" : "+v"(nv) : "v"(nb));
+        negm[mq][r] = nv;
+      }
+    });
   };
   // ---- steady-state step: NG MFMA gaps, everything else hand-assigned to a gap ---------------------------------------
   //   gaps 0 .. 2KS-1      : S_{i+1}[qb] chain, k-step g/2 (the K fragment read once, used by both query blocks)
@@ -554,13 +546,13 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   //   been issued, i.e. with nothing to hide behind).  The step's K or V tile DMA pieces sit in the odd gaps 1, 3, ...
   //   (DPW pieces: M0 is written with the first one and must survive until the last -- hipcc emits no M0 use in this kernel,
   //   checked in the ISA by tools/isa_blocks.py --m0).
-  auto fast_step = [&](auto halfc, int i_nxt, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
+  auto fast_step = [&](auto halfc, auto parc, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
                        const u32x4 (&pf_prev)[QB][2], u32x4 (&pf_cur)[QB][2], const u32x4& dma_srd, const unsigned (&dma_off)[DPW],
-                       unsigned dma_toff, unsigned dma_dst, unsigned long long iter_mask = 0ull) __attribute__((always_inline)) {
-    constexpr int half = decltype(halfc)::value;
+                       unsigned dma_toff, unsigned dma_dst) __attribute__((always_inline)) {
+    constexpr int half = decltype(halfc)::value, par = decltype(parc)::value;
     constexpr int QKG = 2 * KS, PVG = 4 * DB, NG = QKG + PVG;
-    constexpr int KOFF = half * 32 * ROW_BYTES;                    // (+ the buffer parity carried by ka / va)
-    constexpr int VOFF = 2 * TILE_BYTES + half * 32 * ROW_BYTES;
+    constexpr int KOFF = par * TILE_BYTES + half * 32 * ROW_BYTES;                       // K_u: buffer u & 1
+    constexpr int VOFF = (2 + (par ^ 1)) * TILE_BYTES + half * 32 * ROW_BYTES;           // V_{u-1}: buffer (u - 1) & 1
     constexpr int AH = FA_W64_AH, RING = AH + 1;  // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
     constexpr int NF = KS + 2 * DB;       // fragment slots per step: KS K fragments, then 2*DB V fragments
     u32x4 kfr[RING];
@@ -610,8 +602,28 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       }
       // this step's DMA pieces (K_{u+1} in the first step of an iteration, V_u in the second): gaps G0, G0 + GS, ..
       constexpr int G0 = half == 0 ? FA_W64_KDMA_G0 : FA_W64_VDMA_G0, GS = half == 0 ? FA_W64_KDMA_GS : FA_W64_VDMA_GS;
+#if FA_W64_STAG
+      // wave-staggered slots: at most one wave of the workgroup issues a piece in any gap (the four waves run in lock step behind the tile
+      // barrier, so same-gap pieces queue behind each other at the CU's one vector-memory path)
+      constexpr int SG = FA_W64_STAG_GS;   // gaps between slots
+      if constexpr (x % SG == 0 && x / SG < NW * DPW && !(FA_W64_ABL & 32)) {
+        constexpr int sl = x / SG;
+        constexpr int own = FA_W64_STAG == 1 ? sl % NW : sl / DPW, pc = FA_W64_STAG == 1 ? sl / NW : sl % DPW;
+        int wv = wave;
+        asm volatile("" : "+s"(wv));   // (compared here, as a scalar: hoisted, the sixteen compares become lane masks and cost two VALU per slot)
+        if (wv == own) {
+          if constexpr (pc == 0)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
+          else
+            asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2 lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
+        }
+      }
+      if constexpr (false) {
+        constexpr int pc = 0;
+#else
       if constexpr (x >= G0 && (x - G0) % GS == 0 && (x - G0) / GS < DPW && !(FA_W64_ABL & 32)) {
         constexpr int pc = (x - G0) / GS;
+#endif
         // (the tile's byte offset rides in the scalar-offset operand; the range check accounts for it: tools/ubench/lds_dma_oob.hip)
         if constexpr (pc == 0)
           asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
@@ -624,6 +636,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
         const int eq = e >> 4, r = e & 15;
         pe[eq][r] = (FA_W64_ABL & 1) ? s_cur[eq][r] : fast_exp2(s_cur[eq][r]);
         if (!(FA_W64_ABL & (2 | 64))) l_run[eq][r & 1] += pe[eq][r];
+#if FA_W64_STAG
+        asm volatile("" : "+v"(pe[eq][r]), "+v"(l_run[eq][r & 1]));   // (the slot branches end basic blocks: keep the gap's VALU in its gap)
+#endif
       }
       if ((FA_W64_ABL & 64) && x > 0) {  // the adds of the PREVIOUS gap's elements
 #pragma unroll
@@ -667,7 +682,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #pragma unroll
       for (int mq = 0; mq < QB; ++mq)
         if (hm_gap(mq) >= PVG && !(FA_W64_ABL & 8)) tmax[mq] = vhalf_max(tmax[mq]);   // (no gap left for it)
-      decide_and_rescale(tmax, s_nxt, iter_mask, i_nxt);
+      decide_and_rescale(tmax, s_nxt);
     }
   };
 
@@ -697,6 +712,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       if (p_hi < p_lo) { p_lo = u_last + 1; p_hi = u_last; }         // no plain iteration: one masked range
     }
   }
+  u_first = __builtin_amdgcn_readfirstlane(u_first); u_last = __builtin_amdgcn_readfirstlane(u_last);   // (wave-uniform by construction; said so)
   const unsigned wave_dst = (unsigned)(wave * DPW * 1024);
 #if FA_W64_ABL & 256
   const long long abl_t0 = clock64();
@@ -710,46 +726,61 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #if FA_W64_ABL & 2048
     if (abl_n < 62) { FA_W64_STAMP(abl_n); ++abl_n; }
 #endif
-    toggle_parity();
   };
-  auto step_pair = [&](int u) __attribute__((always_inline)) {
-    // K_{u+1} rides in the first step, V_u in the second; tiles past the last one: the null descriptor (zero fill, no traffic)
-    const int par = u & 1;
+  // Active iterations outside [m_lo, m_hi] hold a step that straddles a mask boundary
+  const int m_lo = __builtin_amdgcn_readfirstlane((FA_W64_ABL & 4096) ? 0 : p_lo), m_hi = __builtin_amdgcn_readfirstlane((FA_W64_ABL & 4096) ? 0x3fffffff : p_hi);
+  const unsigned step_k = (unsigned)(BN * 2) * (unsigned)p.k_rs, step_v = (unsigned)(BN * 2) * (unsigned)p.v_rs;
+  unsigned tk_c = 0u, tv_c = 0u;   // byte offsets of tiles u + 1 (K) and u (V), carried through the active loop
+  auto step_pair = [&](auto parc, int u) __attribute__((always_inline)) {
+    constexpr int par = decltype(parc)::value;
+    // K_{u+1} rides in the first step, V_u in the second.  A tile past the block's last one is requested like any other: past the last key
+    // the descriptor's range check zero-fills it, before that it is a real tile nobody looks at (its scores are masked, its V rows meet P = 0)
+    // -- one tile of extra traffic per block against two descriptor selects per iteration.  Everything scalar the steps need is made HERE,
+    // and made cheap: carried offsets, constant descriptors (37 scalar instructions per iteration in round 2's form of this, ~175 clocks of
+    // a 3300-clock iteration).
     q_trickle();
-    const bool k_real = u + 1 < n_tiles, v_real = u < n_tiles;
-    const unsigned toff_k = k_real ? (unsigned)(n_min + u + 1) * (unsigned)(BN * 2) * (unsigned)p.k_rs : 0u;
-    const unsigned toff_v = v_real ? (unsigned)(n_min + u) * (unsigned)(BN * 2) * (unsigned)p.v_rs : 0u;
-    const u32x4 srd_k = k_real ? k_srd : null_srd, srd_v = v_real ? v_srd : null_srd;
-    const unsigned dst_k = __builtin_amdgcn_readfirstlane((unsigned)((par ^ 1) * TILE_BYTES) + wave_dst);
-    unsigned dst_v = __builtin_amdgcn_readfirstlane((unsigned)((2 + par) * TILE_BYTES) + wave_dst);
-    // (computed HERE: left to itself hipcc sinks these scalar selects and multiplies into the steps' MFMA gaps)
-    u32x4 sk_ = srd_k, sv_ = srd_v;
-    unsigned tk_ = toff_k, tv_ = toff_v;
-    // iterations outside [p_lo, p_hi] hold a step that straddles a mask boundary: both of their steps take the cold exit
-    int im32 = __builtin_amdgcn_readfirstlane((!(FA_W64_ABL & 4096) && (u < p_lo || u > p_hi)) ? -1 : 0);   // (ABL 4096: never mask -- timing only)
-    asm volatile("" : "+s"(sk_), "+s"(sv_), "+s"(tk_), "+s"(tv_), "+s"(dst_v), "+s"(im32));
-    const unsigned long long imask = (unsigned long long)(long long)im32;
-    fast_step(ICw<0>{}, 2 * u, sA, sB, pfA, pfB, sk_, koff_l, tk_, dst_k, imask);
-    fast_step(ICw<1>{}, 2 * u + 1, sB, sA, pfB, pfA, sv_, voff_l, tv_, dst_v, imask);
+    const int us = __builtin_amdgcn_readfirstlane(u);   // (uniform by construction; said so)
+    unsigned dst_k = (unsigned)((par ^ 1) * TILE_BYTES) + wave_dst, dst_v = (unsigned)((2 + par) * TILE_BYTES) + wave_dst;
+    unsigned tk_ = __builtin_amdgcn_readfirstlane(tk_c), tv_ = __builtin_amdgcn_readfirstlane(tv_c);   // (hipcc carries them in vector registers)
+    int im32 = ((us - m_lo) | (m_hi - us)) >> 31;   // -1 outside [m_lo, m_hi] (arithmetic, not a compare + select: that one goes through a lane mask)
+    dst_k = __builtin_amdgcn_readfirstlane(dst_k); dst_v = __builtin_amdgcn_readfirstlane(dst_v);
+    im32 = __builtin_amdgcn_readfirstlane(im32);
+    asm volatile("" : "+s"(tk_), "+s"(tv_), "+s"(dst_k), "+s"(dst_v), "+s"(im32));
+    tk_c += step_k; tv_c += step_v;
+    // (each test on a freshly laundered scalar: as one hoisted boolean hipcc keeps a lane mask and spends five instructions per test)
+    auto masked = [&]() __attribute__((always_inline)) { int c = im32; asm volatile("" : "+s"(c)); return c != 0; };
+    if (__builtin_expect(masked(), 0)) set_mask(2 * u);
+    fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
+    if (__builtin_expect(masked(), 0)) set_mask(2 * u + 1);
+    fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
+    if (__builtin_expect(masked(), 0)) clear_mask();
+    iter_end();
+  };
+  auto idle_iter = [&](int u) __attribute__((always_inline)) {
+    q_trickle();
+    if (!(FA_W64_ABL & 32) || u <= 1) { dma_tile(ICw<0>{}, (u & 1) ^ 1, u + 1); dma_tile(ICw<1>{}, u & 1, u); }
     iter_end();
   };
   if (n_tiles > 0) {
+    // idle | active | idle.  The active range starts at an even iteration (one extra, fully masked, iteration for a wave whose window
+    // starts at an odd tile: the block runs that iteration anyway) and leaves the two-iteration body in the middle or at its end.
+    const bool active = u_first <= u_last;
+    const int ua = active ? (u_first & ~1) : n_tiles + 1;
     int u = 0;
 #pragma unroll 1
-    for (int phase = 0; phase < 3; ++phase) {
-      const int end = phase == 0 ? u_first : phase == 1 ? u_last + 1 : n_tiles + 1;
-      if (phase == 1) {
+    for (; u < ua; ++u) idle_iter(u);
+    if (active) {
+      tk_c = __builtin_amdgcn_readfirstlane((unsigned)(n_min + u + 1) * step_k); tv_c = __builtin_amdgcn_readfirstlane((unsigned)(n_min + u) * step_v);
 #pragma unroll 1
-        for (; u < end; ++u) step_pair(u);
-      } else {
-#pragma unroll 1
-        for (; u < end; ++u) {
-          q_trickle();
-          if (!(FA_W64_ABL & 32) || u <= 1) { dma_tile(ICw<0>{}, (u & 1) ^ 1, u + 1); dma_tile(ICw<1>{}, u & 1, u); }
-          iter_end();
-        }
+      for (;;) {
+        step_pair(ICw<0>{}, u); ++u;
+        if (u > u_last) break;
+        step_pair(ICw<1>{}, u); ++u;
+        if (u > u_last) break;
       }
     }
+#pragma unroll 1
+    for (; u <= n_tiles; ++u) idle_iter(u);
   }
 
 #if FA_W64_ABL & 256

@@ -29,7 +29,7 @@ else
     for v in $LIST; do
       [ -z "$v" ] && continue
       name="${v%%:*}"
-      echo "$name: $(FA_GFX950_LIB=$PWD/gpurun_abl/libfa_$name.so python tools/w64_time.py 2>/dev/null | cut -c1-38 | tr '\n' ' ')"
+      echo "$name: $(FA_GFX950_LIB=$PWD/gpurun_abl/libfa_$name.so python tools/w64_time.py 2>/dev/null | cut -c1-110 | sed "s|^|    |")"
     done
   done
 fi
