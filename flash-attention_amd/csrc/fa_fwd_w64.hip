@@ -51,8 +51,11 @@
 
 // Gaps of a step that carry its LDS-DMA pieces (first gap, stride): where a piece is issued prices it between ~30 and ~180 clocks
 // (MI355X_MICROARCH.md "LDS-DMA piece issue cost"; profiles/r03_fwd_w64_dma_placement.txt)
+#ifndef FA_W64_WAIT2
+#define FA_W64_WAIT2 1
+#endif
 #ifndef FA_W64_AH
-#define FA_W64_AH 2   // LDS operand reads run this many fragment slots (2 gaps each) ahead of their MFMAs
+#define FA_W64_AH (FA_W64_WAIT2 ? 3 : 2)   // LDS operand reads run this many fragment slots (2 gaps each) ahead of their MFMAs
 #endif
 #ifndef FA_W64_KDMA_G0
 #define FA_W64_KDMA_G0 1
@@ -371,7 +374,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       const V8 raw = bitcast_u32x4<V8>(qraw[qb][ks]);
       V8 sc;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sc[j] = (E)((float)raw[j] * cq);
+      for (int j = 0; j < 8; j += 2) {   // (packed multiply: the conversion is ~400 instructions of un-overlapped per-block code)
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        f32x2 pr = {(float)raw[j], (float)raw[j + 1]};
+        pr *= f32x2{cq, cq};
+        sc[j] = (E)pr[0]; sc[j + 1] = (E)pr[1];
+      }
       acc_write_frag<W64_Q_BASE + 4 * (qb * KS + ks)>(__builtin_bit_cast(u32x4, sc));
     };
     auto load_q_all = [&](auto qbc) __attribute__((always_inline)) {
@@ -424,7 +432,13 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #pragma unroll
   for (int db = 0; db < DB; ++db) va[db] = vbase ^ (db << 6);
 
-  acc_zero_range<0>(std::make_integer_sequence<int, 32 * DB>{});   // O = 2*DB tuples: a[0 : 32*DB) (query block qb, d-block db at tuple qb*DB + db)
+  // O = 2*DB tuples: a[0 : 32*DB) (query block qb, d-block db at tuple qb*DB + db), zeroed by the matrix pipe (0 . 0 + 0: eight
+  // instructions; 128 v_accvgpr_write statements came with 120 pad s_nop from hipcc, ~1.2k clocks per block)
+  {
+    u32x4 zf = {0u, 0u, 0u, 0u};
+    asm volatile("" : "+v"(zf));
+    acc_zero_tuples_mfma<0>(zf, std::make_integer_sequence<int, 2 * DB>{});
+  }
   float m_run[QB], l_run[QB][2], o_lag[QB];
   float thr_l[QB];          // per-lane decision threshold: -inf until the row has seen a key (any finite score moves m), then rescale_thr
   unsigned long long lag_mask = 0ull;   // wave-uniform, all ones or zero: some o_lag != 1 is waiting to be applied to O
@@ -592,6 +606,16 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       constexpr int x = decltype(xc)::value;
       constexpr int f = x / 2, qb = x & 1;
       if constexpr (qb == 0) rd_frag(f + AH);
+#if FA_W64_WAIT2
+      // One wait per TWO fragment slots: before the MFMAs of an even slot f, wait until slot f + 1 has landed too (everything requested
+      // after it may still be in flight: slots f + 2 .. f + AH, one LDS instruction per K fragment, two per transposed V fragment).  hipcc
+      // models an explicit s_waitcnt and drops its own wait in front of slot f + 1 -- sixteen fewer instructions per iteration.
+      if constexpr (qb == 0 && (f & 1) == 0 && f + 1 < NF) {
+        constexpr auto ops = [](int g) constexpr { return g < KS ? 1 : g < NF ? 2 : 0; };
+        constexpr int out = [&]() constexpr { int n = 0; for (int g = f + 2; g <= f + AH; ++g) n += ops(g); return n; }();
+        __builtin_amdgcn_s_waitcnt(0xC07F | (out << 8));
+      }
+#endif
       if constexpr (x < QKG) {
         if constexpr (f == 0) mfma_s_first<E, qb * KS>(s_nxt[qb], kfr[f % RING], negm[qb]);
         else mfma_s_acc<E, qb * KS + f>(s_nxt[qb], kfr[f % RING]);
@@ -807,11 +831,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       constexpr int db = decltype(dbc)::value;
       acc_read_tuple<16 * (qb * DB + db)>(o_v[db]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o_v[db][r] *= o_lag[qb];
+      for (int r = 0; r < 16; ++r) o_v[db][r] = o_v[db][r];
     });
     const float l_tot = half_sum(l_run[qb][0] + l_run[qb][1]);
     const bool dead = (l_tot == 0.f) || (l_tot != l_tot);
-    const float inv = dead ? 1.f : 1.f / l_tot;
+    const float inv = (dead ? 1.f : 1.f / l_tot) * o_lag[qb];   // normalisation and the pending rescale factor in one multiply per element
     const int row0 = w_row0 + 32 * qb;
     if (row0 < sq) {
       // 32 rows through this wave's staging rows, then whole-row stores through the block's O descriptor: rows past the sequence

@@ -45,12 +45,27 @@ template <int N0, int... I> FA_DEVINL void acc_scale_range(float f, std::integer
   ((I % 2 == 0 ? acc_scale2<N0 + I>(f) : (void)0), ...);
 }
 template <int N0, int... I> FA_DEVINL void acc_zero_range(std::integer_sequence<int, I...>) { (acc_write<N0 + I>(0.f), ...); }
+// accumulator tuples T0 .. (16 registers each) = 0 by the matrix pipe: D = 0 . 0 + 0 (zf = four zero registers, freshly written: two wait states first)
+template <int T> FA_DEVINL void acc_zero_tuple_mfma(const u32x4& zf) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], %0, %0, 0" : : "v"(zf), "i"(16 * T), "i"(16 * T + 15) : FA_W64_CLOB);
+}
+template <int T0, int... I> FA_DEVINL void acc_zero_tuples_mfma(const u32x4& zf, std::integer_sequence<int, I...>) {
+  asm volatile("s_nop 1" : : "v"(zf));
+  (acc_zero_tuple_mfma<T0 + I>(zf), ...);
+}
 // (elements are copied to scalars first: __builtin_bit_cast applied directly to an ext_vector element lvalue reads element 0)
+template <int N0> FA_DEVINL void acc_read8(float (&y)[8]) {   // eight registers per statement (hipcc pads every asm statement with an s_nop)
+  asm volatile("v_accvgpr_read_b32 %0, a[%c8]\n\tv_accvgpr_read_b32 %1, a[%c9]\n\tv_accvgpr_read_b32 %2, a[%c10]\n\tv_accvgpr_read_b32 %3, a[%c11]\n\t"
+               "v_accvgpr_read_b32 %4, a[%c12]\n\tv_accvgpr_read_b32 %5, a[%c13]\n\tv_accvgpr_read_b32 %6, a[%c14]\n\tv_accvgpr_read_b32 %7, a[%c15]"
+               : "=v"(y[0]), "=v"(y[1]), "=v"(y[2]), "=v"(y[3]), "=v"(y[4]), "=v"(y[5]), "=v"(y[6]), "=v"(y[7])
+               : "i"(N0), "i"(N0 + 1), "i"(N0 + 2), "i"(N0 + 3), "i"(N0 + 4), "i"(N0 + 5), "i"(N0 + 6), "i"(N0 + 7) : FA_W64_CLOB);
+}
 template <int N0> FA_DEVINL void acc_read_tuple(f32x16& x) {
-  x[0] = acc_read<N0 + 0>(); x[1] = acc_read<N0 + 1>(); x[2] = acc_read<N0 + 2>(); x[3] = acc_read<N0 + 3>();
-  x[4] = acc_read<N0 + 4>(); x[5] = acc_read<N0 + 5>(); x[6] = acc_read<N0 + 6>(); x[7] = acc_read<N0 + 7>();
-  x[8] = acc_read<N0 + 8>(); x[9] = acc_read<N0 + 9>(); x[10] = acc_read<N0 + 10>(); x[11] = acc_read<N0 + 11>();
-  x[12] = acc_read<N0 + 12>(); x[13] = acc_read<N0 + 13>(); x[14] = acc_read<N0 + 14>(); x[15] = acc_read<N0 + 15>();
+  float lo[8], hi[8];
+  acc_read8<N0>(lo);
+  acc_read8<N0 + 8>(hi);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { x[i] = lo[i]; x[8 + i] = hi[i]; }
 }
 template <int N0> FA_DEVINL void acc_write_frag(u32x4 w) {
   const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
