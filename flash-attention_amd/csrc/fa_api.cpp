@@ -156,14 +156,16 @@ bool w64_span_ok(const FaFwdParams* a) {
   return ((uint64_t)(a->seqlen_k > 0 ? a->seqlen_k : 1) + 128) * rs * 2u < (1ull << 32);
 }
 int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
-  // Schedule (measured on MI355X, tools/ab_bench.py, profiles/r02_fwd_schedules.txt; FA_FWD_NW overrides):
-  //   head dim 128, key loops of >= 32 tiles of 64 keys per query block on average (non-causal S >= 2048, causal S >= 4096 --
-  //   config 3 included) and >= 512 query rows: the 64-rows-per-wave kernel (persistent 256-row workgroups, one per CU) -- its
-  //   steady state is 15-20 % faster than the pipelined kernels (1.19-1.26 vs 1.02-1.05 PFLOP/s at S = 16k); shorter loops
-  //   stay on the 4-wave pipelined kernel (Q fragments in registers, two workgroups per CU hide each other's prologue /
-  //   epilogue).  FA_STRICT keeps the pipelined kernels (fp32 scaling of every score).  D = 64 has half the MFMA work per
-  //   softmax element: the 64-rows-per-wave kernel wins from 64 key tiles on average (non-causal S >= 4096, causal S >= 8192;
-  //   profiles/r03_fwd_schedules.txt), the 4-wave pipelined kernel below.
+  // Schedule (measured on MI355X, tools/ab_bench.py, profiles/r03_fwd_schedules.txt; FA_FWD_NW overrides):
+  //   head dim 128, >= 512 query rows: the 64-rows-per-wave kernel (persistent 256-row workgroups, one per CU) from 8 key tiles of 64
+  //   keys per query block on average, as long as its 256-row blocks still fill the chip (>= 200 of them; key loops of >= 32 tiles
+  //   -- non-causal S >= 2048, causal S >= 4096, config 3 included -- take it regardless).  With round 3's per-block costs (one
+  //   iteration body, 7k-clock prologue) it beats the 4-wave pipelined kernel by 7 % at S = 1024, 14-21 % at S = 2048 and 19-23 %
+  //   from S = 4096 (1.20-1.24 vs 1.01-1.03 PFLOP/s non-causal); at S = 512 the two tie.  Shorter loops and small grids stay on the
+  //   4-wave pipelined kernel (Q fragments in registers, two 128-row workgroups per CU hide each other's prologue / epilogue).
+  //   FA_STRICT keeps the pipelined kernels (fp32 scaling of every score).  D = 64 has half the MFMA work per softmax element: the
+  //   64-rows-per-wave kernel wins from 32 key tiles on average without a right bound (S >= 2048: +1 %, S >= 4096: +12-16 %) and from
+  //   16 under a causal mask (S = 2048: +12 %, S = 1024: -3 %).
   //   K/V views whose key range spans >= 4 GiB (w64_span_ok) fall back from the 64-rows-per-wave kernel to the pipelined one,
   //   which addresses tile by tile.
   int nw = fa::knobs().fwd_nw;
@@ -172,9 +174,19 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
     const long avg_keys = right_bounded ? (a->seqlen_k + 1) / 2 : a->seqlen_k;
     const long span = (wl >= 0) ? std::min<long>(avg_keys, wl + (wr >= 0 ? wr : a->seqlen_k) + 256) : avg_keys;
     const long tiles = span / 64;
-    if (a->d == 128) nw = (tiles >= 32 && a->seqlen_q >= 512) ? (fa::knobs().strict ? (tiles >= 48 ? 38 : 34) : 64) : (a->seqlen_q > 128 ? 34 : 4);
-    else if (a->d == 64) nw = (tiles >= 64 && a->seqlen_q >= 512 && !fa::knobs().strict) ? 64 : (a->seqlen_q > 128 ? 34 : 4);   // r03_fwd_schedules.txt: +6..18 % from 64 tiles
-    else nw = (a->seqlen_q > 128) ? 34 : 4;
+    const long blocks256 = a->cu_seqlens_q ? (long)a->h * (a->total_q / 256 + 1) : (long)a->b * a->h * ((a->seqlen_q + 255) / 256);
+    const bool fills = blocks256 >= 200;
+    const int fallback = a->seqlen_q > 128 ? 34 : 4;
+    if (a->d == 128) {
+      const bool long_loop = tiles >= 32 && a->seqlen_q >= 512;
+      if (fa::knobs().strict) nw = long_loop ? (tiles >= 48 ? 38 : 34) : fallback;
+      else nw = (long_loop || (tiles >= 8 && a->seqlen_q >= 512 && fills)) ? 64 : fallback;
+    } else if (a->d == 64) {
+      const long need = right_bounded ? 16 : 32;
+      nw = (!fa::knobs().strict && a->seqlen_q >= 512 && (tiles >= 64 || (tiles >= need && fills))) ? 64 : fallback;
+    } else {
+      nw = fallback;
+    }
   }
   if (nw == 64 && !w64_span_ok(a)) nw = 38;
   return nw;
@@ -242,7 +254,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   k.k_bs = a->k_batch_stride; k.k_rs = a->k_row_stride; k.k_hs = a->k_head_stride;
   k.v_bs = a->v_batch_stride; k.v_rs = a->v_row_stride; k.v_hs = a->v_head_stride;
   k.o_bs = a->o_batch_stride; k.o_rs = a->o_row_stride; k.o_hs = a->o_head_stride;
-  k.cu_q = a->cu_seqlens_q; k.cu_k = a->cu_seqlens_k; k.seqused_k = a->seqused_k;
+  k.cu_q = a->cu_seqlens_q; k.cu_k = a->cu_seqlens_k; k.seqused_k = a->seqused_k; k.seqused_q = a->seqused_q;
   k.kv_batch_idx = a->cache_batch_idx; k.block_table = a->block_table; k.block_table_bs = a->block_table_batch_stride;
   k.page_size = a->page_block_size; k.seqused_add = a->seqused_k_add; k.leftpad_k = a->leftpad_k;
   k.alibi = a->alibi_slopes; k.alibi_bs = a->alibi_batch_stride;
@@ -370,7 +382,7 @@ int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
   k.dq_bs = a->dq_batch_stride; k.dq_rs = a->dq_row_stride; k.dq_hs = a->dq_head_stride;
   k.dk_bs = a->dk_batch_stride; k.dk_rs = a->dk_row_stride; k.dk_hs = a->dk_head_stride;
   k.dv_bs = a->dv_batch_stride; k.dv_rs = a->dv_row_stride; k.dv_hs = a->dv_head_stride;
-  k.cu_q = a->cu_seqlens_q; k.cu_k = a->cu_seqlens_k;
+  k.cu_q = a->cu_seqlens_q; k.cu_k = a->cu_seqlens_k; k.seqused_q = a->seqused_q; k.seqused_k = a->seqused_k;
   k.alibi = a->alibi_slopes; k.alibi_bs = a->alibi_batch_stride;
   k.b = a->b; k.h = a->h; k.h_k = a->h_k; k.hk_ratio = a->h / a->h_k;
   k.sq = a->seqlen_q; k.sk = a->seqlen_k; k.total_q = a->total_q; k.total_k = a->total_k;

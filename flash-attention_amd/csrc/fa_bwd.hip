@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
     do_boff = 0;
     o_boff = 0;
   }
+  if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
   const int row = blockIdx.x * ROWS + threadIdx.x / LPR;
   const int c = threadIdx.x % LPR;
   float acc = 0.f;
@@ -159,6 +160,8 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   int64_t k_boff = (int64_t)b * p.k_bs, v_boff = (int64_t)b * p.v_bs, dk_boff = (int64_t)b * p.dk_bs, dv_boff = (int64_t)b * p.dv_bs;
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; dk_boff = 0; dv_boff = 0; }
+  if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
+  if (p.seqused_k) sk = min(sk, p.seqused_k[b]);
   const int n0 = n_block * BNK;
   if (n0 >= sk) return;
   const int n1 = min(n0 + BNK, sk);
@@ -615,6 +618,8 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   int64_t k_boff = (int64_t)b * p.k_bs, v_boff = (int64_t)b * p.v_bs;
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; dq_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
+  if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
+  if (p.seqused_k) sk = min(sk, p.seqused_k[b]);
   const int m0 = m_block * BM;
   if (m0 >= sq) return;
 

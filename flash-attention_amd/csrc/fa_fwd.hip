@@ -125,6 +125,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_fwd_kernel(const 
     q_boff = 0;
     o_boff = 0;
   }
+  if (p.seqused_q) sq = min(sq, p.seqused_q[b]);  // padded batch: only the first seqused_q[b] rows of the entry exist
   if (p.cu_k) {
     const int c0 = p.cu_k[b];
     sk = p.cu_k[b + 1] - c0;

@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   int64_t q_boff = (int64_t)b * p.q_bs, k_boff = (int64_t)bkv * p.k_bs, v_boff = (int64_t)bkv * p.v_bs, o_boff = (int64_t)b * p.o_bs;
   if (p.block_table) { k_boff = 0; v_boff = 0; }  // paged cache: the page index supplies the first-dimension offset
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; o_boff = 0; }
+  if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
   if (p.block_table) k_row0 = 0;  // paged K/V: the page table supplies the rows, cu_seqlens_k only the lengths
   if (p.seqused_k) sk = min(p.seqused_k[b] + p.seqused_add, p.sk);  // keys in use, never beyond the addressable capacity

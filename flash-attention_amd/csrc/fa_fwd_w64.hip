@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     const int bkv = p.kv_batch_idx ? p.kv_batch_idx[k.b] : k.b;
     k.q_boff = (int64_t)k.b * p.q_bs; k.k_boff = (int64_t)bkv * p.k_bs; k.v_boff = (int64_t)bkv * p.v_bs; k.o_boff = (int64_t)k.b * p.o_bs;
     if (p.cu_q) { const int c0 = p.cu_q[k.b]; k.sq = p.cu_q[k.b + 1] - c0; k.q_row0 = c0; k.q_boff = 0; k.o_boff = 0; }
+    if (p.seqused_q) k.sq = min(k.sq, p.seqused_q[k.b]);
     if (p.cu_k) { const int c0 = p.cu_k[k.b]; k.sk = p.cu_k[k.b + 1] - c0; k.k_row0 = c0; k.k_boff = 0; k.v_boff = 0; }
     if (p.seqused_k) k.sk = min(p.seqused_k[k.b] + p.seqused_add, p.sk);
     if (p.leftpad_k) {

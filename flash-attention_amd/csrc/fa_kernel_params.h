@@ -19,6 +19,7 @@ struct FwdK {
   const int32_t* cu_q;       // nullptr => fixed length
   const int32_t* cu_k;
   const int32_t* seqused_k;  // optional: keys in use per batch entry (KV cache: cache_seqlens)
+  const int32_t* seqused_q;  // optional: queries in use per batch entry (padded batches: rows past it are neither read nor written)
   const int32_t* kv_batch_idx;   // optional: batch entry -> row of the KV cache (cache_batch_idx)
   const int32_t* block_table;    // optional: paged KV cache, (b, max_blocks) page indices
   int64_t block_table_bs;
@@ -79,6 +80,8 @@ struct BwdK {
   int64_t dv_bs, dv_rs, dv_hs;
   const int32_t* cu_q;
   const int32_t* cu_k;
+  const int32_t* seqused_q;  // optional: queries / keys in use per batch entry (padded batches), as FwdK
+  const int32_t* seqused_k;
   const float* alibi;
   int64_t alibi_bs;
   int32_t b, h, h_k, hk_ratio;

@@ -4,6 +4,7 @@ __version__ = "0.1.0"
 from .flash_attn_interface import (  # noqa: F401
     flash_attn_func,
     flash_attn_kvpacked_func,
+    flash_attn_padded_func,
     flash_attn_qkvpacked_func,
     flash_attn_varlen_func,
     flash_attn_varlen_kvpacked_func,

@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-FA_ABI_VERSION = 5
+FA_ABI_VERSION = 6
 FA_DTYPE_FP16, FA_DTYPE_BF16 = 0, 1
 FA_OK, FA_ERR_INVALID_ARGUMENT, FA_ERR_UNSUPPORTED, FA_ERR_LAUNCH, FA_ERR_WORKSPACE = 0, -1, -2, -3, -4
 
@@ -34,7 +34,7 @@ class FaFwdParams(C.Structure):
         ("page_block_size", _i32), ("num_splits", _i32), ("p_dropout", _f32), ("reserved0", _i32),
         ("rng_state", _vp), ("randval", _vp),
         ("randval_batch_stride", _i64), ("randval_head_stride", _i64), ("randval_row_stride", _i64),
-        ("workspace", _vp), ("workspace_bytes", _i64), ("leftpad_k", _vp),
+        ("workspace", _vp), ("workspace_bytes", _i64), ("leftpad_k", _vp), ("seqused_q", _vp),
     ]
 
 
@@ -80,7 +80,7 @@ class FaBwdParams(C.Structure):
         ("seqlen_q", _i32), ("seqlen_k", _i32), ("total_q", _i32), ("total_k", _i32),
         ("dtype", _i32), ("is_causal", _i32), ("window_left", _i32), ("window_right", _i32),
         ("softmax_scale", _f32), ("softcap", _f32), ("deterministic", _i32),
-        ("p_dropout", _f32), ("reserved", _i32 * 3), ("rng_state", _vp),
+        ("p_dropout", _f32), ("reserved", _i32 * 3), ("rng_state", _vp), ("seqused_q", _vp), ("seqused_k", _vp),
     ]
 
 

@@ -192,8 +192,10 @@ def fwd(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, windo
 def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_, block_table_,
                alibi_slopes_, max_seqlen_q, max_seqlen_k, p_dropout, softmax_scale, zero_tensors,
                is_causal, window_size_left, window_size_right, softcap, return_softmax, gen_,
-               num_splits: int = 0) -> List[torch.Tensor]:
-    """mha_varlen_fwd (flash_api.cpp:538-788): packed q (total_q,H,D), k/v (total_k,Hk,D), int32 cu_seqlens (B+1)."""
+               num_splits: int = 0, seqused_q: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """mha_varlen_fwd (flash_api.cpp:538-788): packed q (total_q,H,D), k/v (total_k,Hk,D), int32 cu_seqlens (B+1).
+    seqused_q (extension, not in the reference's signature): only the first seqused_q[b] rows of entry b are queries -- with seqused_k the
+    in-place form of a padded batch (flash_attn_interface.flash_attn_padded_func)."""
     _common_checks(q, k, v, p_dropout, alibi_slopes_, gen_)
     if return_softmax and not p_dropout > 0.0:
         raise RuntimeError("return_softmax is only supported when p_dropout > 0.0")
@@ -247,6 +249,9 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
         return [out, l2.reshape(Hk, B, ng).permute(0, 2, 1).reshape(H, B), p2, r2]
     if seqused_k is not None and (seqused_k.dtype != torch.int32 or seqused_k.numel() != B or not seqused_k.is_contiguous()):
         raise RuntimeError("seqused_k must be a contiguous int32 tensor of shape (batch_size)")
+    if seqused_q is not None and (seqused_q.dtype != torch.int32 or seqused_q.numel() != B or not seqused_q.is_contiguous()):
+        raise RuntimeError("seqused_q must be a contiguous int32 tensor of shape (batch_size)")
+    _check_dev(seqused_q)
     Dn = _native_d(D)
     qp, kp, vp = _pad_d(q, Dn), _pad_d(k, Dn), _pad_d(v, Dn)
     out = out_ if (out_ is not None and Dn == D) else torch.empty((total_q, H, Dn), dtype=q.dtype, device=q.device)
@@ -276,6 +281,7 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
         a.leftpad_k = _ptr(leftpad_k_)
         a.o_row_stride, a.o_head_stride = out.stride(0), out.stride(1)
         a.cu_seqlens_q, a.cu_seqlens_k, a.seqused_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k), _ptr(seqused_k)
+        a.seqused_q = _ptr(seqused_q)
         a.alibi_slopes, a.alibi_batch_stride = _ptr(alibi), alibi_bs
         a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
         a.seqlen_q, a.seqlen_k, a.total_q = int(max_seqlen_q), int(max_seqlen_k), total_q
@@ -392,9 +398,10 @@ def bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, alibi_slopes_, p_dropout
 
 def varlen_bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, cu_seqlens_q, cu_seqlens_k,
                alibi_slopes_, max_seqlen_q, max_seqlen_k, p_dropout, softmax_scale, zero_tensors,
-               is_causal, window_size_left, window_size_right, softcap, deterministic, gen_, rng_state
-               ) -> List[torch.Tensor]:
-    """mha_varlen_bwd (flash_api.cpp:1010-1241) -> [dq, dk, dv, softmax_d]."""
+               is_causal, window_size_left, window_size_right, softcap, deterministic, gen_, rng_state,
+               seqused_q: Optional[torch.Tensor] = None, seqused_k: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """mha_varlen_bwd (flash_api.cpp:1010-1241) -> [dq, dk, dv, softmax_d].  seqused_q / seqused_k (extension): as in varlen_fwd; gradient
+    rows past them are not written."""
     _common_checks(q, k, v, p_dropout, alibi_slopes_, gen_)
     _check_dev(dout, out, softmax_lse, cu_seqlens_q, cu_seqlens_k)
     for cu in (cu_seqlens_q, cu_seqlens_k):
@@ -415,7 +422,8 @@ def varlen_bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, cu_seqlens_q, cu_
     Dn = _native_d(D)
     if Dn != D:
         dop, qp, kp, vp, op = (_pad_d(t, Dn) for t in (dout, q, k, v, out))
-        dqp, dkp, dvp = (torch.empty(t.shape[:-1] + (Dn,), dtype=t.dtype, device=t.device) for t in (q, k, v))
+        alloc = torch.zeros if zero_tensors else torch.empty
+        dqp, dkp, dvp = (alloc(t.shape[:-1] + (Dn,), dtype=t.dtype, device=t.device) for t in (q, k, v))
     else:
         dop, qp, kp, vp, op, dqp, dkp, dvp = dout, q, k, v, out, dq, dk, dv
     alibi, alibi_bs = _alibi_args(alibi_slopes_, B, H)
@@ -426,6 +434,11 @@ def varlen_bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, cu_seqlens_q, cu_
         setattr(a, nm + "_row_stride", t.stride(0))
         setattr(a, nm + "_head_stride", t.stride(1))
     a.cu_seqlens_q, a.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
+    for nm, t in (("seqused_q", seqused_q), ("seqused_k", seqused_k)):
+        if t is not None and (t.dtype != torch.int32 or t.numel() != B or not t.is_contiguous()):
+            raise RuntimeError(nm + " must be a contiguous int32 tensor of shape (batch_size)")
+    _check_dev(seqused_q, seqused_k)
+    a.seqused_q, a.seqused_k = _ptr(seqused_q), _ptr(seqused_k)
     a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
     a.seqlen_q, a.seqlen_k, a.total_q, a.total_k = int(max_seqlen_q), int(max_seqlen_k), total_q, total_k
     rng = _bwd_rng(p_dropout, rng_state, q.device)

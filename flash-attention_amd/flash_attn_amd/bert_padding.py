@@ -11,7 +11,8 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-__all__ = ["index_first_axis", "index_put_first_axis", "unpad_input", "unpad_input_for_concatenated_sequences", "pad_input"]
+__all__ = ["index_first_axis", "index_put_first_axis", "unpad_input", "unpad_input_for_concatenated_sequences", "pad_input",
+           "padded_batch_args", "padded_batch_is_contiguous"]
 
 
 def index_first_axis(x: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
@@ -65,3 +66,24 @@ def pad_input(hidden_states: torch.Tensor, indices: torch.Tensor, batch: int, se
     """(total, ...) -> (batch, seqlen, ...) with zeros at the padding positions."""
     out = index_put_first_axis(hidden_states, indices, batch * seqlen)
     return out.reshape((batch, seqlen) + tuple(hidden_states.shape[1:]))
+
+
+def padded_batch_args(attention_mask: torch.Tensor):
+    """(batch, seqlen) mask (1 = valid) of a LEFT- or RIGHT-padded batch -> (seqlens int32 (batch,), starts int32 (batch,)): entry b's tokens
+    are the rows starts[b] .. starts[b] + seqlens[b] - 1.  The arguments of ``flash_attn_padded_func`` (attention over the padded tensors in
+    place, no unpad_input / pad_input passes); computed on the device without a host synchronisation.  The valid tokens of an entry must be
+    one contiguous run -- what left or right padding produces; a mask with holes needs ``unpad_input`` (``padded_batch_is_contiguous``
+    checks, at the price of a synchronisation)."""
+    m = attention_mask.to(torch.bool)
+    seqlens = m.sum(dim=-1, dtype=torch.int32)
+    starts = m.to(torch.int8).argmax(dim=-1).to(torch.int32)   # index of the first valid token (0 for an empty entry)
+    return seqlens, starts
+
+
+def padded_batch_is_contiguous(attention_mask: torch.Tensor) -> bool:
+    """True iff every entry's valid tokens form one contiguous run (synchronises)."""
+    m = attention_mask.to(torch.bool)
+    seqlens, starts = padded_batch_args(m)
+    pos = torch.arange(m.shape[1], device=m.device, dtype=torch.int32)[None, :]
+    run = (pos >= starts[:, None]) & (pos < (starts + seqlens)[:, None])
+    return bool((run == m).all().item())

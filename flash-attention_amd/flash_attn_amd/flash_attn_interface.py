@@ -23,7 +23,7 @@ except ImportError:  # same C ABI through ctypes (raises if libfa_gfx950.so is m
 
 __all__ = [
     "flash_attn_func", "flash_attn_varlen_func", "flash_attn_qkvpacked_func", "flash_attn_kvpacked_func",
-    "flash_attn_varlen_qkvpacked_func", "flash_attn_varlen_kvpacked_func", "flash_attn_with_kvcache",
+    "flash_attn_varlen_qkvpacked_func", "flash_attn_varlen_kvpacked_func", "flash_attn_with_kvcache", "flash_attn_padded_func",
     "_flash_attn_forward", "_flash_attn_backward", "_flash_attn_varlen_forward", "_flash_attn_varlen_backward",
 ]
 
@@ -250,6 +250,71 @@ class _VarlenAttnFn(torch.autograd.Function):
         _flash_attn_varlen_backward(dout_p, q, k, v, out, lse, dq, dk, dv, cu_q, cu_k, mq, mk, dropout_p, softmax_scale,
                                     causal, window_size[0], window_size[1], softcap, alibi_slopes, deterministic, rng_state)
         return (dq[..., :d_orig], dk[..., :d_orig], dv[..., :d_orig]) + (None,) * 14
+
+
+class _PaddedAttnFn(torch.autograd.Function):
+    """Attention over a PADDED batch, in place: the reference's unpad_input -> flash_attn_varlen_func -> pad_input chain
+    (flash_attn/bert_padding.py:98-128, 204-218; e.g. flash_attn/modules/mha.py) without its gather and scatter passes.  The varlen
+    kernels address entry b at row b*S + start[b] of the flattened (B*S, H, D) tensors and stop after seqlens[b] rows (C ABI v6:
+    seqused_q / seqused_k next to cu_seqlens); padded rows are never read, their outputs and gradients are zero."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cu_q, len_q, cu_k, len_k, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                deterministic):
+        from . import backend as be   # (the extension module keeps the reference's positional signatures; the extra arguments go through the ctypes binder)
+        B, Sq, H, D = q.shape
+        Sk = k.shape[1]
+        if softmax_scale is None:
+            softmax_scale = D ** (-0.5)
+        q, k, v = _pad_head_dim(q, k, v)
+        qf, kf, vf = (_unit_stride_last(t).reshape(-1, t.shape[2], t.shape[3]) for t in (q, k, v))
+        out, lse, _, rng_state = be.varlen_fwd(qf, kf, vf, None, cu_q, cu_k, len_k, None, None, alibi_slopes, Sq, Sk, dropout_p,
+                                               softmax_scale, True, causal, window_size[0], window_size[1], softcap, False, None, 0,
+                                               seqused_q=len_q)
+        if any(t.requires_grad for t in (q, k, v)):
+            ctx.save_for_backward(qf, kf, vf, out, lse, cu_q, len_q, cu_k, len_k, rng_state)
+            ctx.cfg = (Sq, Sk, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic, D, q.shape, k.shape)
+        return out.reshape(B, Sq, H, -1)[..., :D]
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import backend as be
+        qf, kf, vf, out, lse, cu_q, len_q, cu_k, len_k, rng_state = ctx.saved_tensors
+        Sq, Sk, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic, d_orig, q_shape, k_shape = ctx.cfg
+        (dout_p,) = _pad_head_dim(dout) if dout.shape[-1] % 8 else (dout,)
+        dof = dout_p.contiguous().reshape(-1, dout_p.shape[2], dout_p.shape[3])
+        dq, dk, dv, _ = be.varlen_bwd(dof, qf, kf, vf, out, lse, None, None, None, cu_q, cu_k, alibi_slopes, Sq, Sk, dropout_p,
+                                      softmax_scale, True, causal, window_size[0], window_size[1], softcap, deterministic, None,
+                                      rng_state, seqused_q=len_q, seqused_k=len_k)
+        return (dq.reshape(q_shape)[..., :d_orig], dk.reshape(k_shape)[..., :d_orig], dv.reshape(k_shape)[..., :d_orig]) + (None,) * 11
+
+
+def flash_attn_padded_func(q, k, v, seqlens_q, seqlens_k=None, starts_q=None, starts_k=None, dropout_p=0.0, softmax_scale=None,
+                           causal=False, window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False):
+    """Fused unpad -> attention -> pad.  q (B,Sq,H,D); k, v (B,Sk,Hk,D), PADDED: the tokens of entry b are rows
+    starts[b] .. starts[b] + seqlens[b] - 1 (int32 device tensors of shape (B,); starts default to 0 = right padding, seqlens_k /
+    starts_k default to the query's: self-attention).  ``bert_padding.padded_batch_args(attention_mask)`` derives them from a
+    left- or right-padded mask without a host synchronisation.  Masks (causal, window) are aligned per entry exactly as
+    flash_attn_varlen_func aligns them on the unpadded sequences.  Returns out (B,Sq,H,D) with zeros in the padded rows -- the result
+    of pad_input(flash_attn_varlen_func(unpad_input(..))) without the three gather / scatter passes and the unpadded copies."""
+    B, Sq = q.shape[0], q.shape[1]
+    Sk = k.shape[1]
+
+    def _args(S, lens, starts):
+        lens = lens.to(torch.int32).contiguous()
+        cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device=q.device)
+        if starts is not None:
+            cu[:B] += starts.to(torch.int32)
+        return cu, lens
+
+    if seqlens_k is None:
+        if Sk != Sq:
+            raise ValueError("seqlens_k is required when k is padded to a different length than q")
+        seqlens_k, starts_k = seqlens_q, (starts_q if starts_k is None else starts_k)
+    cu_q, len_q = _args(Sq, seqlens_q, starts_q)
+    cu_k, len_k = _args(Sk, seqlens_k, starts_k)
+    return _PaddedAttnFn.apply(q, k, v, cu_q, len_q, cu_k, len_k, dropout_p, softmax_scale, causal, tuple(window_size), softcap,
+                               alibi_slopes, deterministic)
 
 
 def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), softcap=0.0,

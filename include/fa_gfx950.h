@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 5
+#define FA_ABI_VERSION 6
 
 enum { FA_DTYPE_FP16 = 0, FA_DTYPE_BF16 = 1 };
 
@@ -100,6 +100,12 @@ typedef struct FaFwdParams {
   const int32_t* leftpad_k;         /* fa_varlen_fwd / fa_fwd_kvcache, optional (B): the keys of entry b start at row leftpad_k[b];
                                        lengths (seqused_k / cu_seqlens_k) count from row 0 (reference block_info.h:17-36);
                                        not together with block_table */
+  const int32_t* seqused_q;         /* ABI v6, fa_fwd / fa_varlen_fwd, optional (B): only the first seqused_q[b] query rows of entry b exist
+                                       (the rest of its rows -- cu_seqlens_q[b+1] - cu_seqlens_q[b], or seqlen_q -- are padding: never
+                                       read, their o / softmax_lse rows never written).  With cu_seqlens_q[b] = b*S + first valid row and
+                                       seqused_q / seqused_k = the valid lengths, a PADDED (B,S,H,D) batch runs in place: the gather /
+                                       scatter passes of the reference's unpad_input / pad_input (flash_attn/bert_padding.py:98-128,
+                                       204-218) disappear */
 } FaFwdParams;
 
 /* Append step of the KV-cache path: copy knew/vnew (B, S_new, Hk, D) into the cache at rows
@@ -182,6 +188,8 @@ typedef struct FaBwdParams {
   float p_dropout;              /* as in the forward call                                  */
   int32_t reserved[3];
   const uint64_t* rng_state;    /* device {seed, offset} the forward used (p_dropout > 0) */
+  const int32_t* seqused_q;     /* ABI v6, optional (B): as FaFwdParams::seqused_q; dq rows past it are not written */
+  const int32_t* seqused_k;     /* ABI v6, optional (B): keys of entry b in use; dk / dv rows past it are not written */
 } FaBwdParams;
 
 /* ABI version of the loaded library (== FA_ABI_VERSION of the header it was built from). */

@@ -49,3 +49,16 @@ def test_unpad_for_concatenated_sequences_matches_the_documented_example_and_the
         x = torch.randn(4, 9, 2, 8)
         a, b = ours(x, mil), ref.unpad_input_for_concatenated_sequences(x, mil)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3]
+
+
+def test_padded_batch_args_left_and_right_padding():
+    from flash_attn_amd.bert_padding import padded_batch_args, padded_batch_is_contiguous, unpad_input
+    m = torch.tensor([[1, 1, 1, 0, 0], [0, 0, 1, 1, 1], [0, 0, 0, 0, 0], [1, 1, 1, 1, 1]], dtype=torch.bool)
+    lens, starts = padded_batch_args(m)
+    assert lens.tolist() == [3, 3, 0, 5] and starts.tolist() == [0, 2, 0, 0] and lens.dtype == torch.int32
+    assert padded_batch_is_contiguous(m)
+    assert not padded_batch_is_contiguous(torch.tensor([[1, 0, 1, 0]], dtype=torch.bool))
+    # rows starts[b] .. starts[b] + lens[b] - 1 of the flattened batch are exactly unpad_input's indices
+    S = m.shape[1]
+    rows = torch.cat([torch.arange(int(s), int(s + n)) + b * S for b, (n, s) in enumerate(zip(lens, starts))])
+    assert rows.tolist() == unpad_input(torch.zeros(4, 5, 1), m)[1].tolist()

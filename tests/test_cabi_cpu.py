@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_ctypes_mirror_matches_c_structs(built):
     from flash_attn_amd import _cabi
     lib = _cabi.load()
-    assert lib.fa_abi_version() == _cabi.FA_ABI_VERSION == 5
+    assert lib.fa_abi_version() == _cabi.FA_ABI_VERSION == 6
     assert lib.fa_sizeof_kvappend_params() == ctypes.sizeof(_cabi.FaKvAppendParams)
     assert lib.fa_sizeof_fwd_params() == ctypes.sizeof(_cabi.FaFwdParams)
     assert lib.fa_sizeof_bwd_params() == ctypes.sizeof(_cabi.FaBwdParams)
