@@ -117,7 +117,7 @@ template <typename K> void fill_dropout(K& k, float p_dropout, const uint64_t* r
 // Split-KV schedule of the decode path (reference num_splits_heuristic, flash_api.cpp:275-347, re-derived for 256 CUs
 // with two workgroups each): split only single-block query lengths whose (batch x head) grid leaves most CUs idle,
 // into the fewest key splits that give every CU two workgroups; a split is a whole number of 64-key tiles.
-// Head packing on the KV-cache path (FwdK::pack_g; the reference packs only the single-row decode step by reshaping q,
+// Head packing on the fixed-length forward and the KV-cache path (FwdK::pack_g; the reference packs only the single-row decode step by reshaping q,
 // flash_api.cpp:429-437 -- FA3 generalises it as PackGQA, hopper/pack_gqa.h): when all g query heads of a KV group times the
 // query rows fit one 128-row block, the group's heads become rows of that block and K/V are streamed once per KV head instead
 // of once per query head.  Returns g (1 = no packing).
@@ -277,7 +277,9 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   if (a->dtype == FA_DTYPE_FP16 && k.rescale_thr > 15.f) k.rescale_thr = 15.f;
 
   int nw = fwd_schedule_nw(a, wl, wr);
-  const int pack = kvcache ? pack_group(a) : 1;
+  // (fa_fwd too: a short query chunk with grouped heads is the same problem without a cache -- FA3's PackGQA covers prefill, hopper/pack_gqa.h;
+  // packed varlen batches keep one block per head)
+  const int pack = (kvcache || !varlen) ? pack_group(a) : 1;
   if (pack > 1) {  // grouped query heads become rows of one block (4-wave lock-step kernel)
     k.pack_g = pack; k.h = a->h_k; k.hk_ratio = 1; k.sq = a->seqlen_q * pack;
     nw = 4;

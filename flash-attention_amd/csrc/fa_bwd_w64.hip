@@ -27,6 +27,15 @@
 #define FA_W64_CLOB FA_W64_ACC_CLOBBERS_256
 #include "fa_w64_asm.h"
 
+#ifndef FA_BW64_CDELTA
+#define FA_BW64_CDELTA 0
+#endif
+#ifndef FA_BW64_WAIT2
+#define FA_BW64_WAIT2 1
+#endif
+#ifndef FA_BW64_AH
+#define FA_BW64_AH 2   // (3 with the paired waits costs five spilled registers; the forward measured no difference between 1 and 4)
+#endif
 #ifndef FA_BW64_ABL
 #define FA_BW64_ABL 0  // timing ablations (results become wrong): 1 no exp2, 2 no LDS operand reads, 4 no K/V DMA after the
 #endif                 // first tiles, 8 no DMA wait / barrier per tile, 16 no packing
@@ -38,8 +47,16 @@ constexpr int BW_Q_BASE = 128;    // Q fragments: fragment F at a[128+4F : 131+4
 constexpr int BW_DO_BASE = 192;   // dO fragments, same indexing
 constexpr float kLog2eW = 1.4426950408889634f;
 
-// d(VGPR) = a(VGPR) . frag(AGPR a[BASE:BASE+3])            first k-step of a chain (C = inline constant 0)
-template <typename E, int BASE> FA_DEVINL void mfma_v_first(f32x16& d, u32x4 a) {
+// d(VGPR) = a(VGPR) . frag(AGPR a[BASE:BASE+3]) + c(VGPR)     first k-step of a chain: c = the lane's -LSE*log2e (score chain) or -delta (dP chain)
+// in all sixteen registers, so that the subtraction every element needs is done by the matrix pipe (as the forward's -m, fa_fwd_w64.hip)
+template <typename E, int BASE> FA_DEVINL void mfma_v_first(f32x16& d, u32x4 a, const f32x16& c) {
+  if constexpr (std::is_same<E, __bf16>::value)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c3:%c4], %2" : "=&v"(d) : "v"(a), "v"(c), "i"(BASE), "i"(BASE + 3) : FA_W64_CLOB);
+  else
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c3:%c4], %2" : "=&v"(d) : "v"(a), "v"(c), "i"(BASE), "i"(BASE + 3) : FA_W64_CLOB);
+}
+// the same with C = inline constant 0
+template <typename E, int BASE> FA_DEVINL void mfma_v_first0(f32x16& d, u32x4 a) {
   if constexpr (std::is_same<E, __bf16>::value)
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "i"(BASE), "i"(BASE + 3) : FA_W64_CLOB);
   else
@@ -128,6 +145,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   const int w_kmin = (p.wl >= 0) ? max(0, w_row0 + shift - p.wl) : 0;
   const int w_full_hi = (p.wr >= 0) ? min(sk - 1, w_row0 + shift + p.wr) : sk - 1;
   const int w_full_lo = (p.wl >= 0) ? (w_row1 + shift - p.wl) : 0;
+  const float cs = p.scale_log2;
   int lim_hi[QB], lim_lo[QB];
   float lse_l[QB], delta_l[QB];
 #pragma unroll
@@ -143,7 +161,6 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       delta_l[qb] = p.delta[base + my_row];
     }
   }
-  const float cs = p.scale_log2;
 
   auto step_active = [&](int i) __attribute__((always_inline)) {
     const int k0 = key_base + 32 * i;
@@ -175,7 +192,18 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       const int a = (fbase + qb * 32 * ROW_BYTES) ^ (ks << 5);
       const u32x4 xq = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)a;
       const u32x4 xd = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(a + DO_OFF);
-      acc_write_frag<BW_Q_BASE + 4 * f>(xq);
+      // Q is multiplied by softmax_scale*log2(e) here, once, and rounded to the input dtype (the forward's 64-rows-per-wave kernel
+      // does the same to its Q): scores leave the pipe ready for exp2
+      const V8 raw = bitcast_u32x4<V8>(xq);
+      V8 sc;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        f32x2 pr = {(float)raw[j], (float)raw[j + 1]};
+        pr *= f32x2{cs, cs};
+        sc[j] = (E)pr[0]; sc[j + 1] = (E)pr[1];
+      }
+      acc_write_frag<BW_Q_BASE + 4 * f>(__builtin_bit_cast(u32x4, sc));
       acc_write_frag<BW_DO_BASE + 4 * f>(xd);
     });
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -276,6 +304,22 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) { fA[qb][t] = u32x4{0u, 0u, 0u, 0u}; fB[qb][t] = u32x4{0u, 0u, 0u, 0u}; }
   }
+  // The score chains' C operand: -LSE*log2e broadcast (+inf LSE of a row past the end: -inf, P = 0).  (The dP chains could take -delta the same
+  // way -- FA_BW64_CDELTA -- but two more 32-register broadcasts do not fit: 352 bytes of scratch in the tile loop.)
+  f32x16 nlse[QB];
+#if FA_BW64_CDELTA
+  f32x16 ndel[QB];
+#endif
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      nlse[qb][r] = -lse_l[qb];
+#if FA_BW64_CDELTA
+      ndel[qb][r] = -delta_l[qb];
+#endif
+    }
+  }
   bool have_cur = false, have_prev = false;
 
   lds_dma_wait_all();
@@ -288,9 +332,12 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   };
   // dS_i of one element
   auto ds_elem = [&](float sv, float dpv, int qb) __attribute__((always_inline)) {
-    const float e = __builtin_fmaf(sv, cs, -lse_l[qb]);
-    const float pv = (FA_BW64_ABL & 1) ? e : fast_exp2(e);
+    const float pv = (FA_BW64_ABL & 1) ? sv : fast_exp2(sv);   // sv = s*scale*log2e - LSE*log2e, dpv = dP - delta: both subtractions rode in the chains' C operands
+#if FA_BW64_CDELTA
+    return pv * dpv;
+#else
     return pv * (dpv - delta_l[qb]);
+#endif
   };
   auto pack2 = [&](float x0, float x1) __attribute__((always_inline)) {
     using V2 = __attribute__((ext_vector_type(2))) E;
@@ -314,10 +361,15 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
         const u32x4 kf = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[ks] + HOFF);
         const u32x4 vf = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[ks] + HOFF + V_RING);
         if constexpr (ks == 0) {
-          mfma_v_first<E, BW_Q_BASE>(s_nxt[0], kf);
-          mfma_v_first<E, BW_Q_BASE + 4 * KS>(s_nxt[1], kf);
-          mfma_v_first<E, BW_DO_BASE>(dp_nxt[0], vf);
-          mfma_v_first<E, BW_DO_BASE + 4 * KS>(dp_nxt[1], vf);
+          mfma_v_first<E, BW_Q_BASE>(s_nxt[0], kf, nlse[0]);
+          mfma_v_first<E, BW_Q_BASE + 4 * KS>(s_nxt[1], kf, nlse[1]);
+#if FA_BW64_CDELTA
+          mfma_v_first<E, BW_DO_BASE>(dp_nxt[0], vf, ndel[0]);
+          mfma_v_first<E, BW_DO_BASE + 4 * KS>(dp_nxt[1], vf, ndel[1]);
+#else
+          mfma_v_first0<E, BW_DO_BASE>(dp_nxt[0], vf);
+          mfma_v_first0<E, BW_DO_BASE + 4 * KS>(dp_nxt[1], vf);
+#endif
         } else {
           mfma_v_acc<E, BW_Q_BASE + 4 * ks>(s_nxt[0], kf);
           mfma_v_acc<E, BW_Q_BASE + 4 * (KS + ks)>(s_nxt[1], kf);
@@ -376,7 +428,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
     constexpr bool MASK = decltype(maskc)::value != 0;
     constexpr int HOFF = half * 32 * ROW_BYTES;
     constexpr int QKG = 2 * KS, DQG = 4 * DB, NG = 2 * QKG + DQG;
-    constexpr int AH = 2, RNG = AH + 1;     // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
+    constexpr int AH = FA_BW64_AH, RNG = AH + 1;     // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
     constexpr int NF = 2 * KS + 2 * DB;     // fragment slots: KS K rows, KS V rows, 2*DB transposed K
     u32x4 fr[RNG];
     if (FA_BW64_ABL & 2) {
@@ -410,12 +462,24 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       constexpr int x = decltype(xc)::value;
       constexpr int f = x / 2, qb = x & 1;
       if constexpr (qb == 0) rd_frag(f + AH);
+#if FA_BW64_WAIT2
+      // one wait per TWO fragment slots (as fa_fwd_w64.hip): before the MFMAs of an even slot f, wait until slot f + 1 has landed too
+      if constexpr (qb == 0 && (f & 1) == 0 && f + 1 < NF) {
+        constexpr auto ops = [](int g) constexpr { return g < 2 * KS ? 1 : g < NF ? 2 : 0; };
+        constexpr int out = [&]() constexpr { int n = 0; for (int g = f + 2; g <= f + AH; ++g) n += ops(g); return n; }();
+        __builtin_amdgcn_s_waitcnt(0xC07F | (out << 8));
+      }
+#endif
       if constexpr (x < QKG) {
-        if constexpr (f == 0) mfma_v_first<E, BW_Q_BASE + 4 * (qb * KS)>(s_nxt[qb], fr[f % RNG]);
+        if constexpr (f == 0) mfma_v_first<E, BW_Q_BASE + 4 * (qb * KS)>(s_nxt[qb], fr[f % RNG], nlse[qb]);
         else mfma_v_acc<E, BW_Q_BASE + 4 * (qb * KS + f)>(s_nxt[qb], fr[f % RNG]);
       } else if constexpr (x < 2 * QKG) {
         constexpr int ks = f - KS;
-        if constexpr (ks == 0) mfma_v_first<E, BW_DO_BASE + 4 * (qb * KS)>(dp_nxt[qb], fr[f % RNG]);
+#if FA_BW64_CDELTA
+        if constexpr (ks == 0) mfma_v_first<E, BW_DO_BASE + 4 * (qb * KS)>(dp_nxt[qb], fr[f % RNG], ndel[qb]);
+#else
+        if constexpr (ks == 0) mfma_v_first0<E, BW_DO_BASE + 4 * (qb * KS)>(dp_nxt[qb], fr[f % RNG]);
+#endif
         else mfma_v_acc<E, BW_DO_BASE + 4 * (qb * KS + ks)>(dp_nxt[qb], fr[f % RNG]);
       } else {
         constexpr int op = f - 2 * KS;
@@ -423,11 +487,11 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       }
       if constexpr ((x & 1) && (x / 2) < DPW && !(FA_BW64_ABL & 4)) {
         constexpr int pc = x / 2;
-        const unsigned vo = dma_off[pc] + dma_toff;
+        // (the tile's byte offset rides in the scalar-offset operand, as in fa_fwd_w64.hip: no per-piece address add)
         if constexpr (pc == 0)
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(vo), "s"(dma_dst), "s"(dma_srd) : "memory");
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
         else
-          asm volatile("buffer_load_dwordx4 %0, %1, 0 offen offset:%c2 lds" : : "v"(vo), "s"(dma_srd), "i"(1024 * pc) : "memory");
+          asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2 lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
       }
 #pragma unroll
       for (int e = el_end(x); e < el_end(x + 1); ++e) {

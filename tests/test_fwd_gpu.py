@@ -212,3 +212,30 @@ def test_varlen_default_schedule_matches_per_sequence_within_rounding(be):
         o1, l1 = _fwd(be, q[None, s0:s1], k[None, s0:s1], v[None, s0:s1], True)
         assert max_abs(out[s0:s1].float(), o1[0].float()) < 1.6e-2
         assert max_abs(lse[:, s0:s1], l1[0]) < 1e-4
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("sq,h,hk", [(16, 8, 1), (7, 12, 4), (32, 8, 2), (64, 8, 4)])
+def test_fwd_packs_grouped_heads_of_short_query_chunks(knobs, sq, h, hk, causal):
+    """fa_fwd (no KV cache) packs the g = H / Hk query heads of a KV group into the rows of one block when g * Sq <= 128 (fa_api.cpp
+    pack_group; FA3 PackGQA, hopper/pack_gqa.h): bit for bit the unpacked call (same kernel, same arithmetic per row), and within tolerance of
+    the fp64 oracle."""
+    from flash_attn_amd import backend as be
+    from oracle import attention_oracle as orc
+    torch.manual_seed(3)
+    B, Sk, d = 2, 1500, 128
+    g = h // hk
+    q = torch.randn(B, sq, h, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, Sk, hk, d, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    run = lambda: be.fwd(q, k, v, None, None, 0.0, d ** -0.5, causal, -1, -1, 0.0, False, None)[:2]
+    out, lse = run()
+    assert be.last_schedule()["fwd_pack"] == g, be.last_schedule()
+    knobs.set("FA_PACK_GQA", 0)
+    out0, lse0 = run()
+    assert be.last_schedule()["fwd_pack"] == 1
+    knobs.unset("FA_PACK_GQA")
+    assert torch.equal(out, out0) and torch.equal(lse, lse0)
+    ref, lse_ref = orc.attention_fwd(q, k, v, d ** -0.5, causal)
+    assert float((out.float().cpu() - torch.from_numpy(ref).float()).abs().max()) < 2e-2
+    assert float((lse.cpu() - torch.from_numpy(lse_ref).float()).abs().max()) < 2e-3
