@@ -876,6 +876,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FA_W64_STAMP(62);
         abl_st = (lane == 63) ? (int)(wall_clock64() - abl_rt) : abl_st;
+        abl_st = (lane == 61) ? (int)(abl_rt & 0x3fffff) : abl_st;   // block start on the chip-wide 100 MHz clock (low 22 bits: exact in an fp32)
+        abl_st = (lane == 60) ? (int)blockIdx.x : abl_st;            // workgroup (persistent launch: the CU slot)
+        abl_st = (lane == 59) ? round : abl_st;
         if (w_row0 + lane < sq) lsep[w_row0 + lane] = (float)abl_st;
       }
 #else
