@@ -47,10 +47,13 @@
                       // 32 no K/V DMA after the first tiles, 64 row-sum adds lag their exp2 by one gap, 128 no LDS operand reads at all,
                       // 256 LSE output = shader clocks per MFMA of the wave's tile loop, 512 no DMA wait / barrier per tile,
                       // 1024 no decision (row-max finish + branch), 2048 LSE output = this wave's clock stamps (lane i = stamp i: 0 prologue
-                      // barrier passed, 1 Q converted, 2 K_0 landed, 3 tile loop starts, 4+u iteration u done, 62 O stored), tools/w64_stamps.py
+                      // barrier passed, 1 Q converted, 2 K_0 landed, 3 tile loop starts, 4+u iteration u done, 62 O stored), tools/w64_stamps.py; 16384 (with 2048): lanes 59-61 = round, workgroup, block start on the 100 MHz clock (tools/w64_timeline.py)
 
 // Gaps of a step that carry its LDS-DMA pieces (first gap, stride): where a piece is issued prices it between ~30 and ~180 clocks
 // (MI355X_MICROARCH.md "LDS-DMA piece issue cost"; profiles/r03_fwd_w64_dma_placement.txt)
+#ifndef FA_W64_LAGADD
+#define FA_W64_LAGADD 0   // (1: the row-sum adds lag their exp2 by one gap -- hipcc then places add and v_exp around the same MFMA again and pads it: no gain)
+#endif
 #ifndef FA_W64_WAIT2
 #define FA_W64_WAIT2 1
 #endif
@@ -660,14 +663,18 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       for (int e = el_end(x); e < el_end(x + 1); ++e) {
         const int eq = e >> 4, r = e & 15;
         pe[eq][r] = (FA_W64_ABL & 1) ? s_cur[eq][r] : fast_exp2(s_cur[eq][r]);
-        if (!(FA_W64_ABL & (2 | 64))) l_run[eq][r & 1] += pe[eq][r];
+        if (!(FA_W64_ABL & 2) && !FA_W64_LAGADD) l_run[eq][r & 1] += pe[eq][r];
 #if FA_W64_STAG
         asm volatile("" : "+v"(pe[eq][r]), "+v"(l_run[eq][r & 1]));   // (the slot branches end basic blocks: keep the gap's VALU in its gap)
 #endif
       }
-      if ((FA_W64_ABL & 64) && x > 0) {  // the adds of the PREVIOUS gap's elements
+      // (experiment: the row-sum adds lag their exp2 by one gap -- an add right behind the v_exp that feeds it costs a wait state, which hipcc
+      // pads with an s_nop even across the asm MFMA)
+      if (FA_W64_LAGADD && !(FA_W64_ABL & 2) && x > 0) {
 #pragma unroll
-        for (int e = el_end(x - 1); e < el_end(x); ++e) l_run[e >> 4][e & 1] += pe[e >> 4][e & 15];
+        for (int e = el_end(x - 1); e < el_end(x); ++e) {
+          l_run[e >> 4][e & 1] += pe[e >> 4][e & 15];
+        }
       }
       if constexpr (x >= QKG) {
         constexpr int y = x - QKG;  // gap inside the PV half
@@ -691,18 +698,27 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
           if (y >= g0 && y < g0 + 8 / UPG && !(FA_W64_ABL & 8)) {
 #pragma unroll
             for (int u = (y - g0) * UPG; u < (y - g0 + 1) * UPG; ++u)  // 16 values in 8 ops: max3(s0,s1,s2), 6 x max3(t,.,.), max(t,s15)
+              if (u == 7 && UPG == 1 && !(FA_W64_ABL & 1024)) {   // the tree's last maximum and the copy for the cross-half swap in one statement (no pad between them)
+                float t_in = tmax[mq], t_out, t_cp;
+                asm volatile("v_max_f32 %0, %2, %3\n\tv_mov_b32 %1, %0" : "=&v"(t_out), "=v"(t_cp) : "v"(t_in), "v"(s_nxt[mq][15]));
+                tmax[mq] = t_out; tcopy[mq] = t_cp;
+              } else
               tmax[mq] = u == 0 ? vmax3(s_nxt[mq][0], s_nxt[mq][1], s_nxt[mq][2])
                                 : u < 7 ? vmax3(tmax[mq], s_nxt[mq][2 * u + 1], s_nxt[mq][2 * u + 2]) : vmax2(tmax[mq], s_nxt[mq][15]);
           }
           // cross-half combine in two statements a gap apart: the copy, then swap + max (v_permlane32_swap wants two wait states
           // after the write of its operand: the gap's other instructions provide them, no s_nop)
-          if (y == hm_gap(mq) - 1 && !(FA_W64_ABL & (8 | 1024))) asm volatile("v_mov_b32 %0, %1" : "=v"(tcopy[mq]) : "v"(tmax[mq]));
+          if (y == hm_gap(mq) - 1 && UPG != 1 && !(FA_W64_ABL & (8 | 1024))) asm volatile("v_mov_b32 %0, %1" : "=v"(tcopy[mq]) : "v"(tmax[mq]));
           if (y == hm_gap(mq) && !(FA_W64_ABL & (8 | 1024)))
             asm volatile("v_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(tmax[mq]), "+v"(tcopy[mq]));
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
+    if (FA_W64_LAGADD && !(FA_W64_ABL & 2)) {   // the last gap's elements
+#pragma unroll
+      for (int e = el_end(NG - 1); e < el_end(NG); ++e) l_run[e >> 4][e & 1] += pe[e >> 4][e & 15];
+    }
     if (!(FA_W64_ABL & 1024)) {
 #pragma unroll
       for (int mq = 0; mq < QB; ++mq)
@@ -755,7 +771,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // Active iterations outside [m_lo, m_hi] hold a step that straddles a mask boundary
   const int m_lo = __builtin_amdgcn_readfirstlane((FA_W64_ABL & 4096) ? 0 : p_lo), m_hi = __builtin_amdgcn_readfirstlane((FA_W64_ABL & 4096) ? 0x3fffffff : p_hi);
   const unsigned step_k = (unsigned)(BN * 2) * (unsigned)p.k_rs, step_v = (unsigned)(BN * 2) * (unsigned)p.v_rs;
-  unsigned tk_c = 0u, tv_c = 0u;   // byte offsets of tiles u + 1 (K) and u (V), carried through the active loop
+  const int nmin_s = __builtin_amdgcn_readfirstlane(n_min);
   auto step_pair = [&](auto parc, int u) __attribute__((always_inline)) {
     constexpr int par = decltype(parc)::value;
     // K_{u+1} rides in the first step, V_u in the second.  A tile past the block's last one is requested like any other: past the last key
@@ -766,12 +782,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     q_trickle();
     const int us = __builtin_amdgcn_readfirstlane(u);   // (uniform by construction; said so)
     unsigned dst_k = (unsigned)((par ^ 1) * TILE_BYTES) + wave_dst, dst_v = (unsigned)((2 + par) * TILE_BYTES) + wave_dst;
-    unsigned tk_ = __builtin_amdgcn_readfirstlane(tk_c), tv_ = __builtin_amdgcn_readfirstlane(tv_c);   // (hipcc carries them in vector registers)
+    unsigned tk_ = (unsigned)(nmin_s + 1 + us) * step_k, tv_ = (unsigned)(nmin_s + us) * step_v;   // (two scalar multiplies: carried offsets end up in vector registers)
     int im32 = ((us - m_lo) | (m_hi - us)) >> 31;   // -1 outside [m_lo, m_hi] (arithmetic, not a compare + select: that one goes through a lane mask)
     dst_k = __builtin_amdgcn_readfirstlane(dst_k); dst_v = __builtin_amdgcn_readfirstlane(dst_v);
     im32 = __builtin_amdgcn_readfirstlane(im32);
     asm volatile("" : "+s"(tk_), "+s"(tv_), "+s"(dst_k), "+s"(dst_v), "+s"(im32));
-    tk_c += step_k; tv_c += step_v;
     // (each test on a freshly laundered scalar: as one hoisted boolean hipcc keeps a lane mask and spends five instructions per test)
     auto masked = [&]() __attribute__((always_inline)) { int c = im32; asm volatile("" : "+s"(c)); return c != 0; };
     if (__builtin_expect(masked(), 0)) set_mask(2 * u);
@@ -795,7 +810,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #pragma unroll 1
     for (; u < ua; ++u) idle_iter(u);
     if (active) {
-      tk_c = __builtin_amdgcn_readfirstlane((unsigned)(n_min + u + 1) * step_k); tv_c = __builtin_amdgcn_readfirstlane((unsigned)(n_min + u) * step_v);
 #pragma unroll 1
       for (;;) {
         step_pair(ICw<0>{}, u); ++u;
@@ -876,9 +890,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FA_W64_STAMP(62);
         abl_st = (lane == 63) ? (int)(wall_clock64() - abl_rt) : abl_st;
+#if FA_W64_ABL & 16384   // timeline (tools/w64_timeline.py): these lanes are iteration stamps of blocks with more than 54 iterations otherwise
         abl_st = (lane == 61) ? (int)(abl_rt & 0x3fffff) : abl_st;   // block start on the chip-wide 100 MHz clock (low 22 bits: exact in an fp32)
         abl_st = (lane == 60) ? (int)blockIdx.x : abl_st;            // workgroup (persistent launch: the CU slot)
         abl_st = (lane == 59) ? round : abl_st;
+#endif
         if (w_row0 + lane < sq) lsep[w_row0 + lane] = (float)abl_st;
       }
 #else

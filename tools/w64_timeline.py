@@ -1,4 +1,4 @@
-"""Per-workgroup timeline of the persistent fa_fwd_w64_kernel from its clock stamps (library built with -DFA_W64_ABL=2048): lane 60 = workgroup,
+"""Per-workgroup timeline of the persistent fa_fwd_w64_kernel from its clock stamps (library built with -DFA_W64_ABL=18432 = 2048 + 16384): lane 60 = workgroup,
 59 = round, 61 = block start and 63 = block duration on the chip-wide 100 MHz clock (10 ns units).  Prints, for config 3 (causal) and the same shape
 without a mask: kernel span, per-workgroup busy time (sum of block durations), gaps between a workgroup's blocks, spread of the finish times."""
 import os, sys
