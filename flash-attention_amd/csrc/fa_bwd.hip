@@ -27,12 +27,24 @@
 #include "fa_kernel_params.h"
 #include "fa_launch.h"
 
+#ifndef FA_BWD_WAIT2
+#define FA_BWD_WAIT2 1   // dK/dV kernel: one LDS wait per two MFMA ops, operand reads one slot further ahead
+#endif
 #ifndef FA_BWD_PF
-#define FA_BWD_PF 3    // dK/dV kernel: row-major LDS operands are read this many MFMA slots minus one ahead
+#define FA_BWD_PF (FA_BWD_WAIT2 ? 4 : 3)    // dK/dV kernel: row-major LDS operands are read this many MFMA slots minus one ahead
 #endif
 #ifndef FA_BWD_PFT
-#define FA_BWD_PFT 3   // same for the transposed operands of the dV / dK products
+#define FA_BWD_PFT (FA_BWD_WAIT2 ? 4 : 3)   // same for the transposed operands of the dV / dK products
 #endif
+// s_waitcnt lgkmcnt(n) with n known only after unrolling (the builtin wants a literal)
+#define FA_WAIT_LGKM_CASE(n) case n: __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8)); break;
+static __device__ __forceinline__ void wait_lgkm_le(int n) {
+  switch (n) {
+    FA_WAIT_LGKM_CASE(0) FA_WAIT_LGKM_CASE(1) FA_WAIT_LGKM_CASE(2) FA_WAIT_LGKM_CASE(3) FA_WAIT_LGKM_CASE(4) FA_WAIT_LGKM_CASE(5)
+    FA_WAIT_LGKM_CASE(6) FA_WAIT_LGKM_CASE(7) FA_WAIT_LGKM_CASE(8) FA_WAIT_LGKM_CASE(9) FA_WAIT_LGKM_CASE(10)
+    default: __builtin_amdgcn_s_waitcnt(0xC07F | (0 << 8)); break;
+  }
+}
 #ifndef FA_DKDV_SPLIT
 #define FA_DKDV_SPLIT 0  // experiment: 1 = head dims <= 128 also run 4-wave workgroups of 128 keys with 32-query tiles, two per CU
 #endif
@@ -348,10 +360,11 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
       const int ks = j >> 1;
       if ((FA_DKDV_ABL & 2) && j >= 2) { ra[j % PF] = ra[(j & 1) % PF]; if (j & 1) rb[ks & 1] = rb[0]; return; }
       if ((j & 1) == 0) {
-        ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (QB_OFF + sub) + (k0p ^ (ks << 5)));
+        ra[j % PF] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)((QB_OFF + sub) + (k0p ^ (ks << 5)));   // (byte offsets, not lds + ..: the segment base
+                                                                                                              // is 0 by construction, and as a pointer add it costs a v_add per read)
       } else {
-        ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (DOB_OFF + sub) + (k0p ^ (ks << 5)));
-        rb[ks & 1] = *(const u32x4 FA_LDS*)(lds + (kv0p ^ (ks << 5)));
+        ra[j % PF] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)((DOB_OFF + sub) + (k0p ^ (ks << 5)));
+        rb[ks & 1] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(kv0p ^ (ks << 5));
       }
     };
 #pragma unroll
@@ -359,6 +372,16 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
 #pragma unroll
     for (int j = 0; j < NOPS; ++j) {
       if (j + PF - 1 < NOPS) rd(j + PF - 1);
+#if FA_BWD_WAIT2
+      // one LDS wait per TWO ops (as the 64-rows-per-wave kernels): before an even op, wait until the operands of the odd op behind it have
+      // landed too -- everything requested later (ops j + 2 .. j + PF - 1: one read for an S op, two for a dP op) may stay in flight.
+      // hipcc models the explicit wait and emits none in front of the odd op.
+      if ((j & 1) == 0 && j + 1 < NOPS) {
+        int out = 0;
+        for (int g = j + 2; g <= j + PF - 1 && g < NOPS; ++g) out += (g & 1) ? 2 : 1;
+        wait_lgkm_le(out);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this op's MFMA
       const int ks = j >> 1;
       f32x16 c = (j & 1) ? dp : s;
@@ -481,8 +504,8 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
       const int db = (i >> 1) % DB, t = i / (2 * DB);
       if ((FA_DKDV_ABL & 4) && i >= 2) { tlo[i % PFT] = tlo[(i & 1) % PFT]; thi[i % PFT] = thi[(i & 1) % PFT]; return; }
       const int base = ((i & 1) ? QB_OFF : DOB_OFF) + sub + 16 * t * ROW_BYTES;
-      tlo[i % PFT] = lds_read_tr16(lds + base + (t0p ^ (db << 6)));
-      thi[i % PFT] = lds_read_tr16(lds + base + (t1p ^ (db << 6)));
+      tlo[i % PFT] = lds_read_tr16((const char FA_LDS*)(unsigned long)(unsigned)(base + (t0p ^ (db << 6))));
+      thi[i % PFT] = lds_read_tr16((const char FA_LDS*)(unsigned long)(unsigned)(base + (t1p ^ (db << 6))));
     };
     if (!FA_DKDV_CARRY) mid();
 #pragma unroll
@@ -494,6 +517,13 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
 #pragma unroll
     for (int i = 0; i < NOPS; ++i) {
       if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
+#if FA_BWD_WAIT2
+      if ((i & 1) == 0 && i + 1 < NOPS) {   // (two transpose reads per op)
+        int out = 0;
+        for (int g = i + 2; g <= i + PFT - 1 && g < NOPS; ++g) out += 2;
+        wait_lgkm_le(out);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       const int db = (i >> 1) % DB, t = i / (2 * DB);
       if ((FA_DKDV_ABL & 32) && i >= 2) continue;
@@ -761,7 +791,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
           const int k0p = opaque(k0);
           auto rd = [&](int j) __attribute__((always_inline)) {
             const int ks = j >> 1;
-            ra[j % PF] = *(const u32x4 FA_LDS*)(lds + (((j & 1) ? VB_OFF : KB_OFF) + sub) + (k0p ^ (ks << 5)));
+            ra[j % PF] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)((((j & 1) ? VB_OFF : KB_OFF) + sub) + (k0p ^ (ks << 5)));
           };
 #pragma unroll
           for (int j = 0; j < PF - 1; ++j) rd(j);
@@ -833,8 +863,8 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
           auto rd = [&](int i) __attribute__((always_inline)) {
             const int db = i % DB, t = i / DB;
             const int base = KB_OFF + sub + 16 * t * ROW_BYTES;
-            tlo[i % PFT] = lds_read_tr16(lds + base + (t0p ^ (db << 6)));
-            thi[i % PFT] = lds_read_tr16(lds + base + (t1p ^ (db << 6)));
+            tlo[i % PFT] = lds_read_tr16((const char FA_LDS*)(unsigned long)(unsigned)(base + (t0p ^ (db << 6))));
+            thi[i % PFT] = lds_read_tr16((const char FA_LDS*)(unsigned long)(unsigned)(base + (t1p ^ (db << 6))));
           };
 #pragma unroll
           for (int i = 0; i < PFT - 1; ++i) rd(i);
@@ -892,7 +922,7 @@ static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
   constexpr int smem = NWK * 32 * D * 2 + 4 * BMQ * D * 2 + 4 * BMQ * 4;
   auto kern = fa_bwd_dkdv_kernel<E, D, DV, FEAT>;
   static std::atomic<unsigned long long> attr_mask{0};
-  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem) != 0) return -1;
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;   // (operand reads address LDS by byte offset: the dynamic segment starts at 0)
   const long long total = p.k_list ? (long long)p.k_bound * p.h_k : units_grid(p.k_units, p.k_unit_size);
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NWK * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -925,7 +955,7 @@ static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2 + NW * 32 * 16;  // K/V double buffers (+ the row padding of the staged dQ epilogue)
   auto kern = fa_bwd_dq_kernel<E, D, DV, NW, FEAT>;
   static std::atomic<unsigned long long> attr_mask{0};
-  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem) != 0) return -1;
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;   // (operand reads address LDS by byte offset: the dynamic segment starts at 0)
   const long long total = p.q_list ? (long long)p.q_bound * p.h : units_grid(p.q_units, p.q_unit_size);
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
