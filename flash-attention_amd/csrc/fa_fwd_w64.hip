@@ -19,17 +19,23 @@
 // K/V double buffers (64 KB) + the staged Q block (64 KB).  K/V tiles arrive by LDS-DMA through a buffer descriptor
 // (buffer_load_dwordx4 ... lds: one M0 write per four 1-KiB pieces, immediate offsets walk both LDS and memory).
 //
-// Round 3: ONE code path.  With one wave per SIMD nothing overlaps a wave's once-per-block code, which runs at ~5 clocks per instruction,
-// and round 2's kernel had a lot of it (241 KB: four copies of the hand-placed iteration, compiler-ordered "generic" steps for the pipeline
-// fill / drain, masked step variants, twelve copies of the cold rescale code; per block 23k clocks of prologue, 10-17k for iteration 0,
-// 5.3k instead of 3.2k for every iteration with a masked or draining wave -- profiles/r03_fwd_w64_stamps.txt).  Now (50 KB):
-//   * one iteration body = two hand-placed steps, run-time K/V buffer parity carried by the LDS read bases (toggled per iteration);
+// Round 3: ONE code path, and fewer instructions.  With one wave per SIMD nothing overlaps a wave's own instruction stream: every instruction
+// of the tile loop costs ~4.7 clocks whatever it is (measured in both directions, profiles/r03_fwd_w64_ablations.txt), and the once-per-block
+// code runs at ~5 clocks per instruction.  Round 2's kernel had a lot of both (241 KB: four copies of the hand-placed iteration,
+// compiler-ordered "generic" steps for the pipeline fill / drain, masked step variants, twelve copies of the cold rescale code; per block
+// 23k clocks of prologue, 10-17k for iteration 0, 5.3k instead of 3.2k for every iteration with a masked or draining wave).  Now (53 KB):
+//   * one step body (two hand-placed steps = an iteration; the loop holds an even and an odd iteration so that the K/V buffer parity is
+//     a compile-time constant of the LDS reads' immediate offsets);
 //   * the same body fills and drains the pipeline: chains that score no real key read a zero-filled tile (a buffer descriptor of zero
 //     records "loads" zeros into LDS without touching memory; so do the rows of a partial last tile past the last key) and are masked;
-//   * masks live in the step's cold exit (the one of the rescale decision): in-place -inf + a second row-max tree, taken only by the
-//     iterations that straddle a mask boundary; the plain step carries one scalar OR for it;
+//   * masks ride in the score chain's C operand: set_mask() puts -inf into the -m broadcast of the masked (row, key) pairs before a step
+//     that straddles a mask boundary (two instructions per element from a per-lane bitmap, straight-line), the step itself -- its row-max
+//     tree, exp2 and decision -- runs unchanged; the cold exit of a step is the rescale alone;
+//   * an iteration's scalar preparation is eleven instructions (tile offsets as two multiplies, constant descriptors, an arithmetic mask
+//     flag), LDS waits are paired (one explicit s_waitcnt per two fragment slots, which hipcc models and then omits its own);
 //   * Q / O through buffer descriptors with 32-bit lane offsets (hoisted 64-bit addresses were spilled: a scratch reload waits on vmcnt(0),
-//     i.e. on every tile DMA in flight), the next block's Q trickled in a piece per iteration, block id carried from that prefetch.
+//     i.e. on every tile DMA in flight), the next block's Q trickled in a piece per iteration, block id carried from that prefetch; O zeroed
+//     by eight MFMAs, accumulator reads eight per asm statement (hipcc pads every asm statement with an s_nop).
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -730,7 +736,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // Iteration u (0 .. n_tiles) = two steps: 2u-1 and 2u score K_u (K buffer u & 1) and multiply by V_{u-1} (V buffer (u - 1) & 1);
   // K_{u+1} and V_u are DMA'd during it into the buffers it does not read.  ONE body runs every iteration a wave takes part in,
   // pipeline fill and drain included: a chain that scores no real key (step < 0 side of the fill never occurs -- the fill's first
-  // chain is step 0; steps past the wave's last key, past the last tile) gets C = -inf in every element (prep_c), its scores are
+  // chain is step 0; steps past the wave's last key, past the last tile) gets C = -inf in every element (set_mask), its scores are
   // -inf, its P is 0 and it never moves a maximum; the fill multiplies P = 0 by the zero tile the prologue put into V buffer 1.
   // That wastes four half-steps of MFMA work per wave and block, and replaces the compiler-ordered "generic" fill / drain steps of
   // round 2 -- which, with their own copies of the cold rescale code, made the kernel 240 KB and every once-per-block path an
@@ -738,8 +744,8 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // Waves outside their range (rows past the sequence end, the early-finishing waves of a block under a causal mask, windows) only
   // issue their share of the tile DMAs and meet the barriers.
   // Per wave the iterations 0 .. n_tiles fall into three consecutive ranges -- idle | active | idle -- walked by two tight loops (entered
-  // from a three-round phase loop); inside the active range the iterations outside [p_lo, p_hi] hold a step that straddles a mask
-  // boundary: their steps take the cold exit of decide_and_rescale.
+  // and the active loop between them); inside the active range the iterations outside [p_lo, p_hi] hold a step that straddles a mask
+  // boundary: set_mask() / clear_mask() run around their steps.
   int u_first = n_tiles + 1, u_last = n_tiles, p_lo = n_tiles + 1, p_hi = n_tiles;   // all idle
   if (wave_valid && n_tiles > 0) {
     const int a_lo = max(0, (w_kmin - key_base) >> 5);               // first / last step with a key this wave can see
