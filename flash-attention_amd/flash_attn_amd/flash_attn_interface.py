@@ -264,6 +264,7 @@ class _PaddedAttnFn(torch.autograd.Function):
         from . import backend as be   # (the extension module keeps the reference's positional signatures; the extra arguments go through the ctypes binder)
         B, Sq, H, D = q.shape
         Sk = k.shape[1]
+        needs_grad = any(t.requires_grad for t in (q, k, v))   # (before the head-dim padding: its outputs carry no grad flag in here)
         if softmax_scale is None:
             softmax_scale = D ** (-0.5)
         q, k, v = _pad_head_dim(q, k, v)
@@ -271,7 +272,7 @@ class _PaddedAttnFn(torch.autograd.Function):
         out, lse, _, rng_state = be.varlen_fwd(qf, kf, vf, None, cu_q, cu_k, len_k, None, None, alibi_slopes, Sq, Sk, dropout_p,
                                                softmax_scale, True, causal, window_size[0], window_size[1], softcap, False, None, 0,
                                                seqused_q=len_q)
-        if any(t.requires_grad for t in (q, k, v)):
+        if needs_grad:
             ctx.save_for_backward(qf, kf, vf, out, lse, cu_q, len_q, cu_k, len_k, rng_state)
             ctx.cfg = (Sq, Sk, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic, D, q.shape, k.shape)
         return out.reshape(B, Sq, H, -1)[..., :D]

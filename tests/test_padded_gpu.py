@@ -19,7 +19,7 @@ def _mask(B, S, mode, gen):
 
 @pytest.mark.parametrize("mode", ["right", "left"])
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("B,S,H,Hk,D", [(4, 384, 4, 2, 128), (3, 1100, 2, 2, 64), (5, 200, 4, 4, 96)])
+@pytest.mark.parametrize("B,S,H,Hk,D", [(4, 384, 4, 2, 128), (3, 1100, 2, 2, 64), (5, 200, 4, 4, 96), (2, 300, 2, 2, 100), (3, 260, 4, 1, 72)])
 def test_padded_matches_unpad_varlen_pad(mode, causal, B, S, H, Hk, D):
     from flash_attn_amd import flash_attn_padded_func, flash_attn_varlen_func
     from flash_attn_amd.bert_padding import pad_input, padded_batch_args, unpad_input
