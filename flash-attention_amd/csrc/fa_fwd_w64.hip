@@ -57,6 +57,9 @@
 
 // Gaps of a step that carry its LDS-DMA pieces (first gap, stride): where a piece is issued prices it between ~30 and ~180 clocks
 // (MI355X_MICROARCH.md "LDS-DMA piece issue cost"; profiles/r03_fwd_w64_dma_placement.txt)
+#ifndef FA_W64_MASKED_COPY
+#define FA_W64_MASKED_COPY 0
+#endif
 #ifndef FA_W64_LAGADD
 #define FA_W64_LAGADD 0   // (1: the row-sum adds lag their exp2 by one gap -- hipcc then places add and v_exp around the same MFMA again and pads it: no gain)
 #endif
@@ -795,11 +798,27 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     asm volatile("" : "+s"(tk_), "+s"(tv_), "+s"(dst_k), "+s"(dst_v), "+s"(im32));
     // (each test on a freshly laundered scalar: as one hoisted boolean hipcc keeps a lane mask and spends five instructions per test)
     auto masked = [&]() __attribute__((always_inline)) { int c = im32; asm volatile("" : "+s"(c)); return c != 0; };
+#if FA_W64_MASKED_COPY
+    // (experiment, off: one test per iteration, the masked iteration as a cold COPY of the two steps with the mask rewrites around them.  As with
+    // every step-variant attempt before it the copies' tuples meet the hot ones at the join: 75 vector spills, 160 bytes of scratch, v_accvgpr
+    // traffic in the copies and eight more pad s_nop in the hot steps.)
+    if (__builtin_expect(masked(), 0)) {
+      set_mask(2 * u);
+      fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
+      set_mask(2 * u + 1);
+      fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
+      clear_mask();
+    } else {
+      fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
+      fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
+    }
+#else
     if (__builtin_expect(masked(), 0)) set_mask(2 * u);
     fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
     if (__builtin_expect(masked(), 0)) set_mask(2 * u + 1);
     fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
     if (__builtin_expect(masked(), 0)) clear_mask();
+#endif
     iter_end();
   };
   auto idle_iter = [&](int u) __attribute__((always_inline)) {
