@@ -123,7 +123,7 @@ template <typename K> void fill_dropout(K& k, float p_dropout, const uint64_t* r
 // of once per query head.  Returns g (1 = no packing).
 int pack_group(const FaFwdParams* a) {
   const int g = a->h_k > 0 ? a->h / a->h_k : 1;
-  if (g <= 1 || !fa::knobs().pack_gqa || a->cu_seqlens_q || a->p_dropout > 0.f || a->seqlen_q < 1 || (long)a->seqlen_q * g > 128) return 1;
+  if (g <= 1 || !fa::knobs().pack_gqa || a->cu_seqlens_q || a->seqused_q || a->p_dropout > 0.f || a->seqlen_q < 1 || (long)a->seqlen_q * g > 128) return 1;
   return g;
 }
 int choose_splits(const FaFwdParams* a, int& split_tiles) {

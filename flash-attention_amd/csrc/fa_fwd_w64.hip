@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       // element (sign-extended bit -> select mask -> bit-field insert)
       const int rel_hi = min(lim_hi[mq] - k0m - 4 * hi, 31), rel_lo = max(lim_lo[mq] - k0m - 4 * hi, 0);
       const unsigned ones = (rel_hi - rel_lo >= 31) ? 0xffffffffu : ((2u << ((rel_hi - rel_lo) & 31)) - 1u);
-      unsigned bits = (rel_hi >= rel_lo) ? (ones << rel_lo) : 0u;
+      unsigned bits = (rel_hi >= rel_lo) ? (ones << (rel_lo & 31)) : 0u;   // (rel_lo > 31 only with rel_hi < rel_lo)
       asm volatile("" : "+v"(nb), "+v"(bits));
 #pragma unroll
       for (int r = 0; r < 16; r += 4) {
