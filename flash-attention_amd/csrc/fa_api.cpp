@@ -508,6 +508,28 @@ int fa_last_schedule(int32_t* out, int n) {
   return FA_SCHEDULE_FIELDS;
 }
 const char* fa_last_kernel_name(void) { return fa::last_schedule().name; }
+// (mirrors the schedule resolution of do_fwd for the entry points without a KV cache; kept separate so that the launch path stays as it was validated)
+int fa_fwd_schedule_query(const FaFwdParams* a, int varlen) {
+  if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+  if (int rc = check_common(a->b, a->h, a->h_k, a->d, a->dtype, a->softcap, true)) return rc;
+  int causal = a->is_causal, wl = a->window_left, wr = a->window_right;
+  normalize_window(a->seqlen_q, a->seqlen_k, a->alibi_slopes != nullptr, causal, wl, wr);
+  int nw = fwd_schedule_nw(a, wl, wr);
+  const int pack = !varlen ? pack_group(a) : 1;
+  if (pack > 1) nw = 4;
+  const int dk = head_dim_kernel(a->d);
+  const bool bounded = dk != a->d;
+  if (dk > 128 || head_dim_trimmed(dk) || bounded) nw = 4;
+  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && pack == 1 && !bounded;
+  if (nw == 64 && !(plain && !a->block_table)) nw = 8;
+  if ((nw == 34 || nw == 38) && !plain) nw -= 30;
+  return nw;
+}
+int fa_bwd_dq_schedule_query(const FaBwdParams* a) {
+  if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
+  if (int rc = check_common(a->b, a->h, a->h_k, a->d, a->dtype, a->softcap)) return rc;
+  return bwd_dq_schedule(a);
+}
 
 int fa_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, false); }
 int fa_varlen_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, true); }

@@ -216,6 +216,12 @@ void fa_knobs_reload(void);
 int fa_last_schedule(int32_t* out, int n);
 /* Name of the forward kernel instantiation of that call, e.g. "fa::fa_fwd_il_kernel<bf16,128,4,3>" ("" if none). */
 const char* fa_last_kernel_name(void);
+/* Host logic only (no launch, no pointer is dereferenced -- pointers count as flags: alibi_slopes, block_table, cu_seqlens_q, seqused_q): the forward
+ * schedule fa_fwd (varlen = 0) / fa_varlen_fwd (varlen = 1) would run for these parameters, as an FA_FWD_NW code -- 64 = 64-rows-per-wave kernel,
+ * 34 / 38 = software-pipelined kernel with 4 / 8 waves, 4 / 8 / 16 = lock-step kernel -- after the feature / head-dim / head-packing fallbacks; and the dQ
+ * schedule of the backward (4 / 8 waves x 32 rows, 64 = 4 waves x 64 rows).  Negative = FA_ERR_*.  For tests of the dispatch on a box without a GPU. */
+int fa_fwd_schedule_query(const FaFwdParams* params, int varlen);
+int fa_bwd_dq_schedule_query(const FaBwdParams* params);
 
 /* Forward, fixed-length batch.  cu_seqlens_* must be NULL.  `stream` is a hipStream_t. */
 int fa_fwd(const FaFwdParams* params, void* stream);

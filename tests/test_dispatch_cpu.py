@@ -1,0 +1,112 @@
+"""Host logic of the dispatch, on a box without a GPU: fa_fwd_schedule_query / fa_bwd_dq_schedule_query run the same heuristics the launch path uses
+(fa_api.cpp fwd_schedule_nw, pack_group, the feature / head-dim fallbacks, bwd_dq_schedule) and launch nothing.  The expectations are the measured
+choices of profiles/r03_fwd_schedules.txt and the BASELINE.json configurations."""
+import ctypes as C
+import os
+
+import pytest
+
+from flash_attn_amd import _cabi
+
+
+@pytest.fixture()
+def lib(monkeypatch):
+    for k in ("FA_FWD_NW", "FA_STRICT", "FA_BWD_DQ_NW", "FA_PACK_GQA"):
+        monkeypatch.delenv(k, raising=False)
+    L = _cabi.load()
+    L.fa_knobs_reload()
+    yield L
+    for k in ("FA_FWD_NW", "FA_STRICT", "FA_BWD_DQ_NW", "FA_PACK_GQA"):
+        os.environ.pop(k, None)
+    L.fa_knobs_reload()
+
+
+def fwd_params(B, Sq, Sk, H, Hk, D, causal=False, window=(-1, -1), bf16=True, **kw):
+    a = _cabi.FaFwdParams()
+    a.b, a.h, a.h_k, a.d = B, H, Hk, D
+    a.seqlen_q, a.seqlen_k, a.total_q = Sq, Sk, B * Sq
+    a.dtype = 1 if bf16 else 0
+    a.is_causal, a.window_left, a.window_right = int(causal), window[0], window[1]
+    a.softmax_scale = D ** -0.5
+    a.k_row_stride = a.v_row_stride = Hk * D
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def q(lib, a, varlen=0):
+    return lib.fa_fwd_schedule_query(C.byref(a), varlen)
+
+
+def test_bf16_dtype_code():
+    assert _cabi.FA_DTYPE_BF16 == 1 if hasattr(_cabi, "FA_DTYPE_BF16") else True
+
+
+def test_baseline_configs_pick_the_measured_schedules(lib):
+    assert q(lib, fwd_params(8, 2048, 2048, 16, 16, 64)) == 64                                   # config 2: D = 64, 32 key tiles, grid fills the chip
+    assert q(lib, fwd_params(4, 4096, 4096, 32, 32, 128, causal=True)) == 64                     # config 3 (the headline)
+    assert q(lib, fwd_params(2, 8192, 8192, 32, 8, 128, causal=True, window=(1024, 0))) == 34    # config 5: short windowed key range -> pipelined kernel
+    a = fwd_params(16, 4096, 4096, 16, 16, 128, causal=True, cu_seqlens_q=1, cu_seqlens_k=1)     # config 4-i (pointers only count as flags here)
+    a.total_q = 65536
+    assert q(lib, a, varlen=1) == 64
+
+
+def test_sweep_rows_and_grid_fill(lib):
+    for S, want_nc, want_c in ((512, 64, 34), (1024, 64, 64), (2048, 64, 64), (4096, 64, 64), (16384, 64, 64)):
+        B = max(1, 16384 // S)
+        assert q(lib, fwd_params(B, S, S, 16, 16, 128)) == want_nc, S
+        assert q(lib, fwd_params(B, S, S, 16, 16, 128, causal=True)) == want_c, S
+    assert q(lib, fwd_params(1, 1024, 1024, 4, 4, 128)) == 34          # 16 blocks of 256 rows cannot fill 256 CUs: 128-row blocks
+    assert q(lib, fwd_params(1, 16384, 16384, 2, 2, 128)) == 64        # long key loops take it regardless
+    assert q(lib, fwd_params(64, 128, 4096, 16, 16, 128)) == 4         # short query chunks: lock-step
+    assert q(lib, fwd_params(16, 1024, 1024, 16, 16, 64, causal=True)) == 34   # D = 64 under a causal mask needs 16 tiles on average
+    assert q(lib, fwd_params(8, 2048, 2048, 16, 16, 64, causal=True)) == 64
+
+
+def test_feature_and_head_dim_fallbacks(lib):
+    big = dict(B=4, Sq=4096, Sk=4096, H=32, Hk=32, D=128, causal=True)
+    assert q(lib, fwd_params(**big, softcap=30.0)) == 8                 # features: 8-wave lock-step on the same 256-row blocks
+    assert q(lib, fwd_params(**big, alibi_slopes=1)) == 8
+    assert q(lib, fwd_params(**big, p_dropout=0.1)) == 8
+    assert q(lib, fwd_params(**big, block_table=1)) == 8
+    for d in (32, 96, 192, 256, 72, 160):                               # trimmed / bounded / 256: the 4-wave lock-step kernel
+        assert q(lib, fwd_params(4, 4096, 4096, 32, 32, d, causal=True)) == 4, d
+    assert q(lib, fwd_params(2, 1024, 1024, 8, 8, 128, softcap=30.0)) == 4   # a pipelined choice with a feature: lock-step with the same wave count
+    assert q(lib, fwd_params(2, 16, 2048, 32, 8, 128)) == 4             # grouped heads of a short chunk are packed: 4-wave lock-step
+    assert q(lib, fwd_params(4, 4096, 4096, 32, 32, 200)) == 4         # between the built sizes: column-bounded, the 256 kernel
+    assert q(lib, fwd_params(4, 4096, 4096, 32, 32, 100)) < 0          # not a multiple of 8
+    assert q(lib, fwd_params(4, 4096, 4096, 32, 32, 264)) < 0          # beyond 256
+
+
+def test_knobs_override_and_strict(lib, monkeypatch):
+    a = fwd_params(4, 4096, 4096, 32, 32, 128, causal=True)
+    monkeypatch.setenv("FA_STRICT", "1"); lib.fa_knobs_reload()
+    assert q(lib, a) == 34                                              # fp32 scaling of every score: pipelined kernel (32 tiles on average)
+    assert q(lib, fwd_params(1, 16384, 16384, 16, 16, 128)) == 38
+    monkeypatch.delenv("FA_STRICT"); monkeypatch.setenv("FA_FWD_NW", "38"); lib.fa_knobs_reload()
+    assert q(lib, a) == 38
+    monkeypatch.setenv("FA_FWD_NW", "64"); lib.fa_knobs_reload()
+    assert q(lib, fwd_params(2, 300, 300, 4, 4, 128)) == 64
+    huge = fwd_params(1, 131072, 131072, 128, 128, 128)                 # K/V rows 32 KB apart: the key range spans > 4 GiB
+    assert q(lib, huge) == 38
+
+
+def test_backward_dq_schedule(lib, monkeypatch):
+    def bp(B, S, H, D, **kw):
+        a = _cabi.FaBwdParams()
+        a.b, a.h, a.h_k, a.d = B, H, H, D
+        a.seqlen_q = a.seqlen_k = S
+        a.total_q = a.total_k = B * S
+        a.dtype = 1
+        a.softmax_scale = D ** -0.5
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+    dq = lambda a: lib.fa_bwd_dq_schedule_query(C.byref(a))
+    assert dq(bp(4, 4096, 32, 128)) == 64
+    assert dq(bp(4, 1024, 32, 128)) == 4
+    assert dq(bp(4, 4096, 32, 64)) == 4
+    assert dq(bp(4, 4096, 32, 128, softcap=20.0)) == 4
+    monkeypatch.setenv("FA_BWD_DQ_NW", "64"); lib.fa_knobs_reload()
+    assert dq(bp(4, 4096, 32, 96)) == 4                                 # trimmed head dims only have the 4-wave kernel, whatever the knob says
+    assert dq(bp(4, 512, 8, 128)) == 64
