@@ -116,8 +116,18 @@ template <typename E, int T> FA_DEVINL void mfma_o_acc(u32x4 a, u32x4 b) {
   else
     asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(16 * T), "i"(16 * T + 15) : FA_W64_ACC_CLOBBERS);
 }
-template <typename E, int D>
+// FEAT: 0 = plain, FEAT_ALIBI = causal ALiBi (right bound exactly on the diagonal: every visible key j of query i has j <= i + shift, so the bias
+// -slope * |i + shift - j| is linear in j).  The bias rides in the same C operand as -m: C_r = -m + slope2 * (key_r - i - shift), moved from step
+// to step by 32 in-place adds in the gaps behind the chain starts -- the only cost of the feature in the steady state.  The variant walks the key
+// tiles DOWNWARDS from the diagonal (DESC), as the reference does (flash_fwd_kernel.h: n_block = n_max-1 .. n_min): walking upwards the biased
+// scores grow by slope*32 per step, the running maximum moves at every step and the 540-instruction rescale runs every step (measured: 527
+// TFLOP/s at config 3 against 614 for the lock-step kernel, profiles/r03_fwd_schedules.txt); downwards the maximum is found in the first tiles.
+// set_mask / clear_mask rewrite the broadcast exactly and the rescale moves it, so the incremental adds' rounding does not accumulate past them.
+template <typename E, int D, int FEAT = 0>
 __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
+  constexpr bool ALIBI = FEAT == FEAT_ALIBI;
+  constexpr bool DESC = ALIBI;   // iteration u scores key tile n_tiles - 1 - u instead of tile u
+  static_assert(FEAT == 0 || FEAT == FEAT_ALIBI, "feature variants of this schedule: none, causal ALiBi");
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   constexpr int NW = 4, QB = 2, BM = NW * 64, BN = 64, CPR = D / 8;
@@ -275,7 +285,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   const int n_max = (kmax >= kmin) ? (kmax / BN + 1) : n_min;
   const int n_tiles = n_max - n_min;
   const int n_steps = 2 * n_tiles;
-  const int key_base = n_min * BN;  // first key of step 0
+  const int key_base = n_min * BN;  // first key of the block's first tile
+  // tile (relative to n_min) scored in iteration u, first key of step i (= iteration i / 2, half i % 2)
+  auto tile_of = [&](int u) __attribute__((always_inline)) { return DESC ? n_tiles - 1 - u : u; };
+  auto step_key = [&](int i) __attribute__((always_inline)) { return key_base + BN * tile_of(i >> 1) + 32 * (i & 1); };
+  float slope2 = 0.f;   // ALiBi slope of this head in log2 units
+  if constexpr (ALIBI) slope2 = p.alibi[(int64_t)b * p.alibi_bs + h] * 1.4426950408889634f;
 
   const int w_row0 = m0 + wave * 64;
   const int w_row1 = min(w_row0 + 63, sq - 1);
@@ -289,7 +304,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   for (int qb = 0; qb < QB; ++qb) {
     const int my_row = w_row0 + 32 * qb + qi;
     lim_hi[qb] = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
-    lim_lo[qb] = (p.wl >= 0) ? (my_row + shift - p.wl) : 0;
+    lim_lo[qb] = (p.wl >= 0) ? max(0, my_row + shift - p.wl) : 0;   // (>= 0: the descending walk's drain step scores the zero tile left of key 0 -- it must not count as visible)
   }
   // per query block of this wave (32 rows against the 32 keys of a step): the steps whose keys are ALL visible to all of its rows, and the
   // steps with ANY visible key -- what the cold mask path looks at instead of row / key arithmetic
@@ -364,7 +379,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   __syncthreads();
   FA_W64_STAMP(0);
   if (q_in_lds != vb) dma_q(q_srd_of(blk));
-  if (n_tiles > 0) { dma_tile(ICw<0>{}, 0, 0); dma_tile(ICw<1>{}, 1, -1); }
+  if (n_tiles > 0) { dma_tile(ICw<0>{}, 0, tile_of(0)); dma_tile(ICw<1>{}, 1, -1); }
   if (q_in_lds != vb) {   // Q was not prefetched (first block of this workgroup): its pieces were requested first
     if (n_tiles > 0) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else lds_dma_wait_all();
@@ -455,14 +470,20 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   float m_run[QB], l_run[QB][2], o_lag[QB];
   float thr_l[QB];          // per-lane decision threshold: -inf until the row has seen a key (any finite score moves m), then rescale_thr
   unsigned long long lag_mask = 0ull;   // wave-uniform, all ones or zero: some o_lag != 1 is waiting to be applied to O
-  f32x16 negm[QB];     // the C operand of every score chain's first MFMA: -m broadcast (0 while m = -inf)
+  f32x16 negm[QB];     // the C operand of every score chain's first MFMA: -m broadcast (0 while m = -inf), plus the ALiBi bias of the step's keys
+  float abias[QB] = {0.f, 0.f};   // ALiBi: the lane's part of the bias, slope2 * (4*hi - row - shift); element r of a step: + slope2 * (step_key + acc_row(r, 0))
+  if constexpr (ALIBI) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) abias[qb] = slope2 * (float)(4 * hi - (w_row0 + 32 * qb + qi) - shift);
+  }
+  const float ainc = slope2 * 32.f;
   f32x16 sA[QB], sB[QB];
   u32x4 pfA[QB][2], pfB[QB][2];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     m_run[qb] = -INFINITY; l_run[qb][0] = 0.f; l_run[qb][1] = 0.f; o_lag[qb] = 1.f; thr_l[qb] = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { negm[qb][r] = 0.f; sA[qb][r] = -INFINITY; sB[qb][r] = -INFINITY; }   // S_{-1} = -inf: P_{-1} = 0
+    for (int r = 0; r < 16; ++r) { negm[qb][r] = ALIBI ? abias[qb] + slope2 * (float)(step_key(0) + acc_row(r, 0)) : 0.f; sA[qb][r] = -INFINITY; sB[qb][r] = -INFINITY; }   // S_{-1} = -inf: P_{-1} = 0
 #pragma unroll
     for (int t = 0; t < 2; ++t) { pfA[qb][t] = u32x4{0u, 0u, 0u, 0u}; pfB[qb][t] = u32x4{0u, 0u, 0u, 0u}; }
   }
@@ -492,7 +513,8 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float sv = s_nxt[r], nv = negm[qb][r];
-      asm volatile("v_sub_f32 %0, %0, %2\n\tv_mov_b32 %1, %3" : "+v"(sv), "+v"(nv) : "v"(delta), "v"(neg));
+      if constexpr (ALIBI) asm volatile("v_sub_f32 %0, %0, %2\n\tv_sub_f32 %1, %1, %2" : "+v"(sv), "+v"(nv) : "v"(delta), "v"(neg));   // (the bias stays; -inf stays -inf)
+      else asm volatile("v_sub_f32 %0, %0, %2\n\tv_mov_b32 %1, %3" : "+v"(sv), "+v"(nv) : "v"(delta), "v"(neg));
       s_nxt[r] = sv;
       negm[qb][r] = nv;
     }
@@ -527,7 +549,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // Straight-line on purpose, one path for every case (all visible / none / element by element fall out of the per-lane bounds): with a branch
   // per case the rewritten broadcasts of the cases meet at joins and hipcc copies 32 registers per call.
   auto set_mask = [&](int i_step) __attribute__((always_inline)) {
-    const int k0m = key_base + 32 * i_step;
+    const int k0m = step_key(i_step);
     float ninf = -INFINITY;
     asm volatile("" : "+v"(ninf));
     static_for<QB>([&](auto mqc) __attribute__((always_inline)) {
@@ -538,28 +560,42 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       const int rel_hi = min(lim_hi[mq] - k0m - 4 * hi, 31), rel_lo = max(lim_lo[mq] - k0m - 4 * hi, 0);
       const unsigned ones = (rel_hi - rel_lo >= 31) ? 0xffffffffu : ((2u << ((rel_hi - rel_lo) & 31)) - 1u);
       unsigned bits = (rel_hi >= rel_lo) ? (ones << (rel_lo & 31)) : 0u;   // (rel_lo > 31 only with rel_hi < rel_lo)
+      if constexpr (ALIBI) nb += abias[mq] + slope2 * (float)k0m;   // the step's bias of this lane's element 0
       asm volatile("" : "+v"(nb), "+v"(bits));
 #pragma unroll
       for (int r = 0; r < 16; r += 4) {
         float n0 = negm[mq][r], n1 = negm[mq][r + 1], n2 = negm[mq][r + 2], n3 = negm[mq][r + 3];
         unsigned t0, t1;
-        asm volatile("v_bfe_i32 %4, %6, %c9, 1\n\tv_bfe_i32 %5, %6, %c10, 1\n\tv_bfi_b32 %0, %4, %7, %8\n\tv_bfi_b32 %1, %5, %7, %8\n\t"
-                     "v_bfe_i32 %4, %6, %c11, 1\n\tv_bfe_i32 %5, %6, %c12, 1\n\tv_bfi_b32 %2, %4, %7, %8\n\tv_bfi_b32 %3, %5, %7, %8"
-                     : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "=&v"(t0), "=&v"(t1)
-                     : "v"(bits), "v"(nb), "v"(ninf), "i"(acc_row(r, 0)), "i"(acc_row(r + 1, 0)), "i"(acc_row(r + 2, 0)), "i"(acc_row(r + 3, 0)));
+        if constexpr (ALIBI) {   // (the visible value differs per element: base + slope2 * offset)
+          const float v0 = nb + slope2 * (float)acc_row(r, 0), v1 = nb + slope2 * (float)acc_row(r + 1, 0);
+          const float v2 = nb + slope2 * (float)acc_row(r + 2, 0), v3 = nb + slope2 * (float)acc_row(r + 3, 0);
+          asm volatile("v_bfe_i32 %4, %6, %c11, 1\n\tv_bfe_i32 %5, %6, %c12, 1\n\tv_bfi_b32 %0, %4, %7, %15\n\tv_bfi_b32 %1, %5, %8, %15\n\t"
+                       "v_bfe_i32 %4, %6, %c13, 1\n\tv_bfe_i32 %5, %6, %c14, 1\n\tv_bfi_b32 %2, %4, %9, %15\n\tv_bfi_b32 %3, %5, %10, %15"
+                       : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "=&v"(t0), "=&v"(t1)
+                       : "v"(bits), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "i"(acc_row(r, 0)), "i"(acc_row(r + 1, 0)), "i"(acc_row(r + 2, 0)), "i"(acc_row(r + 3, 0)),
+                         "v"(ninf));
+        } else {
+          asm volatile("v_bfe_i32 %4, %6, %c9, 1\n\tv_bfe_i32 %5, %6, %c10, 1\n\tv_bfi_b32 %0, %4, %7, %8\n\tv_bfi_b32 %1, %5, %7, %8\n\t"
+                       "v_bfe_i32 %4, %6, %c11, 1\n\tv_bfe_i32 %5, %6, %c12, 1\n\tv_bfi_b32 %2, %4, %7, %8\n\tv_bfi_b32 %3, %5, %7, %8"
+                       : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "=&v"(t0), "=&v"(t1)
+                       : "v"(bits), "v"(nb), "v"(ninf), "i"(acc_row(r, 0)), "i"(acc_row(r + 1, 0)), "i"(acc_row(r + 2, 0)), "i"(acc_row(r + 3, 0)));
+        }
         negm[mq][r] = n0; negm[mq][r + 1] = n1; negm[mq][r + 2] = n2; negm[mq][r + 3] = n3;
       }
     });
   };
-  auto clear_mask = [&]() __attribute__((always_inline)) {
+  auto clear_mask = [&](int i_next) __attribute__((always_inline)) {   // i_next: the step whose keys the broadcast serves next (ALiBi)
     static_for<QB>([&](auto mqc) __attribute__((always_inline)) {
       constexpr int mq = decltype(mqc)::value;
       float nb = (m_run[mq] == -INFINITY) ? 0.f : -m_run[mq];
+      if constexpr (ALIBI) nb += abias[mq] + slope2 * (float)step_key(i_next);
       asm volatile("" : "+v"(nb));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float nv = negm[mq][r];
-        asm volatile("v_mov_b32 %0, %1" : "+v"(nv) : "v"(nb));
+        float val = nb;
+        if constexpr (ALIBI) val = nb + slope2 * (float)acc_row(r, 0);
+        asm volatile("v_mov_b32 %0, %1" : "+v"(nv) : "v"(val));
         negm[mq][r] = nv;
       }
     });
@@ -667,6 +703,16 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
         else
           asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2 lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
       }
+      if constexpr (ALIBI) {   // the C broadcasts move on to the next step's keys (the other half of the tile: +32 keys; the next tile down: -96): 32 in-place adds
+        constexpr auto ab_end = [](int g) constexpr { return g < 4 ? 0 : (((g - 3) * 32 + (NG - 5)) / (NG - 4) > 32 ? 32 : ((g - 3) * 32 + (NG - 5)) / (NG - 4)); };
+        const float step_add = (half == 1 && DESC) ? -3.f * ainc : ainc;
+#pragma unroll
+        for (int e = ab_end(x); e < ab_end(x + 1); ++e) {
+          float nv = negm[e >> 4][e & 15];
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(nv) : "v"(step_add));
+          negm[e >> 4][e & 15] = nv;
+        }
+      }
       // exp2 + row sums (two running sums per query block, carried across steps)
 #pragma unroll
       for (int e = el_end(x); e < el_end(x + 1); ++e) {
@@ -759,6 +805,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       const int f_hi = (w_full_hi - 31 - key_base) >> 5;             // last step with no right-masked key (< n_steps: w_full_hi < sk)
       p_lo = max(u_first, (f_lo + 1) >> 1);
       p_hi = min(u_last, (f_hi - 1) >> 1);
+      if constexpr (DESC) {   // the same tiles, walked downwards: tile t is scored in iteration n_tiles - 1 - t, the drain follows the lowest visible tile
+        const int t_lo = a_lo >> 1, t_hi = a_hi >> 1, pl_t = (f_lo + 1) >> 1, ph_t = (f_hi - 1) >> 1;
+        u_first = n_tiles - 1 - t_hi; u_last = n_tiles - t_lo;
+        p_lo = max(u_first, n_tiles - 1 - ph_t);
+        p_hi = min(u_last, n_tiles - 1 - pl_t);
+      }
       if (p_hi < p_lo) { p_lo = u_last + 1; p_hi = u_last; }         // no plain iteration: one masked range
     }
   }
@@ -780,7 +832,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // Active iterations outside [m_lo, m_hi] hold a step that straddles a mask boundary
   const int m_lo = __builtin_amdgcn_readfirstlane((FA_W64_ABL & 4096) ? 0 : p_lo), m_hi = __builtin_amdgcn_readfirstlane((FA_W64_ABL & 4096) ? 0x3fffffff : p_hi);
   const unsigned step_k = (unsigned)(BN * 2) * (unsigned)p.k_rs, step_v = (unsigned)(BN * 2) * (unsigned)p.v_rs;
-  const int nmin_s = __builtin_amdgcn_readfirstlane(n_min);
+  const int nmin_s = __builtin_amdgcn_readfirstlane(n_min), nts_s = __builtin_amdgcn_readfirstlane(n_tiles);
   auto step_pair = [&](auto parc, int u) __attribute__((always_inline)) {
     constexpr int par = decltype(parc)::value;
     // K_{u+1} rides in the first step, V_u in the second.  A tile past the block's last one is requested like any other: past the last key
@@ -791,7 +843,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     q_trickle();
     const int us = __builtin_amdgcn_readfirstlane(u);   // (uniform by construction; said so)
     unsigned dst_k = (unsigned)((par ^ 1) * TILE_BYTES) + wave_dst, dst_v = (unsigned)((2 + par) * TILE_BYTES) + wave_dst;
-    unsigned tk_ = (unsigned)(nmin_s + 1 + us) * step_k, tv_ = (unsigned)(nmin_s + us) * step_v;   // (two scalar multiplies: carried offsets end up in vector registers)
+    // (two scalar multiplies: carried offsets end up in vector registers.  Walking downwards the tile before the first one has a "negative" offset:
+    // it wraps to the top of the 32-bit range, outside the descriptor, and is zero-filled like a tile past the last key)
+    unsigned tk_ = (unsigned)(nmin_s + (DESC ? nts_s - 2 - us : us + 1)) * step_k, tv_ = (unsigned)(nmin_s + (DESC ? nts_s - 1 - us : us)) * step_v;
     int im32 = ((us - m_lo) | (m_hi - us)) >> 31;   // -1 outside [m_lo, m_hi] (arithmetic, not a compare + select: that one goes through a lane mask)
     dst_k = __builtin_amdgcn_readfirstlane(dst_k); dst_v = __builtin_amdgcn_readfirstlane(dst_v);
     im32 = __builtin_amdgcn_readfirstlane(im32);
@@ -807,7 +861,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
       set_mask(2 * u + 1);
       fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
-      clear_mask();
+      clear_mask(2 * u + 2);
     } else {
       fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
       fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
@@ -817,13 +871,13 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
     if (__builtin_expect(masked(), 0)) set_mask(2 * u + 1);
     fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
-    if (__builtin_expect(masked(), 0)) clear_mask();
+    if (__builtin_expect(masked(), 0)) clear_mask(2 * u + 2);
 #endif
     iter_end();
   };
   auto idle_iter = [&](int u) __attribute__((always_inline)) {
     q_trickle();
-    if (!(FA_W64_ABL & 32) || u <= 1) { dma_tile(ICw<0>{}, (u & 1) ^ 1, u + 1); dma_tile(ICw<1>{}, u & 1, u); }
+    if (!(FA_W64_ABL & 32) || u <= 1) { dma_tile(ICw<0>{}, (u & 1) ^ 1, tile_of(u + 1)); dma_tile(ICw<1>{}, u & 1, tile_of(u)); }
     iter_end();
   };
   if (n_tiles > 0) {
@@ -835,6 +889,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #pragma unroll 1
     for (; u < ua; ++u) idle_iter(u);
     if (active) {
+      if constexpr (ALIBI) { if (u > 0) clear_mask(2 * u); }   // (the broadcasts were initialised for step 0)
 #pragma unroll 1
       for (;;) {
         step_pair(ICw<0>{}, u); ++u;
@@ -931,11 +986,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   }  // persistent block loop
 }
 
-template <typename E, int D>
+template <typename E, int D, int FEAT = 0>
 static int launch_fwd_w64_t(const FwdK& p, hipStream_t stream) {
   constexpr int STAGE = 256 * (D * 2 + 16);
   constexpr int smem = ((4 * 64 * D * 2 > STAGE ? 4 * 64 * D * 2 : STAGE + 1023) / 1024 * 1024) + 256 * D * 2;  // K/V buffers | O staging, then the Q block
-  auto kern = fa_fwd_w64_kernel<E, D>;
+  auto kern = fa_fwd_w64_kernel<E, D, FEAT>;
   static std::atomic<unsigned long long> attr_mask{0};  // the kernel addresses LDS by byte offset: the dynamic segment must start at 0
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
   const long long total = p.work_list ? (long long)p.work_bound * p.h : units_grid(p.n_units, p.unit_size);
@@ -955,9 +1010,10 @@ static int launch_fwd_w64_t(const FwdK& p, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, stream, pp);
   if (hipGetLastError() != hipSuccess) return -1;
   LastSchedule& ls = last_schedule();
-  ls.fwd_kernel = 3; ls.fwd_nw = 4; ls.fwd_feat = 0; ls.fwd_splits = 1; ls.fwd_list = p.work_list != nullptr; ls.d = D;
+  ls.fwd_kernel = 3; ls.fwd_nw = 4; ls.fwd_feat = FEAT; ls.fwd_splits = 1; ls.fwd_list = p.work_list != nullptr; ls.d = D;
   ls.bf16 = std::is_same<E, __bf16>::value;
-  snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d>", ls.bf16 ? "bf16" : "f16", D);
+  if (FEAT) snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d,alibi>", ls.bf16 ? "bf16" : "f16", D);
+  else snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d>", ls.bf16 ? "bf16" : "f16", D);
   return 0;
 }
 
@@ -970,6 +1026,7 @@ int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream);
 int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream);
 #if FA_W64_PART != 1
 int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream) {
+  if (p.alibi) return -2;   // (the fp16 rescale threshold is capped at 15: ALiBi stays on the lock-step kernel there)
   if (d == 128) return launch_fwd_w64_t<_Float16, 128>(p, stream);
   if (d == 64) return launch_fwd_w64_t<_Float16, 64>(p, stream);
   return -2;
@@ -977,13 +1034,19 @@ int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream) {
 #endif
 #if FA_W64_PART != 2
 int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream) {
+  if (p.alibi) {
+    if (d == 128) return launch_fwd_w64_t<__bf16, 128, FEAT_ALIBI>(p, stream);
+    if (d == 64) return launch_fwd_w64_t<__bf16, 64, FEAT_ALIBI>(p, stream);
+    return -2;
+  }
   if (d == 128) return launch_fwd_w64_t<__bf16, 128>(p, stream);
   if (d == 64) return launch_fwd_w64_t<__bf16, 64>(p, stream);
   return -2;
 }
-// 4 waves x 64 query rows per workgroup.  Plain attention only (no softcap / ALiBi / dropout / split keys / paged KV).
+// 4 waves x 64 query rows per workgroup.  Plain attention, or bf16 ALiBi under a causal right bound (no softcap / dropout / split keys / paged KV).
 int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
-  if (p.softcap > 0.f || p.alibi != nullptr || p.rng != nullptr || p.n_splits > 1 || p.block_table != nullptr) return -2;
+  if (p.softcap > 0.f || p.rng != nullptr || p.n_splits > 1 || p.block_table != nullptr) return -2;
+  if (p.alibi != nullptr && (p.wr != 0 || !dtype_bf16)) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal
   // buffer addressing: 32-bit byte offsets from the (batch, kv-head) base
   const uint64_t span = ((uint64_t)(p.sk > 0 ? p.sk : 1) + 128) * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u;
   if (span >= (1ull << 32)) return -3;

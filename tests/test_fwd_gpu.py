@@ -239,3 +239,66 @@ def test_fwd_packs_grouped_heads_of_short_query_chunks(knobs, sq, h, hk, causal)
     ref, lse_ref = orc.attention_fwd(q, k, v, d ** -0.5, causal)
     assert float((out.float().cpu() - torch.from_numpy(ref).float()).abs().max()) < 2e-2
     assert float((lse.cpu() - torch.from_numpy(lse_ref).float()).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("window", [(-1, -1), (300, 0)])
+@pytest.mark.parametrize("per_batch", [False, True])
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D", [(2, 1024, 1024, 8, 8, 128), (1, 1500, 1700, 6, 2, 128), (2, 2048, 2048, 4, 4, 64)])
+def test_w64_causal_alibi(be, knobs, B, Sq, Sk, H, Hk, D, per_batch, window):
+    """Causal ALiBi on the 64-rows-per-wave forward (fa_fwd_w64_kernel<.., alibi>: the bias rides in the score chains' C operand, the key tiles are
+    walked downwards from the diagonal; mask rewrites and the rescale keep the bias exact): against the fp64 oracle, and against the lock-step kernel
+    that served ALiBi before."""
+    from oracle import attention_oracle as orc
+    torch.manual_seed(B * Sq + D)
+    q = torch.randn(B, Sq, H, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, Sk, Hk, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    slopes = (torch.rand((B, H) if per_batch else (H,), device="cuda") * 0.6 + 0.004).float()
+    run = lambda: be.fwd(q, k, v, None, slopes, 0.0, D ** -0.5, True, window[0], window[1], 0.0, False, None)[:2]
+    knobs.set("FA_FWD_NW", "64")
+    out, lse = run()
+    s = be.last_schedule()
+    assert s["fwd_kernel"] == 3 and "alibi" in s["name"], s
+    knobs.set("FA_FWD_NW", "8")
+    out8, lse8 = run()
+    assert be.last_schedule()["fwd_kernel"] == 1
+    knobs.unset("FA_FWD_NW")
+    ref, lse_ref = orc.attention_fwd(q, k, v, D ** -0.5, True, window, 0.0, slopes.cpu().numpy())
+    ref, lse_ref = torch.from_numpy(ref).float(), torch.from_numpy(lse_ref).float()
+    assert torch.isfinite(out.float()).all()
+    e64, e8 = float((out.float().cpu() - ref).abs().max()), float((out8.float().cpu() - ref).abs().max())
+    fin = torch.isfinite(lse_ref)
+    el = float((lse.cpu() - lse_ref)[fin].abs().max())
+    assert e64 < max(2 * e8, 1.2e-2) and el < 8e-3 and torch.equal(torch.isinf(lse.cpu()), ~fin), (e64, e8, el)
+
+
+def test_w64_causal_alibi_varlen(be, knobs):
+    """The same through the packed variable-length entry (work list, uneven sequences: a block-aligned one, one with a single row in its last block,
+    one shorter than a block), judged like the fixed-length cases: against the fp64 oracle, relative to the lock-step kernel's error."""
+    from oracle import attention_oracle as orc
+    torch.manual_seed(4)
+    H, D = 8, 128
+    lens = [1300, 70, 2048, 513, 900]
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    tot = int(cu[-1])
+    q = torch.randn(tot, H, D, device="cuda", dtype=torch.bfloat16); k = torch.randn_like(q); v = torch.randn_like(q)
+    slopes = (torch.rand(H, device="cuda") * 0.3 + 0.02).float()
+    run = lambda: be.varlen_fwd(q, k, v, None, cu, cu, None, None, None, slopes, max(lens), max(lens), 0.0, D ** -0.5, False, True, -1, -1, 0.0, False, None)[:2]
+    knobs.set("FA_FWD_NW", "64")
+    out, lse = run()
+    s = be.last_schedule()
+    knobs.set("FA_FWD_NW", "8")
+    out8, lse8 = run()
+    s8 = be.last_schedule()
+    knobs.unset("FA_FWD_NW")
+    assert s["fwd_kernel"] == 3 and "alibi" in s["name"], s
+    assert s8["fwd_kernel"] == 1, s8
+    assert torch.isfinite(out.float()).all()
+    errs = []
+    for i, n in enumerate(lens):
+        a, b_ = int(cu[i]), int(cu[i + 1])
+        ref, lse_ref = orc.attention_fwd(q[a:b_][None], k[a:b_][None], v[a:b_][None], D ** -0.5, True, (-1, -1), 0.0, slopes.cpu().numpy())
+        ref, lse_ref = torch.from_numpy(ref[0]).float(), torch.from_numpy(lse_ref[0]).float()
+        errs.append((float((out[a:b_].float().cpu() - ref).abs().max()), float((out8[a:b_].float().cpu() - ref).abs().max()),
+                     float((lse[:, a:b_].cpu() - lse_ref).abs().max()), float((lse8[:, a:b_].cpu() - lse_ref).abs().max())))
+    assert all(e64 < max(2 * e8, 1.2e-2) and l64 < max(2 * l8, 8e-3) for e64, e8, l64, l8 in errs), errs
