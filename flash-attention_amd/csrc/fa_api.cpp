@@ -308,8 +308,8 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   }
   // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
   const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && k.n_splits == 1 && pack == 1 && !bounded;
-  // (the 64-rows-per-wave kernel has a causal-ALiBi variant, bf16: the bias rides in the score chains' C operand, key tiles walked downwards)
-  const bool w64_alibi = a->alibi_slopes && k.wr == 0 && a->dtype == FA_DTYPE_BF16 && !(a->softcap > 0.f) && !(a->p_dropout > 0.f) && k.n_splits == 1 &&
+  // (the 64-rows-per-wave kernel has a causal-ALiBi variant: the bias rides in the score chains' C operand, key tiles walked downwards)
+  const bool w64_alibi = a->alibi_slopes && k.wr == 0 && !(a->softcap > 0.f) && !(a->p_dropout > 0.f) && k.n_splits == 1 &&
                          pack == 1 && !bounded;
   const bool w64 = nw == 64 && (plain || w64_alibi) && !a->block_table;
   if (nw == 64 && !w64) nw = 8;   // features / paged KV: 8-wave lock-step kernel (same 256-row blocks)
@@ -524,7 +524,7 @@ int fa_fwd_schedule_query(const FaFwdParams* a, int varlen) {
   const bool bounded = dk != a->d;
   if (dk > 128 || head_dim_trimmed(dk) || bounded) nw = 4;
   const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && pack == 1 && !bounded;
-  const bool w64_alibi = a->alibi_slopes && wr == 0 && a->dtype == FA_DTYPE_BF16 && !(a->softcap > 0.f) && !(a->p_dropout > 0.f) && pack == 1 && !bounded;
+  const bool w64_alibi = a->alibi_slopes && wr == 0 && !(a->softcap > 0.f) && !(a->p_dropout > 0.f) && pack == 1 && !bounded;
   if (nw == 64 && !((plain || w64_alibi) && !a->block_table)) nw = 8;
   if ((nw == 34 || nw == 38) && !plain) nw -= 30;
   return nw;

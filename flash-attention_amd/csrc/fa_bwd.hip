@@ -413,9 +413,13 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
     f32x16 dcap;  // d(softcap*tanh(x/softcap))/dx = 1 - tanh^2 (reference flash_bwd_kernel.h:588 / utils.h:395-409)
     if constexpr (XFORM) {
       const float rcap = use_cap ? 1.f / p.softcap : 0.f;
+      // ALiBi: distance of this lane's key from the query of element r = rel + acc_row(r, 0), formed in fp32 (exact below 2^24) from ONE value
+      // made here, behind an opaque copy: written as (float)(q0 + acc_row(r, hi) + shift - my_key) hipcc hoists the sixteen loop-invariant parts
+      // (acc_row(r, hi) + shift - my_key) out of the item loop, finds no registers for them next to the accumulators and reloads them from
+      // scratch in every sub-block -- behind a vmcnt(0) that waits for the Q / dO prefetch in flight (46 spills, 188 bytes of scratch).
+      const float rel = F_ALIBI ? (float)opaque(q0 + 4 * hi + shift - my_key) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int qrow = q0 + acc_row(r, hi);
         float y = s[r] * p.scale;
         if constexpr (F_CAP) {
           dcap[r] = 1.f;
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
           }
         }
         if constexpr (F_ALIBI) {
-          if (use_alibi) y -= slope * fabsf((float)(qrow + shift - my_key));
+          if (use_alibi) y -= slope * fabsf(rel + (float)acc_row(r, 0));
         }
         s[r] = y;
       }

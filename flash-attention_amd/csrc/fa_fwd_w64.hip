@@ -1026,7 +1026,11 @@ int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream);
 int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream);
 #if FA_W64_PART != 1
 int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream) {
-  if (p.alibi) return -2;   // (the fp16 rescale threshold is capped at 15: ALiBi stays on the lock-step kernel there)
+  if (p.alibi) {
+    if (d == 128) return launch_fwd_w64_t<_Float16, 128, FEAT_ALIBI>(p, stream);
+    if (d == 64) return launch_fwd_w64_t<_Float16, 64, FEAT_ALIBI>(p, stream);
+    return -2;
+  }
   if (d == 128) return launch_fwd_w64_t<_Float16, 128>(p, stream);
   if (d == 64) return launch_fwd_w64_t<_Float16, 64>(p, stream);
   return -2;
@@ -1043,10 +1047,10 @@ int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream) {
   if (d == 64) return launch_fwd_w64_t<__bf16, 64>(p, stream);
   return -2;
 }
-// 4 waves x 64 query rows per workgroup.  Plain attention, or bf16 ALiBi under a causal right bound (no softcap / dropout / split keys / paged KV).
+// 4 waves x 64 query rows per workgroup.  Plain attention, or ALiBi under a causal right bound (no softcap / dropout / split keys / paged KV).
 int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   if (p.softcap > 0.f || p.rng != nullptr || p.n_splits > 1 || p.block_table != nullptr) return -2;
-  if (p.alibi != nullptr && (p.wr != 0 || !dtype_bf16)) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal
+  if (p.alibi != nullptr && p.wr != 0) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal
   // buffer addressing: 32-bit byte offsets from the (batch, kv-head) base
   const uint64_t span = ((uint64_t)(p.sk > 0 ? p.sk : 1) + 128) * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u;
   if (span >= (1ull << 32)) return -3;

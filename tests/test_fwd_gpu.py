@@ -242,16 +242,16 @@ def test_fwd_packs_grouped_heads_of_short_query_chunks(knobs, sq, h, hk, causal)
 
 
 @pytest.mark.parametrize("window", [(-1, -1), (300, 0)])
-@pytest.mark.parametrize("per_batch", [False, True])
+@pytest.mark.parametrize("per_batch,dtype", [(False, torch.bfloat16), (True, torch.bfloat16), (False, torch.float16)])
 @pytest.mark.parametrize("B,Sq,Sk,H,Hk,D", [(2, 1024, 1024, 8, 8, 128), (1, 1500, 1700, 6, 2, 128), (2, 2048, 2048, 4, 4, 64)])
-def test_w64_causal_alibi(be, knobs, B, Sq, Sk, H, Hk, D, per_batch, window):
+def test_w64_causal_alibi(be, knobs, B, Sq, Sk, H, Hk, D, per_batch, dtype, window):
     """Causal ALiBi on the 64-rows-per-wave forward (fa_fwd_w64_kernel<.., alibi>: the bias rides in the score chains' C operand, the key tiles are
     walked downwards from the diagonal; mask rewrites and the rescale keep the bias exact): against the fp64 oracle, and against the lock-step kernel
     that served ALiBi before."""
     from oracle import attention_oracle as orc
     torch.manual_seed(B * Sq + D)
-    q = torch.randn(B, Sq, H, D, device="cuda", dtype=torch.bfloat16)
-    k = torch.randn(B, Sk, Hk, D, device="cuda", dtype=torch.bfloat16)
+    q = torch.randn(B, Sq, H, D, device="cuda", dtype=dtype)
+    k = torch.randn(B, Sk, Hk, D, device="cuda", dtype=dtype)
     v = torch.randn_like(k)
     slopes = (torch.rand((B, H) if per_batch else (H,), device="cuda") * 0.6 + 0.004).float()
     run = lambda: be.fwd(q, k, v, None, slopes, 0.0, D ** -0.5, True, window[0], window[1], 0.0, False, None)[:2]
@@ -269,7 +269,7 @@ def test_w64_causal_alibi(be, knobs, B, Sq, Sk, H, Hk, D, per_batch, window):
     e64, e8 = float((out.float().cpu() - ref).abs().max()), float((out8.float().cpu() - ref).abs().max())
     fin = torch.isfinite(lse_ref)
     el = float((lse.cpu() - lse_ref)[fin].abs().max())
-    assert e64 < max(2 * e8, 1.2e-2) and el < 8e-3 and torch.equal(torch.isinf(lse.cpu()), ~fin), (e64, e8, el)
+    assert e64 < max(2 * e8, 1.2e-2 if dtype == torch.bfloat16 else 2e-3) and el < 8e-3 and torch.equal(torch.isinf(lse.cpu()), ~fin), (e64, e8, el)
 
 
 def test_w64_causal_alibi_varlen(be, knobs):
