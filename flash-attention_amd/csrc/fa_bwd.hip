@@ -45,18 +45,10 @@ static __device__ __forceinline__ void wait_lgkm_le(int n) {
     default: __builtin_amdgcn_s_waitcnt(0xC07F | (0 << 8)); break;
   }
 }
-#ifndef FA_DKDV_SPLIT
-#define FA_DKDV_SPLIT 0  // experiment: 1 = head dims <= 128 also run 4-wave workgroups of 128 keys with 32-query tiles, two per CU
-#endif
-#ifndef FA_DKDV_ROT
-#define FA_DKDV_ROT 0  // experiment: 1 = waves 4-7 of the plain D <= 128 dK/dV kernel run their phases rotated by one (see the kernel);
-#endif                 // measured no faster than lock step (profiles/r02_bwd_schedules.txt), so off
-#ifndef FA_DKDV_CARRY
-#define FA_DKDV_CARRY 0  // experiment: 1 = the first transposed operands of the dV / dK segment are read before the vector phase (in flight under
-#endif                   // it); measured identical (1441 | 2138 vs 1447 | 2146 us, profiles/r02_bwd_schedules.txt)
-#ifndef FA_DKDV_PRIO
-#define FA_DKDV_PRIO 0  // experiment: 1 = waves 4-7 of the eight-wave dK/dV kernel run at s_setprio 1 (MI355X_MICROARCH.md, static priority for
-#endif                  // the second-dispatched half)
+// Four schedule experiments of the dK/dV kernel were built, measured and removed again (code: git history up to 3be077c; numbers:
+// profiles/r02_bwd_schedules.txt): 4-wave workgroups of 128 keys at D <= 128 (FA_DKDV_SPLIT), the upper four waves one phase ahead of their SIMD
+// partners (FA_DKDV_ROT: 1494 | 2394 us against 1431 | 2278 in lock step), the dV / dK segment's first operands read before the vector phase
+// (FA_DKDV_CARRY: identical), static priority for the second-dispatched waves (FA_DKDV_PRIO: slower).
 #ifndef FA_DKDV_PRESCALE
 #define FA_DKDV_PRESCALE 1  // 0 = the plain dK/dV kernel subtracts LSE and delta on the vector ALU like the feature variants (A/B)
 #endif
@@ -117,7 +109,7 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
 // dK / dV
 // ------------------------------------------------------------------------------------------------
 template <typename E, int D, int DV, int FEAT>
-__global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_dkdv_kernel(const BwdK p) {
+__global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_dkdv_kernel(const BwdK p) {
   constexpr bool XFORM = (FEAT & (FEAT_CAP | FEAT_ALIBI)) != 0;  // scores pass through the scaled domain
   constexpr bool F_CAP = (FEAT & FEAT_CAP) != 0, F_ALIBI = (FEAT & FEAT_ALIBI) != 0, F_DROP = (FEAT & FEAT_DROP) != 0;
   using T = ElemTraits<E>;
@@ -125,9 +117,9 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   using V4 = typename T::v4;
   // D <= 128: 8 waves (two per SIMD, 256 registers each); D = 256: 4 waves, one per SIMD, with the 512-register budget
   // the two 32 x 256 accumulators need, and 32-query tiles so that V block + Q/dO double buffers fit 160 KB of LDS
-  constexpr int NW = (D > 128 || FA_DKDV_SPLIT) ? 4 : 8, NT = NW * 64;
+  constexpr int NW = D > 128 ? 4 : 8, NT = NW * 64;
   constexpr int BNK = NW * 32;   // keys per workgroup
-  constexpr int BMQ = (D > 128 || FA_DKDV_SPLIT) ? 32 : 64;  // queries per streamed tile (32-row sub-blocks)
+  constexpr int BMQ = D > 128 ? 32 : 64;  // queries per streamed tile (32-row sub-blocks)
   constexpr int CPR = D / 8, ROW_BYTES = D * 2;
   constexpr int KS = DV / 16, DB = DV / 32, CV = DV / 8;   // k-steps / output blocks / 16-B chunks that exist
   static_assert(DV % 32 == 0 && DV <= D && 2 * DV >= D, "DV: a multiple of 32 in [D/2, D]");
@@ -302,7 +294,6 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
     for (int r = 0; r < 16; ++r) { dk_acc[db][r] = 0.f; dv_acc[db][r] = 0.f; }
 
   const float cs = XFORM ? kLog2e : p.scale_log2;
-  if (FA_DKDV_PRIO && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   if (n_items > 0) {
     load_item(0, 0);
@@ -324,15 +315,12 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
   // A sub-block (32 queries x this wave's 32 keys) goes through three phases: P1 = the S / dP contractions (16 MFMAs), SM = the
   // softmax arithmetic (VALU: P, dS, packing), P2 = the dV / dK contractions (16 MFMAs).  The two waves that share a SIMD
   // (waves w and w + 4) start every item together and sit in the same phase all the time; timing ablations give
-  // time = MFMA time + everything else (profiles/r02_bwd_schedules.txt).  FA_DKDV_ROT=1 makes the upper four waves run the
-  // ROTATED loop SM, P2, P1(next sub-block), one phase ahead, with two barriers per item ("next tile landed" before the last
-  // phase, "this tile is free" after it).  Measured: 1494 | 2394 us against 1431 | 2278 us in lock step (causal | full,
-  // config 3) -- the vector phase of one wave does not hide under the matrix phase of its partner, so the default is lock step.
-  f32x16 s, dp;              // S / dP of a sub-block between P1 and SM (the rotated waves carry them across the barriers)
+  // time = MFMA time + everything else (profiles/r02_bwd_schedules.txt).  Running the upper four waves one phase ahead was tried and
+  // measured slower (1494 | 2394 us against 1431 | 2278 us, causal | full, config 3): the vector phase of one wave does not hide under
+  // the matrix phase of its partner.
+  f32x16 s, dp;              // S / dP of a sub-block between P1 and SM
   V8 pfrag[2], dsfrag[2];    // P / dS between SM and P2
   constexpr int NQB = BMQ / 32;
-  constexpr bool ROT_OK = (NW == 8 && NQB == 2 && FEAT == 0) && FA_DKDV_ROT;  // the feature variants have no registers to carry S / dP across the barriers
-  const bool rot = ROT_OK && wave >= NW / 2;
   auto sub_active = [&](int it, int qb) __attribute__((always_inline)) {
     return it < n_items && ds_tile_active(item_m0(it) + 32 * qb, wk0, sq, sk, shift, p.wl, p.wr);
   };
@@ -496,8 +484,7 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
 
   // P2: dV^T[d][key] += dO^T[d][query] . P[query][key] ;  dK^T[d][key] += Q^T[d][query] . dS[query][key]
   // op i: source = dO (even) / Q (odd), d-block (i>>1) % DB, query half t = i / (2*DB); transpose reads PFT-1 ops ahead
-  // `mid` (the vector phase of the same sub-block, or nothing) runs between the first operand reads and the MFMAs: both waves of a
-  // SIMD reach this point together, so nobody hides the LDS round trip of a segment's first operands unless they are already in flight.
+  // `mid` = the vector phase of the same sub-block: it runs first, then the segment's first operand reads are issued.
   auto p2 = [&](auto bufc, auto qbc, auto&& mid) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value, qb = decltype(qbc)::value;
     constexpr int QB_OFF = OFF_Q + buf * QT_BYTES, DOB_OFF = OFF_DO + buf * QT_BYTES, sub = qb * 32 * ROW_BYTES;
@@ -511,13 +498,9 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
       tlo[i % PFT] = lds_read_tr16((const char FA_LDS*)(unsigned long)(unsigned)(base + (t0p ^ (db << 6))));
       thi[i % PFT] = lds_read_tr16((const char FA_LDS*)(unsigned long)(unsigned)(base + (t1p ^ (db << 6))));
     };
-    if (!FA_DKDV_CARRY) mid();
+    mid();
 #pragma unroll
     for (int i = 0; i < PFT - 1; ++i) rd(i);
-    if (FA_DKDV_CARRY) {
-      __builtin_amdgcn_sched_barrier(0);
-      mid();
-    }
 #pragma unroll
     for (int i = 0; i < NOPS; ++i) {
       if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
@@ -538,63 +521,26 @@ __global__ void __launch_bounds__((D > 128 || FA_DKDV_SPLIT) ? 256 : 512, D > 12
 
   using Q0 = std::integral_constant<int, 0>;
   using Q1 = std::integral_constant<int, 1>;
-  // role 0 = every wave in lock step (one barrier per item), 1 = the straight waves of the rotated schedule, 2 = its rotated waves.
-  // The roles are separate loops (one wave-uniform branch around the whole item loop): with the role tested inside the item the
-  // allocator had to agree on one register assignment for S / dP / accumulators at six merge points per item and spilled 246
-  // dwords.  Roles 1 and 2 execute the same two barriers per item.
-  auto item = [&](auto rolec, auto curc, int it) __attribute__((always_inline)) {
-    constexpr int role = decltype(rolec)::value, cur = decltype(curc)::value;
+  // Every wave in lock step, one barrier per item.
+  auto item = [&](auto curc, int it) __attribute__((always_inline)) {
+    constexpr int cur = decltype(curc)::value;
     using CUR = std::integral_constant<int, cur>;
-    using NXT = std::integral_constant<int, cur ^ 1>;
     const bool has_next = it + 1 < n_items;
     if (has_next && !((FA_DKDV_ABL & 64) && it > 0)) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
     const bool a0 = sub_active(it, 0), a1 = NQB > 1 && sub_active(it, 1);
-    if constexpr (role == 0) {
-      if (a0) { p1(CUR{}, Q0{}); p2(CUR{}, Q0{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q0{}, it); }); }
-      if constexpr (NQB > 1) {
-        if (a1) { p1(CUR{}, Q1{}); p2(CUR{}, Q1{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q1{}, it); }); }
-      }
-      if (has_next) store_item(cur ^ 1);
-      if (FA_DKDV_ABL & 8) return;
-      lds_dma_wait_all();
-      __syncthreads();
-    } else {
-      if constexpr (role == 1) {
-        if (a0) { p1(CUR{}, Q0{}); p2(CUR{}, Q0{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q0{}, it); }); }
-        if (a1) { p1(CUR{}, Q1{}); sm(CUR{}, Q1{}, it); }
-      } else {  // P1 of sub-block 0 ran at the end of the previous item (the first one: before the loop)
-        if (a0) p2(CUR{}, Q0{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q0{}, it); });
-        if (a1) { p1(CUR{}, Q1{}); p2(CUR{}, Q1{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q1{}, it); }); }
-      }
-      if (has_next) store_item(cur ^ 1);
-      if (!(FA_DKDV_ABL & 8)) {
-        lds_dma_wait_all();   // the next item's tile (issued at the top) has landed ...
-        __syncthreads();      // ... for every wave
-      }
-      if constexpr (role == 1) {
-        if (a1) p2(CUR{}, Q1{}, []() {});
-      } else {
-        if (sub_active(it + 1, 0)) p1(NXT{}, Q0{});
-      }
-      if (!(FA_DKDV_ABL & 8)) __syncthreads();   // every wave is through with this item's tile: the next DMA may overwrite it
+    if (a0) { p1(CUR{}, Q0{}); p2(CUR{}, Q0{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q0{}, it); }); }
+    if constexpr (NQB > 1) {
+      if (a1) { p1(CUR{}, Q1{}); p2(CUR{}, Q1{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q1{}, it); }); }
     }
+    if (has_next) store_item(cur ^ 1);
+    if (FA_DKDV_ABL & 8) return;
+    lds_dma_wait_all();
+    __syncthreads();
   };
-  auto run = [&](auto rolec) __attribute__((always_inline)) {
-    using ROLE = decltype(rolec);
-    if constexpr (ROLE::value == 2) {
-      if (sub_active(0, 0)) p1(Q0{}, Q0{});
-    }
-    for (int it = 0; it < n_items; it += 2) {
-      item(ROLE{}, Q0{}, it);
-      item_done();
-      if (it + 1 < n_items) { item(ROLE{}, Q1{}, it + 1); item_done(); }
-    }
-  };
-  if constexpr (!ROT_OK) {
-    run(Q0{});
-  } else {
-    if (!rot) run(Q1{});
-    else run(std::integral_constant<int, 2>{});
+  for (int it = 0; it < n_items; it += 2) {
+    item(Q0{}, it);
+    item_done();
+    if (it + 1 < n_items) { item(Q1{}, it + 1); item_done(); }
   }
 
   // ---- epilogue: dK = scale * acc, dV = acc; every key row of the block is written (zeros included) --
@@ -910,7 +856,7 @@ int bwd_block_m(int nw) { return (nw == 8 || nw == 64) ? 256 : 128; }
 int bwd_block_m(int nw);
 #endif
 #if FA_BWD_PART != 2
-int bwd_block_n(int d) { return (d > 128 || FA_DKDV_SPLIT) ? 128 : 256; }
+int bwd_block_n(int d) { return d > 128 ? 128 : 256; }
 
 template <typename E, int D, int DV>
 static int launch_delta_t(const BwdK& p, hipStream_t stream) {
@@ -922,7 +868,7 @@ static int launch_delta_t(const BwdK& p, hipStream_t stream) {
 
 template <typename E, int D, int DV, int FEAT>
 static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
-  constexpr int NWK = (D > 128 || FA_DKDV_SPLIT) ? 4 : 8, BMQ = (D > 128 || FA_DKDV_SPLIT) ? 32 : 64;
+  constexpr int NWK = D > 128 ? 4 : 8, BMQ = D > 128 ? 32 : 64;
   constexpr int smem = NWK * 32 * D * 2 + 4 * BMQ * D * 2 + 4 * BMQ * 4;
   auto kern = fa_bwd_dkdv_kernel<E, D, DV, FEAT>;
   static std::atomic<unsigned long long> attr_mask{0};
