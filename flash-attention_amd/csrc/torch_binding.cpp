@@ -507,6 +507,8 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tenso
   if (is_causal) window_size_right = 0;
 
   int64_t s_new = k_.has_value() ? k_->size(1) : 0;
+  TORCH_CHECK(s_new <= Sk, "If key is supplied, it must have seqlen <= the seqlen of the KV cache");                                  // flash_api.cpp:1397
+  TORCH_CHECK(!rotary_cos_.has_value() || rotary_cos_->size(0) >= Sk, "cos/sin seqlen must be at least the seqlen of KV cache");   // :1470
   if (paged && seqlens_k_.has_value()) {  // the reference's guard (flash_api.cpp:1433-1447); costs a device->host sync
     const int64_t need = seqlens_k_->max().item<int>() + s_new;
     TORCH_CHECK(need <= Sk, "Paged KV cache: max(seqlens_k)", s_new > 0 ? " + seqlen_knew" : "", " (= ", need,

@@ -509,6 +509,10 @@ def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_,
         is_causal = False
     lib = _cabi.load()
     s_new = 0 if k_ is None else k_.shape[1]
+    if s_new > Sk:      # flash_api.cpp:1397
+        raise RuntimeError("If key is supplied, it must have seqlen <= the seqlen of the KV cache")
+    if rotary_cos_ is not None and rotary_cos_.shape[0] < Sk:   # flash_api.cpp:1470
+        raise RuntimeError("cos/sin seqlen must be at least the seqlen of KV cache")
     if paged and seqlens_k_ is not None:  # the reference's guard (flash_api.cpp:1433-1447); costs a device->host sync
         need = int(seqlens_k_.max().item()) + s_new
         if need > Sk:

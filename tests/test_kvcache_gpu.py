@@ -97,6 +97,14 @@ def test_kvcache_interface_and_errors():
                                    rotary_sin=torch.zeros(8, 16, device="cuda", dtype=torch.float16))
     with pytest.raises(RuntimeError, match="divisible by 256"):
         fi.flash_attn_with_kvcache(q, kc[:, :128].contiguous(), vc[:, :128].contiguous(), block_table=torch.zeros(2, 1, dtype=torch.int32, device="cuda"))
+    kn = torch.randn(2, 1, 2, 128, device="cuda", dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="cos/sin seqlen must be at least"):   # flash_api.cpp:1470
+        fi.flash_attn_with_kvcache(q, kc, vc, k=kn, v=kn.clone(), cache_seqlens=300, rotary_cos=torch.zeros(8, 16, device="cuda", dtype=torch.float16),
+                                   rotary_sin=torch.zeros(8, 16, device="cuda", dtype=torch.float16))
+    with pytest.raises(RuntimeError, match="seqlen <= the seqlen of the KV cache"):   # flash_api.cpp:1397
+        qq = torch.randn(2, 9, 8, 128, device="cuda", dtype=torch.float16)
+        k9 = torch.randn(2, 9, 2, 128, device="cuda", dtype=torch.float16)
+        fi.flash_attn_with_kvcache(qq, kc[:, :8], vc[:, :8], k=k9, v=k9.clone(), cache_seqlens=0)
 
 
 @pytest.mark.parametrize("num_splits", [0, 1, 2, 7, 64])
