@@ -221,6 +221,21 @@ int check_common(int b, int h, int h_k, int d, int dtype, float softcap, bool fo
   return FA_OK;
 }
 
+// What the heuristic's pick becomes once the features have had their say (shared by do_fwd and fa_fwd_schedule_query):
+//   64 = the 64-rows-per-wave kernel: plain attention, or ALiBi under a right bound on the diagonal (its FEAT_ALIBI variant: the bias rides in the
+//        score chains' C operand, key tiles walked downwards); anything else that asked for it runs the 8-wave lock-step kernel on the same 256-row blocks;
+//   34 / 38 = the software-pipelined kernel with 4 / 8 waves: plain attention only, else the lock-step kernel with the same wave count.
+int resolve_fwd_features(const FaFwdParams* a, int nw, int wr, int n_splits, int pack, bool bounded, bool& w64, bool& il) {
+  const bool base = !(a->softcap > 0.f) && !(a->p_dropout > 0.f) && n_splits == 1 && pack == 1 && !bounded;
+  const bool plain = base && !a->alibi_slopes;
+  const bool w64_alibi = base && a->alibi_slopes && wr == 0;
+  w64 = nw == 64 && (plain || w64_alibi) && !a->block_table;
+  if (nw == 64 && !w64) nw = 8;
+  il = (nw == 34 || nw == 38) && plain;
+  if ((nw == 34 || nw == 38) && !il) nw -= 30;
+  return nw;
+}
+
 int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false) {
   if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
   g_err[0] = 0;
@@ -306,15 +321,8 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
       }  // auto schedule without a workspace: run unsplit
     }
   }
-  // 34 / 38 = software-pipelined kernel with 4 / 8 waves (falls back to lock-step for softcap / ALiBi)
-  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && k.n_splits == 1 && pack == 1 && !bounded;
-  // (the 64-rows-per-wave kernel has a causal-ALiBi variant: the bias rides in the score chains' C operand, key tiles walked downwards)
-  const bool w64_alibi = a->alibi_slopes && k.wr == 0 && !(a->softcap > 0.f) && !(a->p_dropout > 0.f) && k.n_splits == 1 &&
-                         pack == 1 && !bounded;
-  const bool w64 = nw == 64 && (plain || w64_alibi) && !a->block_table;
-  if (nw == 64 && !w64) nw = 8;   // features / paged KV: 8-wave lock-step kernel (same 256-row blocks)
-  const bool il = (nw == 34 || nw == 38) && plain;
-  if ((nw == 34 || nw == 38) && !il) nw -= 30;
+  bool w64 = false, il = false;
+  nw = resolve_fwd_features(a, nw, k.wr, k.n_splits, pack, bounded, w64, il);
   const int bm = w64 ? 256 : il ? 32 * (nw - 30) : fa::fwd_block_m(nw);
   k.nmb = (k.sq + bm - 1) / bm;
   if (varlen && !kvcache) {  // uneven packed batch: enumerate the non-empty query blocks, heaviest first
@@ -511,7 +519,7 @@ int fa_last_schedule(int32_t* out, int n) {
   return FA_SCHEDULE_FIELDS;
 }
 const char* fa_last_kernel_name(void) { return fa::last_schedule().name; }
-// (mirrors the schedule resolution of do_fwd for the entry points without a KV cache; kept separate so that the launch path stays as it was validated)
+// (the schedule resolution of do_fwd for the entry points without a KV cache: same heuristic, same feature resolution, no split keys)
 int fa_fwd_schedule_query(const FaFwdParams* a, int varlen) {
   if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
   if (int rc = check_common(a->b, a->h, a->h_k, a->d, a->dtype, a->softcap, true)) return rc;
@@ -523,11 +531,8 @@ int fa_fwd_schedule_query(const FaFwdParams* a, int varlen) {
   const int dk = head_dim_kernel(a->d);
   const bool bounded = dk != a->d;
   if (dk > 128 || head_dim_trimmed(dk) || bounded) nw = 4;
-  const bool plain = !(a->softcap > 0.f) && !a->alibi_slopes && !(a->p_dropout > 0.f) && pack == 1 && !bounded;
-  const bool w64_alibi = a->alibi_slopes && wr == 0 && !(a->softcap > 0.f) && !(a->p_dropout > 0.f) && pack == 1 && !bounded;
-  if (nw == 64 && !((plain || w64_alibi) && !a->block_table)) nw = 8;
-  if ((nw == 34 || nw == 38) && !plain) nw -= 30;
-  return nw;
+  bool w64 = false, il = false;
+  return resolve_fwd_features(a, nw, wr, 1, pack, bounded, w64, il);
 }
 int fa_bwd_dq_schedule_query(const FaBwdParams* a) {
   if (!a) return fail(FA_ERR_INVALID_ARGUMENT, "params is NULL");
