@@ -161,6 +161,29 @@ def sweep(be, dev, sync):
     return {"head_dim": D, "heads": H, "dtype": "bf16", "rows": rows}
 
 
+def feature_rows(be, dev, sync, B, H, S, D):
+    """Extra key `features`: the headline config with causal ALiBi (standard slopes 2^(-8(h+1)/H)) -- forward on the 64-rows-per-wave kernel's
+    ALiBi variant, backward on the ALiBi variants of the dK/dV and dQ kernels -- next to the plain numbers of the main line.  Never fatal:
+    any failure is reported in the key instead of taking the contract line down."""
+    try:
+        q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
+        k, v = torch.randn_like(q), torch.randn_like(q)
+        al = torch.tensor([2.0 ** (-8.0 * (i + 1) / H) for i in range(H)], device=dev, dtype=torch.float32)
+        sc = D ** -0.5
+        f = lambda: be.fwd(q, k, v, None, al, 0.0, sc, True, -1, -1, 0.0, False, None)
+        _, ms = time_kernel(f, 20, 5, sync)
+        name = be.last_schedule()["name"]
+        o, l = f()[:2]
+        g = torch.randn_like(o)
+        h = lambda: be.bwd(g, q, k, v, o, l, None, None, None, al, 0.0, sc, True, -1, -1, 0.0, False, None, None)
+        _, mb = time_kernel(h, 8, 2, sync)
+        fl = fwd_flops(B, H, S, D, True)
+        return {"causal_alibi": {"fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
+                                 "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name}}
+    except Exception as e:   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def preroll(fn, sync, min_ms):
     """Clock ramp: the same launch, back to back, for at least `min_ms` of wall time (outside every timed region).  A count-based
     warm-up of a 0.6 ms kernel ends ~3 ms after process start, before the chip has left its idle clocks (round 2: headline 9 %
@@ -332,6 +355,7 @@ def main(argv=None):
             res["roofline"]["traffic_detail"] = detail
         if world == 1 and not a.no_sweep:
             res["sweep"] = sweep(be, dev, dev_sync)
+            res["features"] = feature_rows(be, dev, dev_sync, B, H, S, D)
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(D, S, causal)
         print(json.dumps(res), flush=True)
