@@ -269,7 +269,7 @@ def test_w64_causal_alibi(be, knobs, B, Sq, Sk, H, Hk, D, per_batch, dtype, wind
     e64, e8 = float((out.float().cpu() - ref).abs().max()), float((out8.float().cpu() - ref).abs().max())
     fin = torch.isfinite(lse_ref)
     el = float((lse.cpu() - lse_ref)[fin].abs().max())
-    assert e64 < max(2 * e8, 1.2e-2 if dtype == torch.bfloat16 else 2e-3) and el < 8e-3 and torch.equal(torch.isinf(lse.cpu()), ~fin), (e64, e8, el)
+    assert e64 < max(2 * e8, 1.2e-2 if dtype == torch.bfloat16 else 4e-3) and el < 8e-3 and torch.equal(torch.isinf(lse.cpu()), ~fin), (e64, e8, el)
 
 
 def test_w64_causal_alibi_varlen(be, knobs):
