@@ -106,3 +106,17 @@ def test_descending_walk_scores_each_visible_pair_once(sq, sk, wl):
     """The causal-ALiBi variant's domain: right bound on the diagonal (wr = 0), any left bound."""
     cnt, pad = walk_counts(sq, sk, wl, 0, desc=True)
     assert np.array_equal(cnt, visible(sq, sk, wl, 0, pad))
+
+
+def test_random_shapes_and_windows_both_directions():
+    """Seeded sweep: lengths around the 256-row block / 64-key tile edges, windows from 0 to beyond the sequence."""
+    rng = np.random.default_rng(7)
+    edge = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 700]
+    for _ in range(80):
+        sq, sk = int(rng.choice(edge)), int(rng.choice(edge))
+        wl = int(rng.choice([-1, 0, 1, 31, 32, 63, 64, 65, 200, 1000]))
+        wr = int(rng.choice([-1, 0, 1, 31, 64, 200]))
+        cnt, pad = walk_counts(sq, sk, wl, wr, desc=False)
+        assert np.array_equal(cnt, visible(sq, sk, wl, wr, pad)), (sq, sk, wl, wr, "ascending")
+        cnt, pad = walk_counts(sq, sk, wl, 0, desc=True)
+        assert np.array_equal(cnt, visible(sq, sk, wl, 0, pad)), (sq, sk, wl, 0, "descending")
