@@ -54,6 +54,7 @@ const fa::Knobs* read_knobs() {
   k->lds_pad = env_int("FA_IL_LDS_PAD", 0);
   k->w64_persist = env_int("FA_W64_PERSIST", 1);
   k->strict = env_int("FA_STRICT", 0);
+  k->dkdv_prescale = env_int("FA_DKDV_PRESCALE", 0);
   k->pack_gqa = env_int("FA_PACK_GQA", 1);
   if (k->strict) k->rescale_thr = 0.f;
   return k;
@@ -151,9 +152,11 @@ int64_t splitkv_bytes(const FaFwdParams* a, int n_splits) {
 // (fa_fwd.hip).  wl / wr = normalised window.
 // The 64-rows-per-wave forward addresses K and V through buffer descriptors with 32-bit byte offsets from the (batch, kv-head)
 // base (fa_fwd_w64.hip: launch_fwd_w64): the whole key range of a sequence plus two tiles of overshoot must span < 4 GiB.
+// Q and O are addressed the same way over the 256 rows of a query block (q_srd_of / dma_q_piece, the epilogue's lane_off / soff).
 bool w64_span_ok(const FaFwdParams* a) {
   const uint64_t rs = (uint64_t)std::max<int64_t>(a->k_row_stride, a->v_row_stride);
-  return ((uint64_t)(a->seqlen_k > 0 ? a->seqlen_k : 1) + 128) * rs * 2u < (1ull << 32);
+  const uint64_t qo = (uint64_t)std::max<int64_t>(a->q_row_stride, a->o_row_stride);
+  return ((uint64_t)(a->seqlen_k > 0 ? a->seqlen_k : 1) + 128) * rs * 2u < (1ull << 32) && 256ull * qo * 2u < (1ull << 32);
 }
 int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
   // Schedule (measured on MI355X, tools/ab_bench.py, profiles/r03_fwd_schedules.txt; FA_FWD_NW overrides):
@@ -189,8 +192,8 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
     } else {
       nw = fallback;
     }
+    if (nw == 64 && !w64_span_ok(a)) nw = 38;   // (only the heuristic falls back: a forced FA_FWD_NW=64 reaches the launcher's -3 and its message)
   }
-  if (nw == 64 && !w64_span_ok(a)) nw = 38;
   return nw;
 }
 // query rows per workgroup of the schedule the forward will run (the lock-step variants serve softcap / ALiBi / dropout /
@@ -346,7 +349,7 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
   if (rc == 0 && k.n_splits > 1) rc = fa::launch_splitkv_combine(k, a->dtype == FA_DTYPE_BF16, dk, (hipStream_t)stream);
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no forward kernel for head dim %d", a->d);
   if (rc == -3)
-    return fail(FA_ERR_UNSUPPORTED, w64 ? "k/v key range too large for the 64-rows-per-wave forward: (seqlen_k + 128) * row_stride * 2 bytes must be < 4 GiB "
+    return fail(FA_ERR_UNSUPPORTED, w64 ? "k/v key range (or a 256-row q/o block) too large for the 64-rows-per-wave forward: (seqlen_k + 128) * k/v row_stride * 2 and 256 * q/o row_stride * 2 bytes must be < 4 GiB "
                                           "(FA_FWD_NW=64 was forced; the default schedule falls back to the pipelined kernel)"
                                         : "k/v row stride too large: one 64-key tile (64 * row_stride * 2 bytes) must span less than 2 GiB "
                                           "(the kernels address a tile with 32-bit lane offsets)");

@@ -131,7 +131,13 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   // starts from C = -delta.  Per element that leaves exp2, one multiply and the packing (was: fma, exp2, sub, mul, packing) -- in a kernel
   // whose vector phase does not overlap its matrix phases (profiles/r02_bwd_schedules.txt).  FA_STRICT=1 runs the run-time-checked
   // variant instead, which scales every score in fp32.
-  constexpr bool PRE = (FEAT == FEAT_NONE) && FA_DKDV_PRESCALE;
+  // Round 4: that variant (FEAT_NONE, "fast") is opt-in (FA_DKDV_PRESCALE=1).  The default plain variant is FEAT_EXACT: every score is scaled in fp32
+  // (one fma per element: S*c - LSE*log2e), only the dP chain keeps its C = -delta (exact: nothing is rounded there).  K * scale * log2e rounded to the
+  // input dtype puts an error of |score| * 2^-9 (bf16) / 2^-12 (fp16) log2 units into the exponent of P that the forward's LSE does not share; the
+  // reference's own acceptance tests see it (tests/test_flash_attn.py::test_flash_attn_causal with one visible key: P must be exactly 1 and dV exactly
+  // dO, we returned dO * (1 + 2^-8); test_flash_attn_bwd_overflow in fp16: dV error 7x PyTorch's; profiles/r04_reference_suite.txt).
+  constexpr bool PRE = (FEAT == FEAT_NONE) && FA_DKDV_PRESCALE;                    // K pre-scaled, score chain starts from C = -LSE*log2e
+  constexpr bool PRE_D = ((FEAT & FEAT_ALL) == FEAT_NONE) && FA_DKDV_PRESCALE;     // dP chain starts from C = -delta (FEAT_NONE and FEAT_EXACT)
   // LDS: Q0 | Q1 | dO0 | dO1 | V block | aux0 aux1   (aux = BMQ x LSE*log2e followed by BMQ x delta).  The streamed tiles
   // sit below 64 KB so that (buffer, sub-block) offsets fit the 16-bit immediate of ds_read.
   constexpr int OFF_Q = 0, OFF_DO = 2 * QT_BYTES, OFF_V = 4 * QT_BYTES, OFF_AUX = OFF_V + VBLK_BYTES;
@@ -165,7 +171,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; dk_boff = 0; dv_boff = 0; }
   if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
-  if (p.seqused_k) sk = min(sk, p.seqused_k[b]);
+  if (p.seqused_k) sk = min(p.seqused_k[b], p.sk);   // overrides the cu_seqlens_k length, as in the forward (block_info.h:17-36), clamped to max_seqlen_k
   const int n0 = n_block * BNK;
   if (n0 >= sk) return;
   const int n1 = min(n0 + BNK, sk);
@@ -268,7 +274,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
       const float* src = (tid < BMQ ? p.lse : p.delta) + base + m0 + r;
       const float x = ok ? *src : 0.f;
       aux_reg = (tid < BMQ) ? (ok ? x * kLog2e : INFINITY) : x;  // rows past the end: LSE = +inf => P = 0
-      if constexpr (PRE) aux_reg = -aux_reg;                           // (the C operands of the score / dP chains)
+      if (PRE || (PRE_D && tid >= BMQ)) aux_reg = -aux_reg;            // (the C operands of the score / dP chains)
     }
   };
   auto store_item = [&](int buf) {
@@ -334,14 +340,18 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
     u32x4 ra[PF], rb[2];
     const int k0p = opaque(k0), kv0p = opaque(kv0);
     f32x16 c_s, c_dp;   // PRE: -LSE*log2e / -delta of the accumulator rows (queries acc_row(r, hi))
-    if constexpr (PRE) {
+    if constexpr (PRE_D) {
       const int auxp = opaque(aux_lane);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4);
+        if constexpr (PRE) {
+          const f32x4 l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c_s[4 * g + j] = l4[j];
+        }
         const f32x4 d4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4 + BMQ * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { c_s[4 * g + j] = l4[j]; c_dp[4 * g + j] = d4[j]; }
+        for (int j = 0; j < 4; ++j) c_dp[4 * g + j] = d4[j];
       }
     }
     auto rd = [&](int j) __attribute__((always_inline)) {
@@ -374,7 +384,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
       const int ks = j >> 1;
       f32x16 c = (j & 1) ? dp : s;
       if (j < 2) {
-        if constexpr (PRE) {
+        if ((j & 1) ? PRE_D : PRE) {
           c = (j & 1) ? c_dp : c_s;
         } else {
 #pragma unroll
@@ -440,10 +450,8 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 l4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (!PRE) {
-        l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4);
-        d4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4 + BMQ * 4);
-      }
+      if constexpr (!PRE) l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4);
+      if constexpr (!PRE_D) d4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + (buf * 2 * BMQ + qb * 32 + 8 * g) * 4 + BMQ * 4);
       // Dropout: the 4 lanes of a quad hold the 4 keys of one key group; lane a hashes query row a of this 4-row
       // group (4 bytes = those 4 keys) and the quad exchanges words, so each lane reads its key's byte of every row.
       uint32_t hq = 0u;
@@ -464,7 +472,7 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
             dpe = keep ? dp[r] * p.rp_keep : 0.f;
           }
         }
-        float dsv = PRE ? pv * dpe : pv * (dpe - d4[j]);
+        float dsv = PRE_D ? pv * dpe : pv * (dpe - d4[j]);
         if constexpr (F_CAP) dsv *= dcap[r];
         pfrag[r >> 3][r & 7] = (E)pkeep;
         dsfrag[r >> 3][r & 7] = (E)dsv;
@@ -599,7 +607,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; dq_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
   if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
-  if (p.seqused_k) sk = min(sk, p.seqused_k[b]);
+  if (p.seqused_k) sk = min(p.seqused_k[b], p.sk);   // overrides the cu_seqlens_k length, as in the forward (block_info.h:17-36), clamped to max_seqlen_k
   const int m0 = m_block * BM;
   if (m0 >= sq) return;
 
@@ -882,12 +890,14 @@ static int launch_dkdv_a(const BwdK& p, hipStream_t stream) {
 template <typename E, int D, int DV>
 static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
   int feat = feat_code(p.softcap > 0.f, p.alibi != nullptr, p.rng != nullptr);
-  if (feat == FEAT_NONE && knobs().strict) feat = FEAT_ALL;   // FA_STRICT: every score scaled in fp32 (the plain variant pre-scales K)
+  // plain: FEAT_EXACT (fp32 scaling of every score) unless FA_DKDV_PRESCALE=1 opts into the pre-scaled-K variant (and never under FA_STRICT)
+  if (feat == FEAT_NONE && (knobs().strict || !knobs().dkdv_prescale)) feat = FEAT_EXACT;
   if constexpr (DV < D) {
-    return feat == FEAT_NONE ? launch_dkdv_a<E, D, DV, FEAT_NONE>(p, stream) : launch_dkdv_a<E, D, DV, FEAT_ALL>(p, stream);
+    return feat == FEAT_NONE ? launch_dkdv_a<E, D, DV, FEAT_NONE>(p, stream) : feat == FEAT_EXACT ? launch_dkdv_a<E, D, DV, FEAT_EXACT>(p, stream) : launch_dkdv_a<E, D, DV, FEAT_ALL>(p, stream);
   } else {
     switch (feat) {
       case FEAT_NONE: return launch_dkdv_a<E, D, DV, FEAT_NONE>(p, stream);
+      case FEAT_EXACT: return launch_dkdv_a<E, D, DV, FEAT_EXACT>(p, stream);
       case FEAT_CAP: return launch_dkdv_a<E, D, DV, FEAT_CAP>(p, stream);
       case FEAT_ALIBI: return launch_dkdv_a<E, D, DV, FEAT_ALIBI>(p, stream);
       case FEAT_DROP: return launch_dkdv_a<E, D, DV, FEAT_DROP>(p, stream);

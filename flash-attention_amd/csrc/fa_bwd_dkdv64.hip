@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; dk_boff = 0; dv_boff = 0; }
   if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
-  if (p.seqused_k) sk = min(sk, p.seqused_k[b]);
+  if (p.seqused_k) sk = min(p.seqused_k[b], p.sk);   // overrides the cu_seqlens_k length, as in the forward (block_info.h:17-36), clamped to max_seqlen_k
   const int n0 = n_block * BNK;
   if (n0 >= sk) return;
   const int n1 = min(n0 + BNK, sk);

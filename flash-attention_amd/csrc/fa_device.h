@@ -205,7 +205,8 @@ FA_DEVINL int ds_slot(int key, int hi) { return (key & 3) | (hi << 2) | ((key >>
 
 // Score-transform features of the non-plain kernel variants (template int FEAT): softcap, ALiBi, dropout.  A variant
 // with exactly one feature carries only that feature's code and registers; FEAT_ALL checks the parameters at run time.
-enum { FEAT_NONE = 0, FEAT_CAP = 1, FEAT_ALIBI = 2, FEAT_DROP = 4, FEAT_ALL = 7 };
+enum { FEAT_NONE = 0, FEAT_CAP = 1, FEAT_ALIBI = 2, FEAT_DROP = 4, FEAT_ALL = 7,
+       FEAT_EXACT = 8 };   // dK/dV kernel only: no feature, and no pre-scaled K either (fa_bwd.hip: PRE) -- the default plain variant since round 4
 inline int feat_code(bool cap, bool alibi, bool drop) {
   const int f = (cap ? FEAT_CAP : 0) | (alibi ? FEAT_ALIBI : 0) | (drop ? FEAT_DROP : 0);
   return (f == (FEAT_CAP | FEAT_ALIBI)) ? FEAT_ALL : f;  // every combination but softcap+ALiBi(+dropout) has its own variant

@@ -83,6 +83,26 @@
 #ifndef FA_W64_STAG_GS
 #define FA_W64_STAG_GS 1
 #endif
+#ifndef FA_W64_KV_POLN
+#define FA_W64_KV_POLN 0   // cache-policy bits of the K/V tile DMAs, bit mask: 1 sc0, 2 sc1, 4 nt (A/B in profiles/r04_fwd_w64_dma.txt)
+#endif
+#if FA_W64_KV_POLN == 0
+#define FA_W64_KV_POL ""
+#elif FA_W64_KV_POLN == 1
+#define FA_W64_KV_POL " sc0"
+#elif FA_W64_KV_POLN == 2
+#define FA_W64_KV_POL " sc1"
+#elif FA_W64_KV_POLN == 3
+#define FA_W64_KV_POL " sc0 sc1"
+#elif FA_W64_KV_POLN == 4
+#define FA_W64_KV_POL " nt"
+#elif FA_W64_KV_POLN == 5
+#define FA_W64_KV_POL " sc0 nt"
+#elif FA_W64_KV_POLN == 6
+#define FA_W64_KV_POL " sc1 nt"
+#else
+#define FA_W64_KV_POL " sc0 sc1 nt"
+#endif
 
 namespace fa {
 
@@ -346,16 +366,16 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
     if constexpr (DPW == 4) {
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                   "buffer_load_dwordx4 %1, %6, 0 offen lds\n\t"
-                   "buffer_load_dwordx4 %2, %6, 0 offen offset:1024 lds\n\t"
-                   "buffer_load_dwordx4 %3, %6, 0 offen offset:2048 lds\n\t"
-                   "buffer_load_dwordx4 %4, %6, 0 offen offset:3072 lds\n\t"
+                   "buffer_load_dwordx4 %1, %6, 0 offen" FA_W64_KV_POL " lds" "\n\t"
+                   "buffer_load_dwordx4 %2, %6, 0 offen offset:1024" FA_W64_KV_POL " lds" "\n\t"
+                   "buffer_load_dwordx4 %3, %6, 0 offen offset:2048" FA_W64_KV_POL " lds" "\n\t"
+                   "buffer_load_dwordx4 %4, %6, 0 offen offset:3072" FA_W64_KV_POL " lds" "\n\t"
                    "s_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "s"(dst), "s"(srd) : "memory");
     } else {
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                   "buffer_load_dwordx4 %1, %4, 0 offen lds\n\t"
-                   "buffer_load_dwordx4 %2, %4, 0 offen offset:1024 lds\n\t"
+                   "buffer_load_dwordx4 %1, %4, 0 offen" FA_W64_KV_POL " lds" "\n\t"
+                   "buffer_load_dwordx4 %2, %4, 0 offen offset:1024" FA_W64_KV_POL " lds" "\n\t"
                    "s_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(vo[0]), "v"(vo[DPW - 1]), "s"(dst), "s"(srd) : "memory");
     }
@@ -686,9 +706,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
         asm volatile("" : "+s"(wv));   // (compared here, as a scalar: hoisted, the sixteen compares become lane masks and cost two VALU per slot)
         if (wv == own) {
           if constexpr (pc == 0)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen" FA_W64_KV_POL " lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
           else
-            asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2 lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2" FA_W64_KV_POL " lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
         }
       }
       if constexpr (false) {
@@ -699,9 +719,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #endif
         // (the tile's byte offset rides in the scalar-offset operand; the range check accounts for it: tools/ubench/lds_dma_oob.hip)
         if constexpr (pc == 0)
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen" FA_W64_KV_POL " lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
         else
-          asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2 lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
+          asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2" FA_W64_KV_POL " lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
       }
       if constexpr (ALIBI) {   // the C broadcasts move on to the next step's keys (the other half of the tile: +32 keys; the next tile down: -96): 32 in-place adds
         constexpr auto ab_end = [](int g) constexpr { return g < 4 ? 0 : (((g - 3) * 32 + (NG - 5)) / (NG - 4) > 32 ? 32 : ((g - 3) * 32 + (NG - 5)) / (NG - 4)); };
@@ -1054,6 +1074,7 @@ int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   // buffer addressing: 32-bit byte offsets from the (batch, kv-head) base
   const uint64_t span = ((uint64_t)(p.sk > 0 ? p.sk : 1) + 128) * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u;
   if (span >= (1ull << 32)) return -3;
+  if (256ull * (uint64_t)(p.q_rs > p.o_rs ? p.q_rs : p.o_rs) * 2u >= (1ull << 32)) return -3;   // Q / O: 32-bit byte offsets over a block's 256 rows
   return dtype_bf16 ? launch_fwd_w64_bf16(p, d, stream) : launch_fwd_w64_f16(p, d, stream);
 }
 #endif

@@ -23,6 +23,10 @@ namespace {
 
 using at::Tensor;
 using OptTensor = std::optional<at::Tensor>;
+// The retired `generator` slot of fwd / varlen_fwd / bwd / varlen_bwd (flash_api.cpp:382-386: kept for argument positions, must be None).  The CUDA
+// extension types it std::optional<at::Tensor>, the ROCm one std::optional<at::Generator> (csrc/flash_attn_ck/mha_fwd.cpp): any Python object is
+// taken here and everything but None is refused with the reference's message.
+using GenSlot = py::object;
 
 #define CHECK_DEVICE(x) TORCH_CHECK((x).is_cuda(), #x " must be on CUDA")
 #define CHECK_LAST_CONTIG(x) TORCH_CHECK((x).stride(-1) == 1, #x " must have contiguous last dimension")
@@ -37,23 +41,13 @@ int dtype_code(const Tensor& q) {
   return q.dtype() == at::kBFloat16 ? FA_DTYPE_BF16 : FA_DTYPE_FP16;
 }
 
-// Head dim the tensors go to the kernels with: their own.  Every multiple of 8 up to 256 is taken as it is -- the six built sizes directly,
-// the sizes in between through the kernels' run-time column bound (FaFwdParams / FaBwdParams::d, fa_api.cpp: head_dim_kernel) -- so the
-// padded-copy path below (pad_d) is dead for every head dim this module accepts; it stays for a library built without that bound.
-int native_head_dim(int64_t d) {
-  TORCH_CHECK(d <= 256, "FlashAttention only supports head dimension at most 256");
-  return (int)d;
-}
-
-Tensor pad_d(const Tensor& x, int64_t d_to) {
-  const int64_t d = x.size(-1);
-  if (d == d_to) return x;
-  return at::constant_pad_nd(x, {0, d_to - d}, 0);
-}
+// Head dim the tensors go to the kernels with: their own.  Every multiple of 8 up to 256 is taken as it is -- the six built sizes directly, the sizes
+// in between through the kernels' run-time column bound (FaFwdParams / FaBwdParams::d, fa_api.cpp: head_dim_kernel): no padded copies anywhere.
+void check_head_dim(int64_t d) { TORCH_CHECK(d <= 256, "FlashAttention only supports head dimension at most 256"); }
 
 void common_checks(const Tensor& q, const Tensor& k, const Tensor& v, double p_dropout, const OptTensor& alibi,
-                   const std::optional<at::Generator>& gen) {
-  TORCH_CHECK(!gen.has_value(), "Passing a `generator` argument is no longer supported; seed the default generator instead");
+                   const GenSlot& gen) {
+  TORCH_CHECK(gen.is_none(), "flash-attn: the RNG `generator` argument is no longer supported and must be None; dropout (when enabled) uses the default generator of the device.");
   TORCH_CHECK(p_dropout >= 0.0 && p_dropout < 1.0, "p_dropout must be in [0, 1)");
   CHECK_DEVICE(q); CHECK_DEVICE(k); CHECK_DEVICE(v);
   TORCH_CHECK(k.dtype() == q.dtype() && v.dtype() == q.dtype(), "query, key and value must have the same dtype");
@@ -103,7 +97,7 @@ void set_alibi(const OptTensor& alibi, int64_t B, int64_t H, const float*& ptr, 
 std::vector<Tensor> mha_fwd(Tensor& q, const Tensor& k, const Tensor& v, OptTensor& out_, OptTensor& alibi_slopes_,
                             const double p_dropout, const double softmax_scale, bool is_causal, int64_t window_size_left,
                             int64_t window_size_right, const double softcap, const bool return_softmax,
-                            std::optional<at::Generator> gen_) {
+                            GenSlot gen_) {
   common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
   TORCH_CHECK(!return_softmax || p_dropout > 0.0, "return_softmax is only supported when p_dropout > 0.0");
   TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.dim() == 4, "q, k, v must be 4-D (batch, seqlen, nheads, headdim)");
@@ -125,15 +119,15 @@ std::vector<Tensor> mha_fwd(Tensor& q, const Tensor& k, const Tensor& v, OptTens
     const int64_t ng = H / Hk;
     Tensor q2 = q.reshape({B, Hk, ng, D}).transpose(1, 2);
     OptTensor none;
-    std::vector<Tensor> r = mha_fwd(q2, k, v, none, none, 0.0, softmax_scale, false, -1, -1, softcap, false, std::nullopt);
+    std::vector<Tensor> r = mha_fwd(q2, k, v, none, none, 0.0, softmax_scale, false, -1, -1, softcap, false, GenSlot(py::none()));
     Tensor o = r[0].transpose(1, 2).reshape({B, 1, H, D});
     if (out_.has_value()) { out_->copy_(o); o = *out_; }
     return {o, r[1].reshape({B, H, 1}), r[2], r[3]};
   }
-  const int64_t Dn = native_head_dim(D);
-  const Tensor qp = pad_d(q, Dn), kp = pad_d(k, Dn), vp = pad_d(v, Dn);
+  check_head_dim(D);
+  const Tensor &qp = q, &kp = k, &vp = v;
   Tensor out;
-  out = (out_.has_value() && Dn == D) ? *out_ : at::empty({B, Sq, H, Dn}, q.options());
+  out = out_.has_value() ? *out_ : at::empty({B, Sq, H, D}, q.options());
   Tensor lse = at::empty({B, H, Sq}, q.options().dtype(at::kFloat));
   Tensor rng_state = make_rng_state(q, p_dropout, B, H);
   // return_softmax: the random byte of every (query, key) pair, the ROCm backend's payload (csrc/flash_attn_ck/mha_fwd.cpp:275-279)
@@ -149,7 +143,7 @@ std::vector<Tensor> mha_fwd(Tensor& q, const Tensor& k, const Tensor& v, OptTens
     a.v_batch_stride = vp.stride(0); a.v_row_stride = vp.stride(1); a.v_head_stride = vp.stride(2);
     a.o_batch_stride = out.stride(0); a.o_row_stride = out.stride(1); a.o_head_stride = out.stride(2);
     set_alibi(alibi_slopes_, B, H, a.alibi_slopes, a.alibi_batch_stride);
-    a.b = B; a.h = H; a.h_k = Hk; a.d = Dn; a.seqlen_q = Sq; a.seqlen_k = Sk; a.total_q = B * Sq;
+    a.b = B; a.h = H; a.h_k = Hk; a.d = (int)D; a.seqlen_q = Sq; a.seqlen_k = Sk; a.total_q = B * Sq;
     a.dtype = dtype_code(q);
     a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
     a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap;
@@ -163,11 +157,6 @@ std::vector<Tensor> mha_fwd(Tensor& q, const Tensor& k, const Tensor& v, OptTens
     }
     fa_check(fa_fwd(&a, cur_stream(q)));
   }
-  if (Dn != D) {
-    Tensor res = out.slice(-1, 0, D);
-    if (out_.has_value()) { out_->copy_(res); res = *out_; }
-    out = res;
-  }
   return {out, lse, p, rng_state};
 }
 
@@ -176,7 +165,7 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
                                    OptTensor& block_table_, OptTensor& alibi_slopes_, int64_t max_seqlen_q,
                                    const int64_t max_seqlen_k, const double p_dropout, const double softmax_scale,
                                    const bool zero_tensors, bool is_causal, int64_t window_size_left, int64_t window_size_right,
-                                   const double softcap, const bool return_softmax, std::optional<at::Generator> gen_,
+                                   const double softcap, const bool return_softmax, GenSlot gen_,
                                    const int64_t num_splits) {
   common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
   TORCH_CHECK(!return_softmax || p_dropout > 0.0, "return_softmax is only supported when p_dropout > 0.0");
@@ -232,7 +221,7 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
     Tensor cu_q2 = at::arange(0, (B + 1) * ng, ng, cu_seqlens_q.options());
     OptTensor none;
     std::vector<Tensor> r = mha_varlen_fwd(q2, k, v, none, cu_q2, cu_seqlens_k, seqused_k, leftpad_k_, block_table_, none, ng, max_seqlen_k, 0.0,
-                                           softmax_scale, zero_tensors, false, -1, -1, softcap, false, std::nullopt, num_splits);
+                                           softmax_scale, zero_tensors, false, -1, -1, softcap, false, GenSlot(py::none()), num_splits);
     Tensor o = r[0].reshape({B, ng, Hk, D}).transpose(1, 2).reshape({B, H, D});
     if (out_.has_value()) {
       TORCH_CHECK(out_->dtype() == q.dtype(), "Output must have the same dtype as inputs");
@@ -242,13 +231,13 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
     // lse (Hk, B*ng) -> (H, B): head hk*ng + g of sequence b sits at [hk][b*ng + g]
     return {o, r[1].reshape({Hk, B, ng}).permute({0, 2, 1}).reshape({H, B}), r[2], r[3]};
   }
-  const int64_t Dn = native_head_dim(D);
-  const Tensor qp = pad_d(q, Dn), kp = pad_d(k, Dn), vp = pad_d(v, Dn);
+  check_head_dim(D);
+  const Tensor &qp = q, &kp = k, &vp = v;
   if (out_.has_value()) {
     TORCH_CHECK(out_->dtype() == q.dtype(), "Output must have the same dtype as inputs");
     CHECK_DEVICE(*out_); CHECK_LAST_CONTIG(*out_); CHECK_SHAPE(*out_, total_q, H, D);
   }
-  Tensor out = (out_.has_value() && Dn == D) ? *out_ : at::empty({total_q, H, Dn}, q.options());
+  Tensor out = out_.has_value() ? *out_ : at::empty({total_q, H, D}, q.options());
   Tensor lse = at::empty({H, total_q}, q.options().dtype(at::kFloat));
   Tensor rng_state = make_rng_state(q, p_dropout, B, H);
   // varlen payload layout of the ROCm backend: (nheads, total_q, max_seqlen_k)
@@ -278,7 +267,7 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
     a.cu_seqlens_q = cu_seqlens_q.data_ptr<int>(); a.cu_seqlens_k = cu_seqlens_k.data_ptr<int>();
     a.seqused_k = seqused_k.has_value() ? seqused_k->data_ptr<int>() : nullptr;
     set_alibi(alibi_slopes_, B, H, a.alibi_slopes, a.alibi_batch_stride);
-    a.b = B; a.h = H; a.h_k = Hk; a.d = Dn; a.seqlen_q = (int)max_seqlen_q; a.seqlen_k = (int)max_seqlen_k; a.total_q = total_q;
+    a.b = B; a.h = H; a.h_k = Hk; a.d = (int)D; a.seqlen_q = (int)max_seqlen_q; a.seqlen_k = (int)max_seqlen_k; a.total_q = total_q;
     a.dtype = dtype_code(q);
     a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
     a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap;
@@ -297,11 +286,6 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
       a.workspace = ws.data_ptr(); a.workspace_bytes = ws_bytes;
     }
     fa_check(fa_varlen_fwd(&a, cur_stream(q)));
-  }
-  if (Dn != D) {
-    Tensor res = out.slice(-1, 0, D);
-    if (out_.has_value()) { out_->copy_(res); res = *out_; }
-    out = res;
   }
   return {out, lse, p, rng_state};
 }
@@ -343,7 +327,7 @@ std::vector<Tensor> mha_bwd(const Tensor& dout, const Tensor& q, const Tensor& k
                             const Tensor& softmax_lse, OptTensor& dq_, OptTensor& dk_, OptTensor& dv_, OptTensor& alibi_slopes_,
                             const double p_dropout, const double softmax_scale, const bool is_causal, int64_t window_size_left,
                             int64_t window_size_right, const double softcap, const bool deterministic,
-                            std::optional<at::Generator> gen_, OptTensor& rng_state) {
+                            GenSlot gen_, OptTensor& rng_state) {
   common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
   CHECK_DEVICE(dout); CHECK_DEVICE(out); CHECK_DEVICE(softmax_lse);
   TORCH_CHECK(dout.dtype() == q.dtype() && out.dtype() == q.dtype(), "query and dout/out must have the same dtype");
@@ -364,26 +348,18 @@ std::vector<Tensor> mha_bwd(const Tensor& dout, const Tensor& q, const Tensor& k
     dq.zero_(); dk.zero_(); dv.zero_(); delta.zero_();
     return {dq, dk, dv, delta};
   }
-  const int64_t Dn = native_head_dim(D);
-  BwdBufs t{pad_d(dout, Dn), pad_d(q, Dn), pad_d(k, Dn), pad_d(v, Dn), pad_d(out, Dn), dq, dk, dv};
-  if (Dn != D) {
-    t.dq = at::empty({B, Sq, H, Dn}, q.options());
-    t.dk = at::empty({B, Sk, Hk, Dn}, q.options());
-    t.dv = at::empty({B, Sk, Hk, Dn}, q.options());
-  }
+  check_head_dim(D);
+  BwdBufs t{dout, q, k, v, out, dq, dk, dv};
   FaBwdParams a{};
   fill_bwd_ptrs(a, t, softmax_lse, delta);
   SET3(do, t.dout) SET3(q, t.q) SET3(k, t.k) SET3(v, t.v) SET3(o, t.out) SET3(dq, t.dq) SET3(dk, t.dk) SET3(dv, t.dv)
   set_alibi(alibi_slopes_, B, H, a.alibi_slopes, a.alibi_batch_stride);
-  a.b = B; a.h = H; a.h_k = Hk; a.d = Dn; a.seqlen_q = Sq; a.seqlen_k = Sk; a.total_q = B * Sq; a.total_k = B * Sk;
+  a.b = B; a.h = H; a.h_k = Hk; a.d = (int)D; a.seqlen_q = Sq; a.seqlen_k = Sk; a.total_q = B * Sq; a.total_k = B * Sk;
   a.dtype = dtype_code(q);
   a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
   a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap; a.deterministic = deterministic;
   a.p_dropout = (float)p_dropout; a.rng_state = bwd_rng(p_dropout, rng_state);
   run_bwd(a, q, false);
-  if (Dn != D) {
-    dq.copy_(t.dq.slice(-1, 0, D)); dk.copy_(t.dk.slice(-1, 0, D)); dv.copy_(t.dv.slice(-1, 0, D));
-  }
   return {dq, dk, dv, delta};
 }
 
@@ -393,7 +369,7 @@ std::vector<Tensor> mha_varlen_bwd(const Tensor& dout, const Tensor& q, const Te
                                    const int64_t max_seqlen_q, const int64_t max_seqlen_k, const double p_dropout,
                                    const double softmax_scale, const bool zero_tensors, const bool is_causal,
                                    int64_t window_size_left, int64_t window_size_right, const double softcap,
-                                   const bool deterministic, std::optional<at::Generator> gen_, OptTensor& rng_state) {
+                                   const bool deterministic, GenSlot gen_, OptTensor& rng_state) {
   common_checks(q, k, v, p_dropout, alibi_slopes_, gen_);
   CHECK_DEVICE(dout); CHECK_DEVICE(out); CHECK_DEVICE(softmax_lse); CHECK_DEVICE(cu_seqlens_q); CHECK_DEVICE(cu_seqlens_k);
   TORCH_CHECK(dout.dtype() == q.dtype() && out.dtype() == q.dtype(), "query and dout/out must have the same dtype");
@@ -417,28 +393,20 @@ std::vector<Tensor> mha_varlen_bwd(const Tensor& dout, const Tensor& q, const Te
     dq.zero_(); dk.zero_(); dv.zero_(); delta.zero_();
     return {dq, dk, dv, delta};
   }
-  const int64_t Dn = native_head_dim(D);
-  BwdBufs t{pad_d(dout, Dn), pad_d(q, Dn), pad_d(k, Dn), pad_d(v, Dn), pad_d(out, Dn), dq, dk, dv};
-  if (Dn != D) {
-    t.dq = at::empty({total_q, H, Dn}, q.options());
-    t.dk = at::empty({total_k, Hk, Dn}, q.options());
-    t.dv = at::empty({total_k, Hk, Dn}, q.options());
-  }
+  check_head_dim(D);
+  BwdBufs t{dout, q, k, v, out, dq, dk, dv};
   FaBwdParams a{};
   fill_bwd_ptrs(a, t, softmax_lse, delta);
   SET2(do, t.dout) SET2(q, t.q) SET2(k, t.k) SET2(v, t.v) SET2(o, t.out) SET2(dq, t.dq) SET2(dk, t.dk) SET2(dv, t.dv)
   a.cu_seqlens_q = cu_seqlens_q.data_ptr<int>(); a.cu_seqlens_k = cu_seqlens_k.data_ptr<int>();
   set_alibi(alibi_slopes_, B, H, a.alibi_slopes, a.alibi_batch_stride);
-  a.b = B; a.h = H; a.h_k = Hk; a.d = Dn; a.seqlen_q = (int)max_seqlen_q; a.seqlen_k = (int)max_seqlen_k;
+  a.b = B; a.h = H; a.h_k = Hk; a.d = (int)D; a.seqlen_q = (int)max_seqlen_q; a.seqlen_k = (int)max_seqlen_k;
   a.total_q = total_q; a.total_k = total_k;
   a.dtype = dtype_code(q);
   a.is_causal = is_causal; a.window_left = (int)window_size_left; a.window_right = (int)window_size_right;
   a.softmax_scale = (float)softmax_scale; a.softcap = (float)softcap; a.deterministic = deterministic;
   a.p_dropout = (float)p_dropout; a.rng_state = bwd_rng(p_dropout, rng_state);
   run_bwd(a, q, true);
-  if (Dn != D) {
-    dq.copy_(t.dq.slice(-1, 0, D)); dk.copy_(t.dk.slice(-1, 0, D)); dv.copy_(t.dv.slice(-1, 0, D));
-  }
   return {dq, dk, dv, delta};
 }
 
@@ -485,8 +453,28 @@ std::vector<Tensor> mha_fwd_kvcache(Tensor& q, const Tensor& kcache, const Tenso
   const int64_t page = paged ? kcache.size(1) : 0;
   const int64_t Sk = paged ? block_table_->size(1) * page : kcache.size(1);
   TORCH_CHECK(B > 0, "batch size must be positive");
-  // (a cache cannot be padded on the fly: head dims between the built sizes run the forward with a run-time column bound)
-  TORCH_CHECK(D % 8 == 0 && D <= 256, "libfa_gfx950: fwd_kvcache takes head dimensions that are a multiple of 8, up to 256");
+  TORCH_CHECK(D <= 256, "FlashAttention forward only supports head dimension at most 256");
+  if (D % 8 != 0) {
+    // flash_api.cpp:1340-1350, 1517-1527: q and BOTH caches are zero-padded to the next multiple of 8 (copies of the whole cache -- "we don't expect
+    // to get this case in practice", the reference says of it), the call runs on the copies, and appended keys / values are copied back.
+    // (Head dims that ARE multiples of 8 but have no kernel of their own never copy: they run behind the kernels' run-time column bound.)
+    const int64_t pad = 8 - D % 8;
+    auto padded = [pad](const Tensor& t) { return at::constant_pad_nd(t, {0, pad}, 0); };
+    Tensor q_p = padded(q), kc_p = padded(kcache), vc_p = padded(vcache);
+    OptTensor k_p = k_.has_value() ? OptTensor(padded(*k_)) : OptTensor();
+    OptTensor v_p = v_.has_value() ? OptTensor(padded(*v_)) : OptTensor();
+    OptTensor no_out;
+    std::vector<Tensor> r = mha_fwd_kvcache(q_p, kc_p, vc_p, k_p, v_p, seqlens_k_, rotary_cos_, rotary_sin_, cache_batch_idx_, leftpad_k_, block_table_,
+                                            alibi_slopes_, no_out, softmax_scale, is_causal, window_size_left, window_size_right, softcap,
+                                            is_rotary_interleaved, num_splits);
+    Tensor out = r[0].slice(-1, 0, D);
+    if (out_.has_value()) { out_->copy_(out); out = *out_; }
+    if (k_.has_value()) {
+      const_cast<Tensor&>(kcache).copy_(kc_p.slice(-1, 0, D));
+      const_cast<Tensor&>(vcache).copy_(vc_p.slice(-1, 0, D));
+    }
+    return {out, r[1]};
+  }
   TORCH_CHECK(H % Hk == 0, "Number of heads in key/value must divide number of heads in query");
   TORCH_CHECK(kcache.size(3) == D && vcache.sizes() == kcache.sizes(), "kcache / vcache shape mismatch");
   if (paged) {

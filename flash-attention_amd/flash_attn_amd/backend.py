@@ -57,18 +57,11 @@ def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def _native_d(d: int) -> int:
-    for n in _NATIVE_HEAD_DIMS:
-        if d <= n:
-            return n
-    raise RuntimeError(f"FlashAttention only supports head dimension at most 256 (got {d})")
-
-
-def _pad_d(x: torch.Tensor, d_to: int) -> torch.Tensor:
-    d = x.shape[-1]
-    if d == d_to:
-        return x
-    return torch.nn.functional.pad(x, (0, d_to - d))
+def _check_d(d: int) -> None:
+    """The C ABI takes every head dim that is a multiple of 8 up to 256 as it is (the six built sizes directly, the sizes in between through the
+    kernels' run-time column bound, fa_gfx950.h FaFwdParams::d): no padded copies on this side either."""
+    if d > 256:
+        raise RuntimeError(f"FlashAttention only supports head dimension at most 256 (got {d})")
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -148,9 +141,9 @@ def fwd(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, windo
             out_.copy_(out)
             out = out_
         return [out, l2.reshape(B, H, 1), p2, r2]
-    Dn = _native_d(D)
-    qp, kp, vp = _pad_d(q, Dn), _pad_d(k, Dn), _pad_d(v, Dn)
-    out = out_ if (out_ is not None and Dn == D) else torch.empty((B, Sq, H, Dn), dtype=q.dtype, device=q.device)
+    _check_d(D)
+    qp, kp, vp = q, k, v
+    out = out_ if out_ is not None else torch.empty((B, Sq, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     rng_state = _new_rng_state(q.device, p_dropout, B, H)
     # return_softmax: the random byte of every (query, key) pair, the ROCm backend's payload (mha_fwd.cpp:275-279)
@@ -168,7 +161,7 @@ def fwd(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, windo
         a.v_batch_stride, a.v_row_stride, a.v_head_stride = vp.stride(0), vp.stride(1), vp.stride(2)
         a.o_batch_stride, a.o_row_stride, a.o_head_stride = out.stride(0), out.stride(1), out.stride(2)
         a.alibi_slopes, a.alibi_batch_stride = _ptr(alibi), alibi_bs
-        a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
+        a.b, a.h, a.h_k, a.d = B, H, Hk, D
         a.seqlen_q, a.seqlen_k, a.total_q = Sq, Sk, B * Sq
         a.dtype = _dtype_code(q)
         a.is_causal, a.window_left, a.window_right = int(bool(is_causal)), int(window_size_left), int(window_size_right)
@@ -180,12 +173,6 @@ def fwd(q, k, v, out_, alibi_slopes_, p_dropout, softmax_scale, is_causal, windo
                 a.randval_batch_stride, a.randval_head_stride, a.randval_row_stride = p_out.stride(0), p_out.stride(1), p_out.stride(2)
         with torch.cuda.device(q.device):
             _cabi.check(_cabi.load().fa_fwd(C.byref(a), C.c_void_p(_stream_ptr(q.device))))
-    if Dn != D:
-        res = out[..., :D]
-        if out_ is not None:
-            out_.copy_(res)
-            res = out_
-        out = res
     return [out, lse, p_out, rng_state]
 
 
@@ -252,9 +239,9 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
     if seqused_q is not None and (seqused_q.dtype != torch.int32 or seqused_q.numel() != B or not seqused_q.is_contiguous()):
         raise RuntimeError("seqused_q must be a contiguous int32 tensor of shape (batch_size)")
     _check_dev(seqused_q)
-    Dn = _native_d(D)
-    qp, kp, vp = _pad_d(q, Dn), _pad_d(k, Dn), _pad_d(v, Dn)
-    out = out_ if (out_ is not None and Dn == D) else torch.empty((total_q, H, Dn), dtype=q.dtype, device=q.device)
+    _check_d(D)
+    qp, kp, vp = q, k, v
+    out = out_ if out_ is not None else torch.empty((total_q, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((H, total_q), dtype=torch.float32, device=q.device)
     rng_state = _new_rng_state(q.device, p_dropout, B, H)
     # varlen payload layout of the ROCm backend: (nheads, total_q, max_seqlen_k) (mha_varlen_fwd.cpp)
@@ -283,7 +270,7 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
         a.cu_seqlens_q, a.cu_seqlens_k, a.seqused_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k), _ptr(seqused_k)
         a.seqused_q = _ptr(seqused_q)
         a.alibi_slopes, a.alibi_batch_stride = _ptr(alibi), alibi_bs
-        a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
+        a.b, a.h, a.h_k, a.d = B, H, Hk, D
         a.seqlen_q, a.seqlen_k, a.total_q = int(max_seqlen_q), int(max_seqlen_k), total_q
         a.dtype = _dtype_code(q)
         a.is_causal, a.window_left, a.window_right = int(bool(is_causal)), int(window_size_left), int(window_size_right)
@@ -300,12 +287,6 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
                 ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=q.device)
                 a.workspace, a.workspace_bytes = _ptr(ws), ws_bytes
             _cabi.check(lib.fa_varlen_fwd(C.byref(a), C.c_void_p(_stream_ptr(q.device))))
-    if Dn != D:
-        res = out[..., :D]
-        if out_ is not None:
-            out_.copy_(res)
-            res = out_
-        out = res
     return [out, lse, p_out, rng_state]
 
 
@@ -371,12 +352,8 @@ def bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, alibi_slopes_, p_dropout
     if Sq == 0 or Sk == 0:  # flash_api.cpp:992-999
         dq.zero_(); dk.zero_(); dv.zero_(); delta.zero_()
         return [dq, dk, dv, delta]
-    Dn = _native_d(D)
-    if Dn != D:
-        dop, qp, kp, vp, op = (_pad_d(t, Dn) for t in (dout, q, k, v, out))
-        dqp, dkp, dvp = (torch.empty(t.shape[:-1] + (Dn,), dtype=t.dtype, device=t.device) for t in (q, k, v))
-    else:
-        dop, qp, kp, vp, op, dqp, dkp, dvp = dout, q, k, v, out, dq, dk, dv
+    _check_d(D)
+    dop, qp, kp, vp, op, dqp, dkp, dvp = dout, q, k, v, out, dq, dk, dv
     alibi, alibi_bs = _alibi_args(alibi_slopes_, B, H)
     a = _cabi.FaBwdParams()
     _fill_bwd_common(a, dop, qp, kp, vp, op, softmax_lse, dqp, dkp, dvp, delta, alibi, alibi_bs,
@@ -385,14 +362,12 @@ def bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, alibi_slopes_, p_dropout
         setattr(a, nm + "_batch_stride", t.stride(0))
         setattr(a, nm + "_row_stride", t.stride(1))
         setattr(a, nm + "_head_stride", t.stride(2))
-    a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
+    a.b, a.h, a.h_k, a.d = B, H, Hk, D
     a.seqlen_q, a.seqlen_k, a.total_q, a.total_k = Sq, Sk, B * Sq, B * Sk
     rng = _bwd_rng(p_dropout, rng_state, q.device)
     if rng is not None:
         a.p_dropout, a.rng_state = float(p_dropout), _ptr(rng)
     _run_bwd(a, q.device, False)
-    if Dn != D:
-        dq.copy_(dqp[..., :D]); dk.copy_(dkp[..., :D]); dv.copy_(dvp[..., :D])
     return [dq, dk, dv, delta]
 
 
@@ -419,13 +394,8 @@ def varlen_bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, cu_seqlens_q, cu_
     if max_seqlen_q == 0 or total_q == 0 or total_k == 0:
         dk.zero_(); dv.zero_(); delta.zero_(); dq.zero_()
         return [dq, dk, dv, delta]
-    Dn = _native_d(D)
-    if Dn != D:
-        dop, qp, kp, vp, op = (_pad_d(t, Dn) for t in (dout, q, k, v, out))
-        alloc = torch.zeros if zero_tensors else torch.empty
-        dqp, dkp, dvp = (alloc(t.shape[:-1] + (Dn,), dtype=t.dtype, device=t.device) for t in (q, k, v))
-    else:
-        dop, qp, kp, vp, op, dqp, dkp, dvp = dout, q, k, v, out, dq, dk, dv
+    _check_d(D)
+    dop, qp, kp, vp, op, dqp, dkp, dvp = dout, q, k, v, out, dq, dk, dv
     alibi, alibi_bs = _alibi_args(alibi_slopes_, B, H)
     a = _cabi.FaBwdParams()
     _fill_bwd_common(a, dop, qp, kp, vp, op, softmax_lse, dqp, dkp, dvp, delta, alibi, alibi_bs,
@@ -439,14 +409,12 @@ def varlen_bwd(dout, q, k, v, out, softmax_lse, dq_, dk_, dv_, cu_seqlens_q, cu_
             raise RuntimeError(nm + " must be a contiguous int32 tensor of shape (batch_size)")
     _check_dev(seqused_q, seqused_k)
     a.seqused_q, a.seqused_k = _ptr(seqused_q), _ptr(seqused_k)
-    a.b, a.h, a.h_k, a.d = B, H, Hk, Dn
+    a.b, a.h, a.h_k, a.d = B, H, Hk, D
     a.seqlen_q, a.seqlen_k, a.total_q, a.total_k = int(max_seqlen_q), int(max_seqlen_k), total_q, total_k
     rng = _bwd_rng(p_dropout, rng_state, q.device)
     if rng is not None:
         a.p_dropout, a.rng_state = float(p_dropout), _ptr(rng)
     _run_bwd(a, q.device, True)
-    if Dn != D:
-        dq.copy_(dqp[..., :D]); dk.copy_(dkp[..., :D]); dv.copy_(dvp[..., :D])
     return [dq, dk, dv, delta]
 
 
@@ -499,8 +467,25 @@ def fwd_kvcache(q, kcache, vcache, k_, v_, seqlens_k_, rotary_cos_, rotary_sin_,
     Hk = kcache.shape[2]
     page = kcache.shape[1] if paged else 0
     Sk = block_table_.shape[1] * page if paged else kcache.shape[1]
-    if D % 8 != 0 or D > 256:
-        raise RuntimeError("libfa_gfx950: fwd_kvcache takes head dimensions that are a multiple of 8, up to 256")
+    if D > 256:
+        raise RuntimeError("FlashAttention forward only supports head dimension at most 256")
+    if D % 8 != 0:
+        # flash_api.cpp:1340-1350, 1517-1527: q and both caches zero-padded to the next multiple of 8 (whole-cache copies, as in the reference), the call
+        # runs on the copies, appended keys / values are copied back
+        pad = 8 - D % 8
+        P = lambda t: None if t is None else torch.nn.functional.pad(t, (0, pad))
+        kc_p, vc_p = P(kcache), P(vcache)
+        o, lse = fwd_kvcache(P(q), kc_p, vc_p, P(k_), P(v_), seqlens_k_, rotary_cos_, rotary_sin_, cache_batch_idx_, leftpad_k_, block_table_,
+                             alibi_slopes_, None, softmax_scale, is_causal, window_size_left, window_size_right, softcap,
+                             is_rotary_interleaved, num_splits)
+        o = o[..., :D]
+        if out_ is not None:
+            out_.copy_(o)
+            o = out_
+        if k_ is not None:
+            kcache.copy_(kc_p[..., :D])
+            vcache.copy_(vc_p[..., :D])
+        return [o, lse]
     if H % Hk != 0:
         raise RuntimeError("Number of heads in key/value must divide number of heads in query")
     if paged and page % 256 != 0:

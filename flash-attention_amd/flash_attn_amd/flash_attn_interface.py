@@ -129,6 +129,47 @@ def _varlen_bwd_fake(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, 
     return torch.empty((H, total_q), dtype=torch.float32, device=q.device)
 
 
+# The fused unpad -> attention -> pad path (flash_attn_padded_func) as custom ops too: the varlen kernels with C ABI v6's seqused_q / seqused_k next to
+# cu_seqlens.  The extension module keeps the reference's positional signatures, so these two go through the ctypes binder of the same C ABI.
+def _padded_fwd_impl(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor, seqused_q: torch.Tensor,
+                     cu_seqlens_k: torch.Tensor, seqused_k: torch.Tensor, max_seqlen_q: int, max_seqlen_k: int, dropout_p: float,
+                     softmax_scale: float, causal: bool, window_size_left: int, window_size_right: int, softcap: float,
+                     alibi_slopes: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    from . import backend as be
+    q, k, v = (_unit_stride_last(t) for t in (q, k, v))
+    out, lse, _, rng_state = be.varlen_fwd(q, k, v, None, cu_seqlens_q, cu_seqlens_k, seqused_k, None, None, alibi_slopes, max_seqlen_q,
+                                           max_seqlen_k, dropout_p, softmax_scale, True, causal, window_size_left, window_size_right,
+                                           softcap, False, None, 0, seqused_q=seqused_q)
+    return out, lse, rng_state
+
+
+def _padded_fwd_fake(q, k, v, cu_seqlens_q, seqused_q, cu_seqlens_k, seqused_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
+                     causal, window_size_left, window_size_right, softcap, alibi_slopes):
+    total_q, H, _ = q.shape
+    return (torch.empty_like(q), torch.empty((H, total_q), dtype=torch.float32, device=q.device),
+            torch.empty((2,), dtype=torch.int64, device=q.device))
+
+
+def _padded_bwd_impl(dout: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, softmax_lse: torch.Tensor,
+                     dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cu_seqlens_q: torch.Tensor, seqused_q: torch.Tensor,
+                     cu_seqlens_k: torch.Tensor, seqused_k: torch.Tensor, max_seqlen_q: int, max_seqlen_k: int, dropout_p: float,
+                     softmax_scale: float, causal: bool, window_size_left: int, window_size_right: int, softcap: float,
+                     alibi_slopes: Optional[torch.Tensor], deterministic: bool, rng_state: Optional[torch.Tensor] = None) -> torch.Tensor:
+    from . import backend as be
+    dout, q, k, v, out = (_unit_stride_last(t) for t in (dout, q, k, v, out))
+    _, _, _, softmax_d = be.varlen_bwd(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, cu_seqlens_k, alibi_slopes, max_seqlen_q,
+                                       max_seqlen_k, dropout_p, softmax_scale, True, causal, window_size_left, window_size_right, softcap,
+                                       deterministic, None, rng_state, seqused_q=seqused_q, seqused_k=seqused_k)
+    return softmax_d
+
+
+def _padded_bwd_fake(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_seqlens_q, seqused_q, cu_seqlens_k, seqused_k, max_seqlen_q,
+                     max_seqlen_k, dropout_p, softmax_scale, causal, window_size_left, window_size_right, softcap, alibi_slopes,
+                     deterministic, rng_state=None):
+    total_q, H, _ = q.shape
+    return torch.empty((H, total_q), dtype=torch.float32, device=q.device)
+
+
 def _register(name, impl, fake, mutates=()):
     op = torch.library.custom_op(f"flash_attn_amd::{name}", impl, mutates_args=mutates, device_types="cuda")
     op.register_fake(fake)
@@ -138,6 +179,8 @@ def _register(name, impl, fake, mutates=()):
 _flash_attn_forward = _register("_flash_attn_forward", _fwd_impl, _fwd_fake)
 _flash_attn_varlen_forward = _register("_flash_attn_varlen_forward", _varlen_fwd_impl, _varlen_fwd_fake)
 _flash_attn_backward = _register("_flash_attn_backward", _bwd_impl, _bwd_fake, ("dq", "dk", "dv"))
+_flash_attn_padded_forward = _register("_flash_attn_padded_forward", _padded_fwd_impl, _padded_fwd_fake)
+_flash_attn_padded_backward = _register("_flash_attn_padded_backward", _padded_bwd_impl, _padded_bwd_fake, ("dq", "dk", "dv"))
 _flash_attn_varlen_backward = _register("_flash_attn_varlen_backward", _varlen_bwd_impl, _varlen_bwd_fake, ("dq", "dk", "dv"))
 
 
@@ -261,7 +304,6 @@ class _PaddedAttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, cu_q, len_q, cu_k, len_k, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
                 deterministic):
-        from . import backend as be   # (the extension module keeps the reference's positional signatures; the extra arguments go through the ctypes binder)
         B, Sq, H, D = q.shape
         Sk = k.shape[1]
         needs_grad = any(t.requires_grad for t in (q, k, v))   # (before the head-dim padding: its outputs carry no grad flag in here)
@@ -269,9 +311,8 @@ class _PaddedAttnFn(torch.autograd.Function):
             softmax_scale = D ** (-0.5)
         q, k, v = _pad_head_dim(q, k, v)
         qf, kf, vf = (_unit_stride_last(t).reshape(-1, t.shape[2], t.shape[3]) for t in (q, k, v))
-        out, lse, _, rng_state = be.varlen_fwd(qf, kf, vf, None, cu_q, cu_k, len_k, None, None, alibi_slopes, Sq, Sk, dropout_p,
-                                               softmax_scale, True, causal, window_size[0], window_size[1], softcap, False, None, 0,
-                                               seqused_q=len_q)
+        out, lse, rng_state = _flash_attn_padded_forward(qf, kf, vf, cu_q, len_q, cu_k, len_k, Sq, Sk, dropout_p, softmax_scale, causal,
+                                                         window_size[0], window_size[1], softcap, alibi_slopes)
         if needs_grad:
             ctx.save_for_backward(qf, kf, vf, out, lse, cu_q, len_q, cu_k, len_k, rng_state)
             ctx.cfg = (Sq, Sk, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic, D, q.shape, k.shape)
@@ -279,14 +320,13 @@ class _PaddedAttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        from . import backend as be
         qf, kf, vf, out, lse, cu_q, len_q, cu_k, len_k, rng_state = ctx.saved_tensors
         Sq, Sk, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic, d_orig, q_shape, k_shape = ctx.cfg
         (dout_p,) = _pad_head_dim(dout) if dout.shape[-1] % 8 else (dout,)
         dof = dout_p.contiguous().reshape(-1, dout_p.shape[2], dout_p.shape[3])
-        dq, dk, dv, _ = be.varlen_bwd(dof, qf, kf, vf, out, lse, None, None, None, cu_q, cu_k, alibi_slopes, Sq, Sk, dropout_p,
-                                      softmax_scale, True, causal, window_size[0], window_size[1], softcap, deterministic, None,
-                                      rng_state, seqused_q=len_q, seqused_k=len_k)
+        dq, dk, dv = torch.empty_like(qf), torch.empty_like(kf), torch.empty_like(vf)   # (zero_tensors: the kernels' launcher clears them first)
+        _flash_attn_padded_backward(dof, qf, kf, vf, out, lse, dq, dk, dv, cu_q, len_q, cu_k, len_k, Sq, Sk, dropout_p, softmax_scale, causal,
+                                    window_size[0], window_size[1], softcap, alibi_slopes, deterministic, rng_state)
         return (dq.reshape(q_shape)[..., :d_orig], dk.reshape(k_shape)[..., :d_orig], dv.reshape(k_shape)[..., :d_orig]) + (None,) * 11
 
 
@@ -301,11 +341,16 @@ def flash_attn_padded_func(q, k, v, seqlens_q, seqlens_k=None, starts_q=None, st
     B, Sq = q.shape[0], q.shape[1]
     Sk = k.shape[1]
 
+    if B == 0 or Sq == 0 or Sk == 0:   # nothing to attend: the padded output (and, through autograd, the gradients) are zeros
+        return (q * 0.0) + (k.sum() + v.sum()) * 0.0 if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v)) else torch.zeros_like(q)
+
     def _args(S, lens, starts):
-        lens = lens.to(torch.int32).contiguous()
+        # clamped on the device, no host synchronisation: a run may not leave its entry (starts[b] + seqlens[b] <= S), or the kernels would read the
+        # next entry's rows and, for the last entry, read and write past the end of the tensors
+        st = torch.zeros((B,), dtype=torch.int32, device=q.device) if starts is None else starts.to(torch.int32).clamp(0, S)
+        lens = torch.minimum(lens.to(torch.int32).clamp_min(0), S - st).contiguous()
         cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device=q.device)
-        if starts is not None:
-            cu[:B] += starts.to(torch.int32)
+        cu[:B] += st
         return cu, lens
 
     if seqlens_k is None:

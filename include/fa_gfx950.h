@@ -189,7 +189,9 @@ typedef struct FaBwdParams {
   int32_t reserved[3];
   const uint64_t* rng_state;    /* device {seed, offset} the forward used (p_dropout > 0) */
   const int32_t* seqused_q;     /* ABI v6, optional (B): as FaFwdParams::seqused_q; dq rows past it are not written */
-  const int32_t* seqused_k;     /* ABI v6, optional (B): keys of entry b in use; dk / dv rows past it are not written */
+  const int32_t* seqused_k;     /* ABI v6, optional (B): keys of entry b in use -- the SAME rule as the forward's seqused_k: it replaces the
+                                   cu_seqlens_k length of the entry (clamped to seqlen_k = max_seqlen_k), so a forward / backward pair given the
+                                   same arrays attends to and differentiates the same keys; dk / dv rows past it are not written */
 } FaBwdParams;
 
 /* ABI version of the loaded library (== FA_ABI_VERSION of the header it was built from). */

@@ -91,7 +91,9 @@ def test_knobs_override_and_strict(lib, monkeypatch):
     monkeypatch.setenv("FA_FWD_NW", "64"); lib.fa_knobs_reload()
     assert q(lib, fwd_params(2, 300, 300, 4, 4, 128)) == 64
     huge = fwd_params(1, 131072, 131072, 128, 128, 128)                 # K/V rows 32 KB apart: the key range spans > 4 GiB
-    assert q(lib, huge) == 38
+    assert q(lib, huge) == 64                                           # forced: the knob stands, the launcher then refuses with its own message (-3)
+    monkeypatch.delenv("FA_FWD_NW"); lib.fa_knobs_reload()
+    assert q(lib, huge) == 38                                           # the heuristic itself falls back to the pipelined kernel
 
 
 def test_backward_dq_schedule(lib, monkeypatch):

@@ -60,11 +60,11 @@ def test_no_scratch_in_the_hot_kernels():
         for n, v in fam(s).items():
             ints = template_ints(n)
             d, feat = ints[0], ints[feat_at]
-            if d <= 128 and feat < FEAT_DROP:   # none / softcap / ALiBi / softcap + ALiBi
+            if d <= 128 and (feat < FEAT_DROP or feat == 8):   # none / softcap / ALiBi / softcap + ALiBi; 8 = FEAT_EXACT, the dK/dV kernel's default plain variant (round 4)
                 assert v["private_segment_fixed_size"] == 0, (n, v)
                 checked += 1
     assert checked >= 60, checked
     # and the total stays where round 3 left it (default library; build.py --experiments adds kernels of its own)
     if not os.path.exists(os.path.join(ROOT, "flash-attention_amd", "csrc", ".experiments")):
         with_scratch = sorted(n for n, v in ks.items() if v["private_segment_fixed_size"] > 0)
-        assert len(with_scratch) <= 28, with_scratch
+        assert len(with_scratch) <= 31, with_scratch   # (round 4: + the two D = 256 FEAT_EXACT dK/dV variants, 6 spills outside the tile loop like their FEAT_NONE twins)
