@@ -1,11 +1,12 @@
 """Headline benchmark: attention forward (and forward+backward) TFLOP/s on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--windows 5] [--preroll-ms 400] [--no-sweep] [--no-cpu] [--no-traffic]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--windows 5] [--preroll-ms 400] [--no-sweep] [--no-cpu] [--no-traffic] [--no-parity]
 
 Workload (BASELINE.json): config 3 -- B=4 H=32 S=4096 D=128 bf16 causal, synthetic N(0,1) inputs
 resident in HBM.  One "step" = one forward pass of the hot path (fa_fwd through the C ABI); the
-forward+backward rate on the same config and the reference's seqlen sweep (S = 512 .. 16k, D = 128, causal and not) are
-reported as extra keys, `roofline.kernel` is what fa_last_schedule() says the C ABI launched, `roofline.traffic` comes from
+forward+backward rate on the same config, the reference's seqlen sweep (S = 512 .. 16k at D = 128 and D = 64, causal and not), BASELINE's
+configs 2 / 4 / 5 at their real shapes (`configs`) and the error table of the timed workload against PyTorch fp32 / bf16 / an fp64 sample
+(`parity`, default and FA_STRICT numerics) are reported as extra keys, `roofline.kernel` is what fa_last_schedule() says the C ABI launched, `roofline.traffic` comes from
 two rocprofv3 --pmc passes run from here (outside the timed region).  FLOP convention = the reference's (benchmarks/benchmark_flash_attention.py:
 27-30): fwd = 4*B*H*S^2*D (/2 causal), bwd = 2.5x, fwd+bwd = 3.5x.
 Timing: an untimed clock ramp (>= --preroll-ms of the same launch), W counted warm-up launches, then --windows regions of EXACTLY K
@@ -136,11 +137,11 @@ def replica_aggregate(wall_seconds, units_per_rank, world, device="cpu"):
     return world * units_per_rank / wall_max, wall_max
 
 
-def sweep(be, dev, sync):
-    """The reference's headline sweep (benchmarks/benchmark_flash_attention.py:70-78): hidden dim 2048 (H = 16 at D = 128),
-    B = 16384 / S, bf16, dropout 0; TFLOP/s forward and forward+backward, non-causal and causal."""
+def sweep(be, dev, sync, D=128):
+    """The reference's headline sweep (benchmarks/benchmark_flash_attention.py:70-78): hidden dim 2048 (H = 16 at D = 128, 32 at D = 64 -- it
+    sweeps both head dims), B = 16384 / S, bf16, dropout 0; TFLOP/s forward and forward+backward, non-causal and causal."""
     rows = []
-    D, H = 128, 16
+    H = 2048 // D
     for causal in (False, True):
         for S in (512, 1024, 2048, 4096, 8192, 16384):
             B = 16384 // S
@@ -156,7 +157,7 @@ def sweep(be, dev, sync):
             h = lambda: be.bwd(g, q, k, v, o, l, dq, dk, dv, None, 0.0, sc, causal, -1, -1, 0.0, False, None, None)
             _, mb = time_kernel(h, 8, 2, sync)
             fl = fwd_flops(B, H, S, D, causal)
-            rows.append({"seqlen": S, "batch": B, "causal": causal, "fwd_tflops": round(fl / ms / 1e9, 1),
+            rows.append({"seqlen": S, "batch": B, "causal": causal, "fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
                          "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name})
     return {"head_dim": D, "heads": H, "dtype": "bf16", "rows": rows}
 
@@ -180,6 +181,162 @@ def feature_rows(be, dev, sync, B, H, S, D):
         fl = fwd_flops(B, H, S, D, True)
         return {"causal_alibi": {"fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
                                  "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name}}
+    except Exception as e:   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def _visible_pairs(S, causal, window):
+    """Number of visible (query, key) pairs of an S x S problem under a causal / sliding-window mask (bottom-right aligned; here Sq = Sk)."""
+    wl, wr = window
+    if causal:
+        wr = 0
+    i = torch.arange(S, dtype=torch.int64)
+    hi = torch.clamp(i + wr, max=S - 1) if wr >= 0 else torch.full_like(i, S - 1)
+    lo = torch.clamp(i - wl, min=0) if wl >= 0 else torch.zeros_like(i)
+    return int(torch.clamp(hi - lo + 1, min=0).sum())
+
+
+def long_tail_lengths(total=65536, seed=0):
+    """Long-tail sequence lengths in the spirit of benchmarks/benchmark_varlen_sched.py:76-84 (generator seed 0), trimmed to `total` tokens."""
+    g = torch.Generator().manual_seed(seed)
+    lens = []
+    while sum(lens) < total:
+        x = float(torch.rand(1, generator=g))
+        lens.append(max(16, min(int(64 * (1.0 / max(x, 1e-3)) ** 0.9), 16384)))
+    lens[-1] -= sum(lens) - total
+    if lens[-1] <= 0:
+        lens.pop()
+        lens[-1] += total - sum(lens)
+    return lens
+
+
+def config_rows(be, dev, sync):
+    """Extra key `configs`: BASELINE.json configs 2, 4 (i: 16 x 4096, ii: long-tail lengths, both 64k tokens) and 5 at their real shapes -- forward,
+    backward and forward+backward TFLOP/s on the visible (query, key) pairs, and the kernels fa_last_schedule() names.  Never fatal."""
+    rows = []
+
+    def fixed(name, B, S, H, Hk, D, causal, window):
+        q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
+        k = torch.randn(B, S, Hk, D, device=dev, dtype=torch.bfloat16)
+        v = torch.randn_like(k)
+        sc = D ** -0.5
+        f = lambda: be.fwd(q, k, v, None, None, 0.0, sc, causal, window[0], window[1], 0.0, False, None)
+        _, ms = time_kernel(f, 20, 5, sync)
+        sched = be.last_schedule()
+        o, l = f()[:2]
+        g = torch.randn_like(o)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        h = lambda: be.bwd(g, q, k, v, o, l, dq, dk, dv, None, 0.0, sc, causal, window[0], window[1], 0.0, False, None, None)
+        _, mb = time_kernel(h, 8, 2, sync)
+        sb = be.last_schedule()
+        fl = 4.0 * B * H * D * _visible_pairs(S, causal, window)
+        rows.append({"config": name, "fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
+                     "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_ms": round(ms, 4), "bwd_ms": round(mb, 4),
+                     "fwd_kernel": sched["name"], "bwd_dq_waves_x_rows": sb["bwd_dq_nw"], "bwd_dkdv_waves": sb["bwd_dkdv_nw"]})
+
+    def varlen(name, lens, H, D):
+        import itertools
+        cu = torch.tensor([0] + list(itertools.accumulate(lens)), dtype=torch.int32, device=dev)
+        tot, mx = sum(lens), max(lens)
+        q = torch.randn(tot, H, D, device=dev, dtype=torch.bfloat16)
+        k, v = torch.randn_like(q), torch.randn_like(q)
+        sc = D ** -0.5
+        f = lambda: be.varlen_fwd(q, k, v, None, cu, cu, None, None, None, None, mx, mx, 0.0, sc, False, True, -1, -1, 0.0, False, None)
+        _, ms = time_kernel(f, 20, 5, sync)
+        sched = be.last_schedule()
+        o, l = f()[:2]
+        g = torch.randn_like(o)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        h = lambda: be.varlen_bwd(g, q, k, v, o, l, dq, dk, dv, cu, cu, None, mx, mx, 0.0, sc, False, True, -1, -1, 0.0, False, None, None)
+        _, mb = time_kernel(h, 8, 2, sync)
+        sb = be.last_schedule()
+        fl = sum(4.0 * H * D * (n * (n + 1) // 2) for n in lens)
+        rows.append({"config": name, "sequences": len(lens), "total_tokens": tot, "max_seqlen": mx, "fwd_tflops": round(fl / ms / 1e9, 1),
+                     "bwd_tflops": round(2.5 * fl / mb / 1e9, 1), "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_ms": round(ms, 4),
+                     "bwd_ms": round(mb, 4), "fwd_kernel": sched["name"], "work_list": bool(sched["fwd_list"]),
+                     "bwd_dq_waves_x_rows": sb["bwd_dq_nw"], "bwd_dkdv_waves": sb["bwd_dkdv_nw"]})
+
+    for fn, args in ((fixed, ("2: B=8 H=16 S=2048 D=64 non-causal", 8, 2048, 16, 16, 64, False, (-1, -1))),
+                     (varlen, ("4-i: varlen 16 x 4096, H=16 D=128 causal", [4096] * 16, 16, 128)),
+                     (varlen, ("4-ii: varlen long-tail lengths, 64k tokens, H=16 D=128 causal", long_tail_lengths(), 16, 128)),
+                     (fixed, ("5: B=2 S=8192 H=32 / 8 KV heads D=128 causal, sliding window 1024", 2, 8192, 32, 8, 128, True, (1024, 0)))):
+        try:
+            fn(*args)
+        except Exception as e:   # noqa: BLE001
+            rows.append({"config": args[0], "error": f"{type(e).__name__}: {e}"})
+    return rows
+
+
+def _torch_attention(q, k, v, causal, dtype):
+    """Plain PyTorch attention of ONE (batch, head) -- q, k, v (S, D) -- in `dtype` (fp32 / fp64: the reference point; bf16: the same-dtype
+    baseline whose error calibrates the tolerance, tests/test_flash_attn.py:1121).  Returns out (S, D), lse (S,)."""
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    s = (q * (q.shape[-1] ** -0.5)) @ k.T
+    if causal:
+        S = q.shape[0]
+        s = s.masked_fill(torch.ones(S, S, dtype=torch.bool, device=q.device).triu(1), float("-inf"))
+    lse = torch.logsumexp(s.float() if dtype != torch.float64 else s, dim=-1)
+    return torch.softmax(s, dim=-1).to(v.dtype) @ v, lse
+
+
+def _ref_all_heads(q, k, v, do, causal, dtype):
+    B, S, H, D = q.shape
+    out = torch.empty(B, S, H, D, device=q.device, dtype=dtype)
+    lse = torch.empty(B, H, S, device=q.device, dtype=torch.float32)
+    dq, dk, dv = torch.empty_like(out), torch.empty_like(out), torch.empty_like(out)
+    for b in range(B):
+        for h in range(H):
+            qs, ks, vs = (t[b, :, h].detach().to(dtype).requires_grad_(True) for t in (q, k, v))
+            o, l = _torch_attention(qs, ks, vs, causal, dtype)
+            gq, gk, gv = torch.autograd.grad(o, (qs, ks, vs), do[b, :, h].to(dtype))
+            out[b, :, h], lse[b, h], dq[b, :, h], dk[b, :, h], dv[b, :, h] = o.detach(), l.detach().float(), gq, gk, gv
+    return out, lse, dq, dk, dv
+
+
+def parity_report(be, dev, q, k, v, causal):
+    """Extra key `parity` (outside every timed region): max / mean |error| of out, LSE, dQ, dK, dV of the timed workload against plain PyTorch in fp32
+    (all (batch, head) units, computed on the GPU), next to the error of the same computation done by PyTorch in bf16 -- the reference's own
+    acceptance yardstick -- for the DEFAULT numerics and for FA_STRICT=1 (softmax_scale applied in fp32 to every score; the default 64-rows-per-wave
+    forward rounds q*scale*log2e to bf16 once); plus one sampled (batch, head) unit in fp64, gradients included, to tie the fp32 reference itself down."""
+    def err(a, b):
+        d = (a.double() - b.double()).abs()
+        return {"max": float(d.max()), "mean": float(d.mean())}
+
+    def ours():
+        D = q.shape[-1]
+        out, lse, _, _ = be.fwd(q, k, v, None, None, 0.0, D ** -0.5, causal, -1, -1, 0.0, False, None)
+        name = be.last_schedule()["name"]
+        dq, dk, dv, _ = be.bwd(do, q, k, v, out, lse, None, None, None, None, 0.0, D ** -0.5, causal, -1, -1, 0.0, False, None, None)
+        return (out, lse, dq, dk, dv), name
+
+    try:
+        torch.manual_seed(1234)
+        do = torch.randn_like(q)
+        names = ("out", "lse", "dq", "dk", "dv")
+        ref = _ref_all_heads(q, k, v, do, causal, torch.float32)
+        pt = _ref_all_heads(q, k, v, do, causal, torch.bfloat16)
+        rep = {"reference": "PyTorch fp32 on the GPU, all (batch, head) units of the timed workload", "tensors": {}}
+        got, kname = ours()
+        rep["default_forward_kernel"] = kname
+        os.environ["FA_STRICT"] = "1"
+        be.reload_knobs()
+        try:
+            got_s, sname = ours()
+        finally:
+            os.environ.pop("FA_STRICT", None)
+            be.reload_knobs()
+        rep["strict_forward_kernel"] = sname
+        for i, nm in enumerate(names):
+            rep["tensors"][nm] = {"default": err(got[i], ref[i]), "strict": err(got_s[i], ref[i]), "pytorch_bf16": err(pt[i], ref[i])}
+        b, h = q.shape[0] - 1, q.shape[2] // 2 + 1
+        qs, ks, vs = (t[b, :, h].detach().double().requires_grad_(True) for t in (q, k, v))
+        o64, l64 = _torch_attention(qs, ks, vs, causal, torch.float64)
+        g64 = torch.autograd.grad(o64, (qs, ks, vs), do[b, :, h].double())
+        r64 = (o64.detach(), l64.detach(), g64[0], g64[1], g64[2])
+        sel = lambda t, i: t[b, h] if i == 1 else t[b, :, h]
+        rep["fp64_sample"] = {"unit": [b, h], "tensors": {nm: {"default": err(sel(got[i], i), r64[i]), "fp32_reference": err(sel(ref[i], i), r64[i])}
+                                                           for i, nm in enumerate(names)}}
+        return rep
     except Exception as e:   # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
 
@@ -242,6 +399,7 @@ def parse_args(argv=None):
     ap.add_argument("--preroll-ms", type=float, default=400.0, help="clock ramp before the counted warm-up (same launch, untimed)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the seqlen sweep (extra key `sweep`)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the error table of the timed workload (extra key `parity`)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--one-launch", action="store_true", help="(internal) a few forward launches of the workload, for the PMC passes")
     ap.add_argument("--stub-workload", action="store_true",
@@ -355,7 +513,11 @@ def main(argv=None):
             res["roofline"]["traffic_detail"] = detail
         if world == 1 and not a.no_sweep:
             res["sweep"] = sweep(be, dev, dev_sync)
+            res["sweep_d64"] = sweep(be, dev, dev_sync, 64)
+            res["configs"] = config_rows(be, dev, dev_sync)
             res["features"] = feature_rows(be, dev, dev_sync, B, H, S, D)
+        if world == 1 and not a.no_parity:
+            res["parity"] = parity_report(be, dev, q, k, v, causal)
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(D, S, causal)
         print(json.dumps(res), flush=True)

@@ -18,7 +18,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "fa_device.h"
+#include "fa_device.h"   // (-I flash-attention_amd/csrc: experiments/build_experiments.py)
 #include "fa_kernel_params.h"
 #include "fa_launch.h"
 #include "fa_fwd_w64_regs.h"

@@ -5,9 +5,9 @@
                          (fwd / varlen_fwd / bwd / varlen_bwd / fwd_kvcache) on top of the C ABI
   probe_gfx950         hardware-semantics probe (lane layouts the kernels rely on)
 
-Usage: python flash-attention_amd/build.py [--no-torch-ext] [--force] [--experiments]
-  --experiments   also build the kernels that were measured and did not win (64-keys-per-wave dK/dV kernel fa_bwd_dkdv64.hip, the dS-spill
-                  dQ kernel): FA_BWD_DKDV=64 / FA_BWD_MODE=2 select them; the default library holds only what the dispatch can pick
+Usage: python flash-attention_amd/build.py [--no-torch-ext] [--force]
+The library holds only what the dispatch can pick; kernels that were measured and did not win live under experiments/ with a build script of
+their own (experiments/build_experiments.py -> experiments/libfa_gfx950_experiments.so).
 Outputs land next to this file so they travel to the GPU box with the repo snapshot.
 """
 from __future__ import annotations
@@ -52,7 +52,7 @@ def _sources(names):
     return [os.path.join(CSRC, n) for n in names]
 
 
-def build_lib(force=False, experiments=False):
+def build_lib(force=False):
     hdrs = _sources(["fa_device.h", "fa_kernel_params.h", "fa_launch.h"]) + [os.path.join(ROOT, "include", "fa_gfx950.h")]
     # (source, object, extra flags).  fa_fwd.hip, fa_fwd_w64.hip and fa_bwd.hip are compiled twice each, side by side (bf16 / fp16 instantiations of the
     # forwards: FA_FWD_PART, FA_W64_PART; dK/dV half / dQ half of the backward: FA_BWD_PART): they are the slowest units of the build.  The 64-per-wave units place their row-sum adds by hand (see the note on asm
@@ -60,21 +60,6 @@ def build_lib(force=False, experiments=False):
     units = [("fa_fwd.hip", "fa_fwd_bf16.o", ["-DFA_FWD_PART=1"]), ("fa_fwd.hip", "fa_fwd_f16.o", ["-DFA_FWD_PART=2"]), ("fa_fwd_il.hip", "fa_fwd_il.o", []), ("fa_fwd_w64.hip", "fa_fwd_w64_bf16.o", ["-fno-slp-vectorize", "-DFA_W64_PART=1"]), ("fa_fwd_w64.hip", "fa_fwd_w64_f16.o", ["-fno-slp-vectorize", "-DFA_W64_PART=2"]),
              ("fa_bwd.hip", "fa_bwd_dkdv.o", ["-DFA_BWD_PART=1"]), ("fa_bwd.hip", "fa_bwd_dq.o", ["-DFA_BWD_PART=2"]),
              ("fa_bwd_w64.hip", "fa_bwd_w64.o", ["-fno-slp-vectorize"]), ("fa_api.cpp", "fa_api.o", [])]
-    stamp = os.path.join(CSRC, ".experiments")
-    was = os.path.exists(stamp)
-    if experiments:
-        units = [(u, o, e + ["-DFA_EXPERIMENTS=1"] if u in ("fa_bwd_w64.hip", "fa_api.cpp") else e) for u, o, e in units]
-        units.append(("fa_bwd_dkdv64.hip", "fa_bwd_dkdv64.o", ["-fno-slp-vectorize"]))
-    if was != experiments:   # the flag changes two translation units: rebuild them
-        for o in ("fa_bwd_w64.o", "fa_api.o"):
-            if os.path.exists(os.path.join(CSRC, o)):
-                os.remove(os.path.join(CSRC, o))
-        if os.path.exists(LIB):
-            os.remove(LIB)
-        if experiments:
-            open(stamp, "w").close()
-        elif was:
-            os.remove(stamp)
     hdrs += _sources(["fa_w64_asm.h", "fa_fwd_w64_regs.h"])
     objs, cmds = [], []
     for u, o, extra in units:
@@ -132,9 +117,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--no-torch-ext", action="store_true")
     ap.add_argument("--force", action="store_true")
-    ap.add_argument("--experiments", action="store_true", help="also build the measured-and-not-faster kernel variants (see the module docstring)")
     a = ap.parse_args(argv)
-    build_lib(a.force, a.experiments)
+    build_lib(a.force)
     build_probe(a.force)
     if not a.no_torch_ext and os.path.exists(os.path.join(CSRC, "torch_binding.cpp")):
         build_torch_ext(a.force)

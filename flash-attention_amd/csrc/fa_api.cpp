@@ -372,8 +372,8 @@ int bwd_dq_schedule(const FaBwdParams* a) {
 
 // dK/dV schedule (fa_launch.h Knobs::bwd_dkdv)
 #ifndef FA_EXPERIMENTS
-#define FA_EXPERIMENTS 0   // build.py --experiments: the 64-keys-per-wave dK/dV kernel (FA_BWD_DKDV=64) and the dS-spill backward (FA_BWD_MODE=2)
-#endif                     // -- both measured and not faster (profiles/r02_bwd_schedules.txt) -- are built and dispatchable
+#define FA_EXPERIMENTS 0   // experiments/build_experiments.py: the 64-keys-per-wave dK/dV kernel (FA_BWD_DKDV=64) and the dS-spill backward (FA_BWD_MODE=2),
+#endif                     // both measured and not faster (profiles/r02_bwd_schedules.txt); their sources live under experiments/, outside the product tree
 int bwd_dkdv_schedule(const FaBwdParams* a) {
   const int knob = fa::knobs().bwd_dkdv;
   if (FA_EXPERIMENTS && (knob == 8 || knob == 64)) return knob;

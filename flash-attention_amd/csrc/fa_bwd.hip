@@ -49,6 +49,9 @@ static __device__ __forceinline__ void wait_lgkm_le(int n) {
 // profiles/r02_bwd_schedules.txt): 4-wave workgroups of 128 keys at D <= 128 (FA_DKDV_SPLIT), the upper four waves one phase ahead of their SIMD
 // partners (FA_DKDV_ROT: 1494 | 2394 us against 1431 | 2278 in lock step), the dV / dK segment's first operands read before the vector phase
 // (FA_DKDV_CARRY: identical), static priority for the second-dispatched waves (FA_DKDV_PRIO: slower).
+#ifndef FA_EXPERIMENTS
+#define FA_EXPERIMENTS 0
+#endif
 #ifndef FA_DKDV_PRESCALE
 #define FA_DKDV_PRESCALE 1  // 0 = the plain dK/dV kernel subtracts LSE and delta on the vector ALU like the feature variants (A/B)
 #endif
@@ -479,6 +482,9 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
       }
     }
 
+    // (hook of experiments/fa_bwd_dq_ds.inc.hip, FA_BWD_MODE=2: ds_ws is NULL in the default library and the branch is never taken.  It is not compiled
+    // out: without it hipcc's register allocation of the softcap variant at D = 128 comes out two vector spills worse -- 12 bytes of scratch,
+    // tests/test_kernel_resources_cpu.py)
     if (p.ds_ws) {  // dS spill: this sub-tile's fragments, one 16-byte slot per lane (fa_device.h ds_slot), for the dQ contraction
       if (!key_valid) {  // keys past the end (their K rows are clamped copies over there): no contribution
 #pragma unroll

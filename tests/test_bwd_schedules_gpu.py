@@ -1,7 +1,7 @@
 """Backward schedules added in round 2 (reference: compute_dq_dk_dv_1colblock, csrc/flash_attn/src/flash_bwd_kernel.h:80-795):
   * fa_bwd_dq_w64_kernel  (FA_BWD_DQ_NW=64, the default from 2k keys at head dim 128): 64 query rows per wave;
-  * the dS-spill path     (FA_BWD_MODE=2): the dK/dV kernel writes dS, dQ = dS.K is one contraction (5 instead of 7).
-Both must reproduce the 32-rows-per-wave recomputing kernels: same arithmetic per element, so dq agrees to rounding of the
+(The dS-spill path and the 64-keys-per-wave dK/dV kernel are experiments: their tests live in experiments/test_bwd_schedules_gpu.py.)
+It must reproduce the 32-rows-per-wave recomputing kernels: same arithmetic per element, so dq agrees to rounding of the
 fp32 accumulation order, and dk / dv -- produced by the same kernel -- bit for bit.  An fp32 PyTorch reference bounds the
 error of each in absolute terms (tolerance: twice the error of the established kernel, floor 1e-2 bf16 / 2e-3 fp16)."""
 import numpy as np
@@ -56,13 +56,14 @@ SHAPES = [  # B, Sq, Sk, H, Hk, causal, wl, wr
 ]
 
 
+@pytest.mark.parametrize("d", [128, 64])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "B%d_Sq%d_Sk%d_H%d_%d_c%d_w%d_%d" % s)
-def test_dq_w64_kernel_matches_recomputing_kernel_and_fp32(be, knobs, dtype, shape):
+def test_dq_w64_kernel_matches_recomputing_kernel_and_fp32(be, knobs, dtype, shape, d):
     B, Sq, Sk, H, Hk, causal, wl, wr = shape
     torch.manual_seed(0)
-    q = torch.randn(B, Sq, H, 128, device="cuda", dtype=dtype)
-    k = torch.randn(B, Sk, Hk, 128, device="cuda", dtype=dtype)
+    q = torch.randn(B, Sq, H, d, device="cuda", dtype=dtype)
+    k = torch.randn(B, Sk, Hk, d, device="cuda", dtype=dtype)
     v = torch.randn_like(k)
     do = torch.randn_like(q)
     knobs.set("FA_BWD_DQ_NW", 4)
@@ -82,7 +83,7 @@ def test_dq_w64_kernel_matches_recomputing_kernel_and_fp32(be, knobs, dtype, sha
 def test_dq_w64_default_dispatch_and_fallbacks(be, knobs):
     """Heuristic (fa_api.cpp bwd_dq_schedule): 64 rows per wave from 2k keys at head dim 128 for plain attention; everything
     else on the 32-rows-per-wave kernels.  A forced 64 falls back to the 8-wave kernel (same 256-row blocks) where the
-    schedule does not apply (dropout, head dim 64) -- and still computes the right thing."""
+    schedule does not apply (dropout) -- and still computes the right thing."""
     knobs.unset("FA_BWD_DQ_NW")
     torch.manual_seed(1)
     q = torch.randn(1, 2048, 2, 128, device="cuda", dtype=torch.bfloat16)
@@ -96,9 +97,9 @@ def test_dq_w64_default_dispatch_and_fallbacks(be, knobs):
     knobs.set("FA_BWD_DQ_NW", 4)
     d_ref = run_bwd(be, q, k, v, do, True, p_drop=0.1)
     assert float((d_forced[0].float() - d_ref[0].float()).abs().max()) < 1e-2
-    q64 = torch.randn(1, 2048, 2, 64, device="cuda", dtype=torch.bfloat16)
+    q96 = torch.randn(1, 2048, 2, 96, device="cuda", dtype=torch.bfloat16)   # (head dim 64 has the kernel since round 4; trimmed head dims do not)
     knobs.set("FA_BWD_DQ_NW", 64)
-    assert run_bwd(be, q64, torch.randn_like(q64), torch.randn_like(q64), torch.randn_like(q64), False)[3]["bwd_dq_nw"] == 8
+    assert run_bwd(be, q96, torch.randn_like(q96), torch.randn_like(q96), torch.randn_like(q96), False)[3]["bwd_dq_nw"] == 4
 
 
 @pytest.mark.parametrize("causal", [False, True])
@@ -136,101 +137,25 @@ def test_dq_w64_varlen_equals_per_sequence(be, knobs, causal):
 FEATS = [dict(), dict(softcap=20.0), dict(alibi=True), dict(p_drop=0.2)]
 
 
-@pytest.mark.parametrize("d", [64, 128])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", SHAPES[::2] + [SHAPES[5], SHAPES[9]], ids=lambda s: "B%d_Sq%d_Sk%d_H%d_%d_c%d_w%d_%d" % s)
-def test_ds_spill_backward_equals_recomputing_backward(be, knobs, d, dtype, shape):
-    """FA_BWD_MODE=2 (5 contractions): every feature is folded into dS by the dK/dV kernel, so softcap / ALiBi / dropout ride
-    along.  dk, dv bit-exact (same kernel, the spill only adds stores); dq within accumulation-order rounding."""
-    B, Sq, Sk, H, Hk, causal, wl, wr = shape
-    torch.manual_seed(2)
-    q = torch.randn(B, Sq, H, d, device="cuda", dtype=dtype)
-    k = torch.randn(B, Sk, Hk, d, device="cuda", dtype=dtype)
-    v, do = torch.randn_like(k), torch.randn_like(q)
-    knobs.set("FA_BWD_DQ_NW", 4)
-    for ft in FEATS:
-        ft = dict(ft)
-        if ft.get("alibi"):
-            ft["alibi"] = torch.rand(B, H, device="cuda") * 0.3
-        knobs.set("FA_BWD_MODE", 1)
-        a = run_bwd(be, q, k, v, do, causal, wl, wr, **ft)
-        knobs.set("FA_BWD_MODE", 2)
-        s = run_bwd(be, q, k, v, do, causal, wl, wr, **ft)
-        if s[3]["bwd_spill"] == 0:
-            pytest.skip("dS-spill backward not in this build (flash-attention_amd/build.py --experiments)")
-        assert a[3]["bwd_spill"] == 0 and s[3]["bwd_spill"] == 1
-        assert torch.equal(a[1], s[1]) and torch.equal(a[2], s[2]), list(ft)
-        assert torch.isfinite(s[0].float()).all()
-        tol = (1e-2 if dtype == torch.bfloat16 else 2e-3) * max(1.0, float(a[0].float().abs().max()))
-        assert float((a[0].float() - s[0].float()).abs().max()) <= tol, list(ft)
-
-
-def test_ds_spill_needs_its_workspace_and_respects_the_cap(be, knobs):
-    """fa_bwd_workspace_bytes reports the dS scratch only under FA_BWD_MODE=2 and only below FA_BWD_DS_CAP_MB; without it the
-    backward recomputes."""
-    import ctypes as C
-    from flash_attn_amd import _cabi
-    torch.manual_seed(3)
-    q = torch.randn(1, 512, 2, 128, device="cuda", dtype=torch.bfloat16)
-    k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
-    knobs.set("FA_BWD_MODE", 2)
-    knobs.set("FA_BWD_DS_CAP_MB", 1)            # 1*2*16*16*2 KB = 1 MB fits, twice the heads does not
-    if run_bwd(be, q, k, v, do, False)[3]["bwd_spill"] == 0:
-        pytest.skip("dS-spill backward not in this build (flash-attention_amd/build.py --experiments)")
-    assert run_bwd(be, q, k, v, do, False)[3]["bwd_spill"] == 1
-    q4 = torch.randn(1, 512, 4, 128, device="cuda", dtype=torch.bfloat16)
-    assert run_bwd(be, q4, torch.randn_like(q4), torch.randn_like(q4), torch.randn_like(q4), False)[3]["bwd_spill"] == 0
-    knobs.unset("FA_BWD_MODE")
-    assert run_bwd(be, q, k, v, do, False)[3]["bwd_spill"] == 0
-    assert _cabi is not None and C is not None
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "B%d_Sq%d_Sk%d_H%d_%d_c%d_w%d_%d" % s)
-def test_dkdv_w64_kernel_matches_eight_wave_kernel_and_fp32(be, knobs, dtype, shape):
-    """fa_bwd_dkdv_w64_kernel (FA_BWD_DKDV=64, opt-in: four waves x 64 keys, software-pipelined, fa_bwd_dkdv64.hip) against the
-    default eight-wave dK/dV kernel: dq comes from the same dQ kernel (bit for bit); dk / dv have the same arithmetic per element
-    and the same accumulation order over the query tiles, so they agree bit for bit as well."""
-    B, Sq, Sk, H, Hk, causal, wl, wr = shape
-    torch.manual_seed(0)
-    q = torch.randn(B, Sq, H, 128, device="cuda", dtype=dtype)
-    k = torch.randn(B, Sk, Hk, 128, device="cuda", dtype=dtype)
-    v = torch.randn_like(k)
-    do = torch.randn_like(q)
-    knobs.set("FA_BWD_DKDV", 8)
-    a = run_bwd(be, q, k, v, do, causal, wl, wr)
-    knobs.set("FA_BWD_DKDV", 64)
-    w = run_bwd(be, q, k, v, do, causal, wl, wr)
-    if w[3]["bwd_dkdv_nw"] != 64:
-        pytest.skip("64-keys-per-wave dK/dV kernel not in this build (flash-attention_amd/build.py --experiments)")
-    assert a[3]["bwd_dkdv_nw"] == 8 and w[3]["bwd_dkdv_nw"] == 64, (a[3], w[3])
-    assert torch.equal(a[0], w[0])
-    r = ref_grads(q, k, v, do, causal, wl, wr)
-    floor = 1e-2 if dtype == torch.bfloat16 else 2e-3
-    for i in (1, 2):
-        e8 = float((a[i].float() - r[i]).abs().max())
-        e64 = float((w[i].float() - r[i]).abs().max())
-        assert torch.isfinite(w[i].float()).all()
-        assert e64 <= max(2 * e8, floor), (i, e64, e8)
-
-
 @pytest.mark.parametrize("shape", [SHAPES[1], SHAPES[5], SHAPES[8]], ids=lambda s: "B%d_Sq%d_Sk%d_H%d_%d_c%d_w%d_%d" % s)
-def test_strict_knob_keeps_fp32_score_scaling_in_the_backward(be, knobs, shape):
-    """The plain dK/dV kernel multiplies its K fragments by softmax_scale*log2(e) once (rounded to the input dtype) and lets the
-    matrix pipe subtract LSE and delta (C operands of the score / dP chains).  FA_STRICT=1 routes to the variant that scales every
-    score in fp32, as the reference does (flash_bwd_kernel.h:536).  Both must sit inside the usual error budget of the fp32
-    reference; the strict one is the yardstick."""
+def test_prescaled_k_variant_stays_inside_the_budget_of_the_default(be, knobs, shape):
+    """Since round 4 the plain dK/dV kernel scales every score in fp32, as the reference does (flash_bwd_kernel.h:536): FEAT_EXACT.  FA_DKDV_PRESCALE=1
+    opts into the variant that multiplies its K fragments by softmax_scale*log2(e) once (rounded to the input dtype) and lets the matrix pipe subtract
+    LSE as well (~3 % faster).  Both must sit inside the usual error budget of the fp32 reference; the default is the yardstick, and FA_STRICT=1 must
+    not change the backward any more (bit for bit: same kernel)."""
     B, Sq, Sk, H, Hk, causal, wl, wr = shape
     torch.manual_seed(0)
     q = torch.randn(B, Sq, H, 128, device="cuda", dtype=torch.bfloat16)
     k = torch.randn(B, Sk, Hk, 128, device="cuda", dtype=torch.bfloat16)
     v = torch.randn_like(k)
     do = torch.randn_like(q)
+    default = run_bwd(be, q, k, v, do, causal, wl, wr)
+    knobs.set("FA_DKDV_PRESCALE", 1)
     fast = run_bwd(be, q, k, v, do, causal, wl, wr)
-    knobs.set("FA_STRICT", 1)
-    strict = run_bwd(be, q, k, v, do, causal, wl, wr)
+    knobs.unset("FA_DKDV_PRESCALE")
     r = ref_grads(q, k, v, do, causal, wl, wr)
     for i in range(3):
-        e_s = float((strict[i].float() - r[i]).abs().max())
+        e_d = float((default[i].float() - r[i]).abs().max())
         e_f = float((fast[i].float() - r[i]).abs().max())
-        assert e_f <= max(2 * e_s, 1e-2), (i, e_f, e_s)
+        assert e_f <= max(2 * e_d, 1e-2), (i, e_f, e_d)
+    assert not torch.equal(fast[1], default[1]) or Sk < 64   # (the knob does select another kernel)

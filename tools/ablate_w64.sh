@@ -12,7 +12,7 @@ LIST=""
 for m in $MASKS; do LIST="$LIST;abl_$m:-DFA_W64_ABL=$m"; done
 LIST="$LIST;$VARIANTS"
 OTHERS="$PKG/csrc/fa_fwd_bf16.o $PKG/csrc/fa_fwd_f16.o $PKG/csrc/fa_fwd_il.o $PKG/csrc/fa_bwd_dkdv.o $PKG/csrc/fa_bwd_dq.o $PKG/csrc/fa_bwd_w64.o $PKG/csrc/fa_api.o"
-[ -f $PKG/csrc/fa_bwd_dkdv64.o ] && OTHERS="$OTHERS $PKG/csrc/fa_bwd_dkdv64.o"
+
 IFS=';'
 if [ "$1" != "run" ]; then
   mkdir -p gpurun_abl
