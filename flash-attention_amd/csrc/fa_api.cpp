@@ -367,6 +367,13 @@ int bwd_dq_schedule(const FaBwdParams* a) {
   const int knob = fa::knobs().bwd_dq_nw;
   if (knob == 4 || knob == 8 || knob == 64) return knob;
   const bool plain = a->softcap <= 0.f && !a->alibi_slopes && a->p_dropout <= 0.f;
+  if (a->d == 64) {
+    // round 4 (profiles/r04_bwd_schedules.txt): at head dim 64 the 64-rows-per-wave kernel wins from ~2k visible keys per query row ON AVERAGE -- non-causal
+    // S >= 2048 (+5.5 .. +7.5 % on the whole backward), causal S >= 8192 (+5.6 .. +7.4 %); it ties at causal S = 4096 and loses below
+    const bool right_bounded = a->is_causal || a->window_right >= 0;
+    const long avg_keys = right_bounded ? a->seqlen_k / 2 : a->seqlen_k;
+    return (plain && a->window_left < 0 && a->seqlen_q >= 512 && avg_keys >= 2048) ? 64 : 4;
+  }
   return (a->d == 128 && plain && a->seqlen_k >= 2048 && a->seqlen_q >= 512) ? 64 : 4;
 }
 

@@ -437,8 +437,19 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       load_q(qbc, ICw<0>{}); load_q(qbc, ICw<1>{}); load_q(qbc, ICw<2>{}); load_q(qbc, ICw<3>{});
       if constexpr (KS == 8) { load_q(qbc, ICw<4>{}); load_q(qbc, ICw<5>{}); load_q(qbc, ICw<6>{}); load_q(qbc, ICw<7>{}); }
     };
+#if FA_W64_ABL & 32768   // experiment: the conversion twice (idempotent), lane 58 = end of the first pass: cold vs warm instruction fetch of per-block code
+    int abl_nrep = 2;
+    asm volatile("" : "+s"(abl_nrep));
+#pragma unroll 1
+    for (int abl_rep = 0; abl_rep < abl_nrep; ++abl_rep) {
+      if (abl_rep == 1) FA_W64_STAMP(58);
+      load_q_all(ICw<0>{});
+      load_q_all(ICw<1>{});
+    }
+#else
     load_q_all(ICw<0>{});
     load_q_all(ICw<1>{});
+#endif
   }
   FA_W64_STAMP(1);
   lds_dma_wait_all();   // K_0 (requested before the conversion)
@@ -494,10 +505,15 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   float thr_l[QB];          // per-lane decision threshold: -inf until the row has seen a key (any finite score moves m), then rescale_thr
   unsigned long long lag_mask = 0ull;   // wave-uniform, all ones or zero: some o_lag != 1 is waiting to be applied to O
   f32x16 negm[QB];     // the C operand of every score chain's first MFMA: -m broadcast (0 while m = -inf), plus the ALiBi bias of the step's keys
-  float abias[QB] = {0.f, 0.f};   // ALiBi: the lane's part of the bias, slope2 * (4*hi - row - shift); element r of a step: + slope2 * (step_key + acc_row(r, 0))
+  // ALiBi: element r of a step has the bias slope2 * (step_key + 4*hi + acc_row(r, 0) - row - shift).  The key distance is formed in INTEGERS first
+  // (arel = the lane's part, 4*hi - row - shift) and converted once: round 3 added two fp32 terms, slope2 * (4*hi - row - shift) + slope2 * key, which
+  // cancel -- exact enough below 16k keys, ~1e-2 log2 units at 128k keys even for the keys next to the diagonal, the ones that matter
+  // (tests/test_fwd_gpu.py: the 128k-key ALiBi case).  The in-place adds of the steady state only ever add +-slope2 * 32 / 96 to values whose size is
+  // the bias itself: their rounding is relative to a distance-sized term, i.e. small exactly where the probabilities are not.
+  int arel[QB] = {0, 0};
   if constexpr (ALIBI) {
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) abias[qb] = slope2 * (float)(4 * hi - (w_row0 + 32 * qb + qi) - shift);
+    for (int qb = 0; qb < QB; ++qb) arel[qb] = 4 * hi - (w_row0 + 32 * qb + qi) - shift;
   }
   const float ainc = slope2 * 32.f;
   f32x16 sA[QB], sB[QB];
@@ -506,7 +522,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   for (int qb = 0; qb < QB; ++qb) {
     m_run[qb] = -INFINITY; l_run[qb][0] = 0.f; l_run[qb][1] = 0.f; o_lag[qb] = 1.f; thr_l[qb] = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { negm[qb][r] = ALIBI ? abias[qb] + slope2 * (float)(step_key(0) + acc_row(r, 0)) : 0.f; sA[qb][r] = -INFINITY; sB[qb][r] = -INFINITY; }   // S_{-1} = -inf: P_{-1} = 0
+    for (int r = 0; r < 16; ++r) { negm[qb][r] = ALIBI ? slope2 * (float)(arel[qb] + step_key(0) + acc_row(r, 0)) : 0.f; sA[qb][r] = -INFINITY; sB[qb][r] = -INFINITY; }   // S_{-1} = -inf: P_{-1} = 0
 #pragma unroll
     for (int t = 0; t < 2; ++t) { pfA[qb][t] = u32x4{0u, 0u, 0u, 0u}; pfB[qb][t] = u32x4{0u, 0u, 0u, 0u}; }
   }
@@ -583,7 +599,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       const int rel_hi = min(lim_hi[mq] - k0m - 4 * hi, 31), rel_lo = max(lim_lo[mq] - k0m - 4 * hi, 0);
       const unsigned ones = (rel_hi - rel_lo >= 31) ? 0xffffffffu : ((2u << ((rel_hi - rel_lo) & 31)) - 1u);
       unsigned bits = (rel_hi >= rel_lo) ? (ones << (rel_lo & 31)) : 0u;   // (rel_lo > 31 only with rel_hi < rel_lo)
-      if constexpr (ALIBI) nb += abias[mq] + slope2 * (float)k0m;   // the step's bias of this lane's element 0
+      if constexpr (ALIBI) nb += slope2 * (float)(arel[mq] + k0m);   // the step's bias of this lane's element 0
       asm volatile("" : "+v"(nb), "+v"(bits));
 #pragma unroll
       for (int r = 0; r < 16; r += 4) {
@@ -611,7 +627,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     static_for<QB>([&](auto mqc) __attribute__((always_inline)) {
       constexpr int mq = decltype(mqc)::value;
       float nb = (m_run[mq] == -INFINITY) ? 0.f : -m_run[mq];
-      if constexpr (ALIBI) nb += abias[mq] + slope2 * (float)step_key(i_next);
+      if constexpr (ALIBI) nb += slope2 * (float)(arel[mq] + step_key(i_next));
       asm volatile("" : "+v"(nb));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -999,6 +1015,13 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   }
   // O tile through LDS (the K/V buffers are free after the last tile barrier; the Q region may already hold the next block's
   // rows and is not touched): whole-row stores
+#if FA_W64_ABL & 32768   // experiment: the epilogue twice (idempotent), lane 57 = end of the first pass
+  int abl_erep = 2;
+  asm volatile("" : "+s"(abl_erep));
+#pragma unroll 1
+  for (int abl_e = 0; abl_e < abl_erep; ++abl_e) {
+  if (abl_e == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FA_W64_STAMP(57); }
+#endif
   static_for<QB>([&](auto qbc) __attribute__((always_inline)) {
     constexpr int qb = decltype(qbc)::value;
     f32x16 o_v[DB];
@@ -1062,6 +1085,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #endif
     }
   });
+#if FA_W64_ABL & 32768
+  }
+#endif
   }  // wave_valid
   }  // persistent block loop
 }

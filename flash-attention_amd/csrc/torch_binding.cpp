@@ -229,7 +229,7 @@ std::vector<Tensor> mha_varlen_fwd(Tensor& q, const Tensor& k, const Tensor& v, 
       out_->copy_(o); o = *out_;
     }
     // lse (Hk, B*ng) -> (H, B): head hk*ng + g of sequence b sits at [hk][b*ng + g]
-    return {o, r[1].reshape({Hk, B, ng}).permute({0, 2, 1}).reshape({H, B}), r[2], r[3]};
+    return {o, r[1].reshape({Hk, B, ng}).permute({0, 2, 1}).reshape({H, B}).contiguous(), r[2], r[3]};   // (.contiguous(): with ONE KV head the reshape is a strided view)
   }
   check_head_dim(D);
   const Tensor &qp = q, &kp = k, &vp = v;

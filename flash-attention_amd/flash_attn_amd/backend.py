@@ -233,7 +233,7 @@ def varlen_fwd(q, k, v, out_, cu_seqlens_q, cu_seqlens_k, seqused_k, leftpad_k_,
             out_.copy_(out)
             out = out_
         # lse (Hk, B*ng) -> (H, B): head hk*ng + g of sequence b sits at [hk][b*ng + g]
-        return [out, l2.reshape(Hk, B, ng).permute(0, 2, 1).reshape(H, B), p2, r2]
+        return [out, l2.reshape(Hk, B, ng).permute(0, 2, 1).reshape(H, B).contiguous(), p2, r2]
     if seqused_k is not None and (seqused_k.dtype != torch.int32 or seqused_k.numel() != B or not seqused_k.is_contiguous()):
         raise RuntimeError("seqused_k must be a contiguous int32 tensor of shape (batch_size)")
     if seqused_q is not None and (seqused_q.dtype != torch.int32 or seqused_q.numel() != B or not seqused_q.is_contiguous()):

@@ -104,13 +104,19 @@ def test_backward_dq_schedule(lib, monkeypatch):
         a.total_q = a.total_k = B * S
         a.dtype = 1
         a.softmax_scale = D ** -0.5
+        a.window_left = a.window_right = -1
         for k, v in kw.items():
             setattr(a, k, v)
         return a
     dq = lambda a: lib.fa_bwd_dq_schedule_query(C.byref(a))
     assert dq(bp(4, 4096, 32, 128)) == 64
     assert dq(bp(4, 1024, 32, 128)) == 4
-    assert dq(bp(4, 4096, 32, 64)) == 4
+    assert dq(bp(4, 4096, 32, 64)) == 64                                 # head dim 64 (round 4): from ~2k visible keys per row on average
+    assert dq(bp(8, 2048, 16, 64)) == 64                                 # config 2's shape
+    assert dq(bp(4, 4096, 32, 64, is_causal=1)) == 64                    # (a tie there)
+    assert dq(bp(8, 2048, 32, 64, is_causal=1)) == 4
+    assert dq(bp(2, 8192, 32, 64, is_causal=1)) == 64
+    assert dq(bp(16, 1024, 32, 64)) == 4
     assert dq(bp(4, 4096, 32, 128, softcap=20.0)) == 4
     monkeypatch.setenv("FA_BWD_DQ_NW", "64"); lib.fa_knobs_reload()
     assert dq(bp(4, 4096, 32, 96)) == 4                                 # trimmed head dims only have the 4-wave kernel, whatever the knob says

@@ -272,6 +272,33 @@ def test_w64_causal_alibi(be, knobs, B, Sq, Sk, H, Hk, D, per_batch, dtype, wind
     assert e64 < max(2 * e8, 1.2e-2 if dtype == torch.bfloat16 else 4e-3) and el < 8e-3 and torch.equal(torch.isinf(lse.cpu()), ~fin), (e64, e8, el)
 
 
+def test_w64_causal_alibi_128k_keys(be, knobs):
+    """The ALiBi bias at very long sequences: the key distance is formed in integers before it meets the slope (fa_fwd_w64.hip: arel).  Round 3 added two
+    fp32 terms of size slope * 128k that cancel -- ~1e-2 log2 units of error on the keys next to the diagonal at this length.  fp16, so that the kernel's
+    own rounding of q * scale * log2e (2^-12 relative) leaves room to see it; sampled query rows against fp64 on the GPU."""
+    torch.manual_seed(5)
+    S, H, D = 131072, 2, 128
+    q = torch.randn(1, S, H, D, device="cuda", dtype=torch.float16)
+    k, v = torch.randn_like(q), torch.randn_like(q)
+    slopes = torch.tensor([0.5, 2.0 ** -6], device="cuda", dtype=torch.float32)
+    knobs.set("FA_FWD_NW", "64")
+    out, lse = be.fwd(q, k, v, None, slopes, 0.0, D ** -0.5, True, -1, -1, 0.0, False, None)[:2]
+    s = be.last_schedule()
+    knobs.unset("FA_FWD_NW")
+    assert s["fwd_kernel"] == 3 and "alibi" in s["name"], s
+    rows = torch.cat([torch.arange(0, 64), torch.arange(65500, 65600), torch.arange(S - 200, S)]).cuda()
+    j = torch.arange(S, device="cuda")
+    for h in range(H):
+        sc = (q[0, rows, h].double() * D ** -0.5) @ k[0, :, h].double().T            # (rows, S)
+        sc = sc - slopes[h].double() * (rows[:, None] - j[None, :]).abs().double()
+        sc = sc.masked_fill(j[None, :] > rows[:, None], float("-inf"))
+        lse_ref = torch.logsumexp(sc, -1)
+        o_ref = torch.softmax(sc, -1) @ v[0, :, h].double()
+        e_l = float((lse[0, h, rows].double() - lse_ref).abs().max())
+        e_o = float((out[0, rows, h].double() - o_ref).abs().max())
+        assert e_l < 2e-3 and e_o < 4e-3, (h, e_l, e_o)
+
+
 def test_w64_causal_alibi_varlen(be, knobs):
     """The same through the packed variable-length entry (work list, uneven sequences: a block-aligned one, one with a single row in its last block,
     one shorter than a block), judged like the fixed-length cases: against the fp64 oracle, relative to the lock-step kernel's error."""

@@ -115,3 +115,23 @@ def test_generator_slot_must_be_none():
         ext.varlen_fwd(qf, kf, kf, None, cu, cu, None, None, None, None, 1, 1, 0.0, 0.35, False, True, -1, -1, 0.0, False, bad)
     with pytest.raises(RuntimeError, match=match):
         ext.varlen_bwd(qf, qf, kf, kf, qf, lse.view(2, 1), None, None, None, cu, cu, None, 1, 1, 0.0, 0.35, False, True, -1, -1, 0.0, False, bad, None)
+
+
+@pytest.mark.parametrize("hk", [1, 2])
+def test_varlen_one_query_per_sequence_grouped_heads_backward(fa, hk):
+    """tests/test_flash_attn*.py::test_flash_attn_varlen_output[..-1-147-..-mqa-..]: one query row per sequence with grouped heads takes the head-packing
+    swap of mha_varlen_fwd (flash_api.cpp:620-629); with ONE KV head the un-swapped LSE came back as a strided view and varlen_bwd refused it."""
+    torch.manual_seed(3)
+    B, H, D, Sk = 4, 6, 64, 147
+    q = torch.randn(B, H, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    k = torch.randn(B * Sk, hk, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    v = torch.randn(B * Sk, hk, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    cu_q = torch.arange(0, B + 1, dtype=torch.int32, device="cuda")
+    cu_k = torch.arange(0, (B + 1) * Sk, Sk, dtype=torch.int32, device="cuda")
+    out = fa.flash_attn_varlen_func(q, k, v, cu_q, cu_k, 1, Sk)
+    g = torch.randn_like(out)
+    dq, dk, dv = torch.autograd.grad(out, (q, k, v), g)
+    qr, kr, vr = q.detach().view(B, 1, H, D), k.detach().view(B, Sk, hk, D), v.detach().view(B, Sk, hk, D)
+    ref = _grads(lambda a, b, c: attention_torch(a, b, c)[0], qr, kr, vr, g.view(B, 1, H, D))
+    assert max_abs(out.view(B, 1, H, D), ref[0]) < 2e-2
+    assert max_abs(dq.view(B, 1, H, D), ref[1]) < 3e-2 and max_abs(dk.view(B, Sk, hk, D), ref[2]) < 3e-2 and max_abs(dv.view(B, Sk, hk, D), ref[3]) < 3e-2
