@@ -83,9 +83,6 @@
 #ifndef FA_W64_STAG_GS
 #define FA_W64_STAG_GS 1
 #endif
-#ifndef FA_W64_FASTDIAG
-#define FA_W64_FASTDIAG 1   // causal diagonal tile of a wave / its drain iteration: mask rewrites from a per-lane constant triangle (see mask_tri below); 0 = the general set_mask path (A/B)
-#endif
 #ifndef FA_W64_KV_POLN
 #define FA_W64_KV_POLN 0   // cache-policy bits of the K/V tile DMAs, bit mask: 1 sc0, 2 sc1, 4 nt (A/B in profiles/r04_fwd_w64_dma.txt)
 #endif
@@ -402,9 +399,14 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   __syncthreads();
   FA_W64_STAMP(0);
   if (q_in_lds != vb) dma_q(q_srd_of(blk));
-  if (n_tiles > 0) { dma_tile(ICw<0>{}, 0, tile_of(0)); dma_tile(ICw<1>{}, 1, -1); }
+  // (round 4: only K_0 here.  Eight tile DMAs issued back to back cost ~160 clocks each -- the vector-memory queue fills --, 1300 clocks between the barrier
+  // and the first LDS read of Q; the zero fill of V buffer 1 is issued between the two halves of the Q conversion instead, profiles/r04_fwd_w64_per_block_code.txt)
+  if (n_tiles > 0) dma_tile(ICw<0>{}, 0, tile_of(0));
+#if FA_W64_ABL & 32768
+  FA_W64_STAMP(56);
+#endif
   if (q_in_lds != vb) {   // Q was not prefetched (first block of this workgroup): its pieces were requested first
-    if (n_tiles > 0) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    if (n_tiles > 0) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }   // (all but K_0's pieces)
     else lds_dma_wait_all();
   }
   // this wave's B-operand fragments of Q, pre-multiplied by softmax_scale*log2(e) and rounded once to the input dtype, into
@@ -438,16 +440,20 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       if constexpr (KS == 8) { load_q(qbc, ICw<4>{}); load_q(qbc, ICw<5>{}); load_q(qbc, ICw<6>{}); load_q(qbc, ICw<7>{}); }
     };
 #if FA_W64_ABL & 32768   // experiment: the conversion twice (idempotent), lane 58 = end of the first pass: cold vs warm instruction fetch of per-block code
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    FA_W64_STAMP(55);   // Q fragments read from LDS
     int abl_nrep = 2;
     asm volatile("" : "+s"(abl_nrep));
 #pragma unroll 1
     for (int abl_rep = 0; abl_rep < abl_nrep; ++abl_rep) {
       if (abl_rep == 1) FA_W64_STAMP(58);
       load_q_all(ICw<0>{});
+      if (abl_rep == 0 && n_tiles > 0) dma_tile(ICw<1>{}, 1, -1);
       load_q_all(ICw<1>{});
     }
 #else
     load_q_all(ICw<0>{});
+    if (n_tiles > 0) dma_tile(ICw<1>{}, 1, -1);   // V buffer 1 <- zeros (the pipeline's first two steps multiply it by P = 0)
     load_q_all(ICw<1>{});
 #endif
   }
@@ -585,6 +591,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // window edges, the partial last tile, the drain's empty chains).  (Rounds 2-3 tried masked step VARIANTS, a pre-loaded chain start in separate
   // loops, and masking the finished scores in the step's cold exit + a second row-max tree: 30k / 30k / 26k clocks for the last five iterations
   // of a block under a causal mask against 17.6k with nothing masked, profiles/r03_fwd_w64_stamps.txt.)
+  // (Round 4 tried a fast path for the common case -- a wave's tile-aligned causal diagonal and the drain behind it, mask rewrites from a per-lane constant
+  // triangle, 112 instead of ~420 instructions per masked iteration: those iterations went from ~4180 to ~4120 clocks, the first iteration and the steady state
+  // lost as much to the longer code.  A masked iteration's cost follows the code layout, not the instruction count: profiles/r04_fwd_w64_stamps.txt; removed.)
   // Straight-line on purpose, one path for every case (all visible / none / element by element fall out of the per-lane bounds): with a branch
   // per case the rewritten broadcasts of the cases meet at joins and hipcc copies 32 registers per call.
   auto set_mask = [&](int i_step) __attribute__((always_inline)) {
@@ -638,43 +647,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
         negm[mq][r] = nv;
       }
     });
-  };
-  // Round 4: the common masked iterations under a causal mask -- a wave's diagonal tile and the drain iteration behind it -- without set_mask's
-  // per-step bitmap arithmetic, without rewriting broadcasts that stay as they are, and without clear_mask (the block ends behind the drain).  With the
-  // diagonal tile-aligned (shift % 64 == 0) the diagonal tile of EVERY wave looks the same: step A (keys 0-31 of the tile) sees rows 0-31 through the
-  // lower triangle and rows 32-63 in full, step B (keys 32-63) sees nothing from rows 0-31 and the triangle from rows 32-63.  The triangle is a per-lane
-  // constant of the kernel (tri_bits: element r of lane (hi, qi) scores key offset 4*hi + acc_row(r, 0), visible iff <= qi).  Per masked iteration
-  // this is 112 instructions (32 + 48 + 32) against ~420 for two set_mask + clear_mask pairs, on the critical path of every one of a causal block's
-  // last five iterations (the four waves reach their diagonals one iteration apart and run in lock step): profiles/r04_fwd_w64_stamps.txt.
-  // Every rewrite is state-independent (from m_run, not from the old broadcast): the cold rescale path may have restored a broadcast in between.
-  const unsigned tri_bits = (qi - 4 * hi >= 0) ? ((2u << ((qi - 4 * hi) & 31)) - 1u) : 0u;
-  auto mask_tri = [&](auto mqc) __attribute__((always_inline)) {
-    constexpr int mq = decltype(mqc)::value;
-    float nb = (m_run[mq] == -INFINITY) ? 0.f : -m_run[mq];
-    float ninf = -INFINITY;
-    unsigned bits = tri_bits;
-    asm volatile("" : "+v"(nb), "+v"(bits), "+v"(ninf));
-#pragma unroll
-    for (int r = 0; r < 16; r += 4) {
-      float n0 = negm[mq][r], n1 = negm[mq][r + 1], n2 = negm[mq][r + 2], n3 = negm[mq][r + 3];
-      unsigned t0, t1;
-      asm volatile("v_bfe_i32 %4, %6, %c9, 1\n\tv_bfe_i32 %5, %6, %c10, 1\n\tv_bfi_b32 %0, %4, %7, %8\n\tv_bfi_b32 %1, %5, %7, %8\n\t"
-                   "v_bfe_i32 %4, %6, %c11, 1\n\tv_bfe_i32 %5, %6, %c12, 1\n\tv_bfi_b32 %2, %4, %7, %8\n\tv_bfi_b32 %3, %5, %7, %8"
-                   : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "=&v"(t0), "=&v"(t1)
-                   : "v"(bits), "v"(nb), "v"(ninf), "i"(acc_row(r, 0)), "i"(acc_row(r + 1, 0)), "i"(acc_row(r + 2, 0)), "i"(acc_row(r + 3, 0)));
-      negm[mq][r] = n0; negm[mq][r + 1] = n1; negm[mq][r + 2] = n2; negm[mq][r + 3] = n3;
-    }
-  };
-  auto mask_all = [&](auto mqc) __attribute__((always_inline)) {   // no key of the step is visible to this query block
-    constexpr int mq = decltype(mqc)::value;
-    float ninf = -INFINITY;
-    asm volatile("" : "+v"(ninf));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float nv = negm[mq][r];
-      asm volatile("v_mov_b32 %0, %1" : "+v"(nv) : "v"(ninf));
-      negm[mq][r] = nv;
-    }
   };
   // ---- steady-state step: NG MFMA gaps, everything else hand-assigned to a gap ---------------------------------------
   //   gaps 0 .. 2KS-1      : S_{i+1}[qb] chain, k-step g/2 (the K fragment read once, used by both query blocks)
@@ -907,11 +879,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   };
   // Active iterations outside [m_lo, m_hi] hold a step that straddles a mask boundary
   const int m_lo = __builtin_amdgcn_readfirstlane((FA_W64_ABL & 4096) ? 0 : p_lo), m_hi = __builtin_amdgcn_readfirstlane((FA_W64_ABL & 4096) ? 0x3fffffff : p_hi);
-  // fast diagonal path (mask_tri above): causal right bound exactly on the diagonal, no left bound, diagonal tile-aligned; then this wave's masked
-  // iterations are exactly its diagonal tile (u_last - 1) and the drain (u_last)
-  const int fd_s = __builtin_amdgcn_readfirstlane((FA_W64_FASTDIAG && !ALIBI && p.wr == 0 && p.wl < 0 && (shift & 63) == 0 && u_first <= u_last &&
-                                                   p_hi == u_last - 2 && (w_row0 + shift - key_base) == 64 * (u_last - 1)) ? 1 : 0);
-  const int u_diag_s = __builtin_amdgcn_readfirstlane(u_last - 1);
   const unsigned step_k = (unsigned)(BN * 2) * (unsigned)p.k_rs, step_v = (unsigned)(BN * 2) * (unsigned)p.v_rs;
   const int nmin_s = __builtin_amdgcn_readfirstlane(n_min), nts_s = __builtin_amdgcn_readfirstlane(n_tiles);
   auto step_pair = [&](auto parc, int u) __attribute__((always_inline)) {
@@ -948,26 +915,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
     }
 #else
-    // (fresh laundered scalars per test, as masked(): a hoisted boolean becomes a lane mask)
-    int fd32 = __builtin_amdgcn_readfirstlane(fd_s), od32 = __builtin_amdgcn_readfirstlane(us - u_diag_s);
-    asm volatile("" : "+s"(fd32), "+s"(od32));
-    auto fastdiag = [&]() __attribute__((always_inline)) { int c = fd32; asm volatile("" : "+s"(c)); return c != 0; };
-    auto on_diag = [&]() __attribute__((always_inline)) { int c = od32; asm volatile("" : "+s"(c)); return c == 0; };
-    if (__builtin_expect(masked(), 0)) {
-      if (fastdiag()) {
-        if (on_diag()) mask_tri(ICw<0>{});                        // step A of the diagonal tile: rows 0-31 see the triangle, rows 32-63 everything
-        else { mask_all(ICw<0>{}); mask_all(ICw<1>{}); }          // drain
-      } else set_mask(2 * u);
-    }
+    if (__builtin_expect(masked(), 0)) set_mask(2 * u);
     fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
-    if (__builtin_expect(masked(), 0)) {
-      if (fastdiag()) {
-        mask_all(ICw<0>{});                                       // step B: rows 0-31 see nothing (drain: the rescale path may have restored the broadcast)
-        if (on_diag()) mask_tri(ICw<1>{}); else mask_all(ICw<1>{});
-      } else set_mask(2 * u + 1);
-    }
+    if (__builtin_expect(masked(), 0)) set_mask(2 * u + 1);
     fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
-    if (__builtin_expect(masked(), 0)) { if (!fastdiag()) clear_mask(2 * u + 2); }   // (fast path: the drain is the block's last iteration of this wave, the diagonal tile is followed by the drain)
+    if (__builtin_expect(masked(), 0)) clear_mask(2 * u + 2);
 #endif
     iter_end();
   };

@@ -15,9 +15,6 @@ def acc_row(r, hi):   # fa_device.h: row of accumulator element r in the 32x32 M
     return (r & 3) + 8 * (r >> 2) + 4 * hi
 
 
-FAST_HITS = [0]   # (iterations the model walked through the fast diagonal path: the sweep asserts it is exercised)
-
-
 def walk_counts(sq, sk, wl, wr, desc):
     """Times each (query, key) pair is scored as visible; keys are offset by PAD so that keys < 0 and >= sk have a slot."""
     PAD = 2 * BN
@@ -60,10 +57,6 @@ def walk_counts(sq, sk, wl, wr, desc):
                 p_lo, p_hi = max(u_first, n_tiles - 1 - ph_t), min(u_last, n_tiles - 1 - pl_t)
             if p_hi < p_lo:
                 p_lo, p_hi = u_last + 1, u_last
-            # round 4, mask_tri / mask_all: the fast path of a wave's causal diagonal tile and the drain behind it (never in the descending variant)
-            fd = (not desc and wr == 0 and wl < 0 and (shift & 63) == 0 and u_first <= u_last and p_hi == u_last - 2
-                  and (w_row0 + shift - key_base) == 64 * (u_last - 1))
-            u_diag = u_last - 1
             for u in range(u_first & ~1, u_last + 1):
                 masked = not (p_lo <= u <= p_hi)
                 for i_step in (2 * u, 2 * u + 1):
@@ -76,13 +69,7 @@ def walk_counts(sq, sk, wl, wr, desc):
                             lim_hi = min(sk - 1, my_row + shift + wr) if wr >= 0 else sk - 1
                             lim_lo = max(0, my_row + shift - wl) if wl >= 0 else 0
                             for hi in range(2):
-                                if masked and fd:
-                                    FAST_HITS[0] += 1
-                                    tri = ((2 << ((qi - 4 * hi) & 31)) - 1) & 0xffffffff if qi - 4 * hi >= 0 else 0
-                                    half = i_step & 1
-                                    # diagonal tile: step A = (triangle, everything), step B = (nothing, triangle); drain: nothing
-                                    bits = 0 if u != u_diag else ((tri, 0xffffffff)[qb] if half == 0 else (0, tri)[qb])
-                                elif masked:
+                                if masked:
                                     rel_hi, rel_lo = min(lim_hi - k0m - 4 * hi, 31), max(lim_lo - k0m - 4 * hi, 0)
                                     ones = 0xffffffff if rel_hi - rel_lo >= 31 else ((2 << ((rel_hi - rel_lo) & 31)) - 1) & 0xffffffff
                                     bits = ((ones << (rel_lo & 31)) & 0xffffffff) if rel_hi >= rel_lo else 0
@@ -119,19 +106,6 @@ def test_descending_walk_scores_each_visible_pair_once(sq, sk, wl):
     """The causal-ALiBi variant's domain: right bound on the diagonal (wr = 0), any left bound."""
     cnt, pad = walk_counts(sq, sk, wl, 0, desc=True)
     assert np.array_equal(cnt, visible(sq, sk, wl, 0, pad))
-
-
-def test_fast_diagonal_path_is_taken_for_aligned_causal_blocks():
-    for sq, sk in ((256, 256), (512, 512), (256, 320), (1024, 1024), (300, 300), (192, 448)):
-        FAST_HITS[0] = 0
-        cnt, pad = walk_counts(sq, sk, -1, 0, desc=False)
-        assert np.array_equal(cnt, visible(sq, sk, -1, 0, pad)), (sq, sk)
-        assert FAST_HITS[0] > 0, (sq, sk)
-    FAST_HITS[0] = 0
-    walk_counts(300, 333, -1, 0, desc=False)      # diagonal not tile-aligned: the general path
-    walk_counts(512, 512, 100, 0, desc=False)     # left bound
-    walk_counts(512, 512, -1, 0, desc=True)       # descending variant
-    assert FAST_HITS[0] == 0
 
 
 def test_random_shapes_and_windows_both_directions():

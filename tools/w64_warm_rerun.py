@@ -16,10 +16,11 @@ for (B, S, H, D, causal) in ((4, 4096, 32, 128, True), (16, 1024, 16, 128, True)
     st = f()[1].float().cpu().reshape(B, H, S // 64, 64).double()      # per wave: 64 stamps
     nb = S // 256
     print(f"S={S} causal={int(causal)}: per query block position (mean over batch, heads, waves), shader clocks")
-    print("  m_block | Q conversion: 1st pass  2nd pass | epilogue: 1st pass  2nd pass")
+    print("  m_block | barrier->K0/V DMA issued  ->Q frags read from LDS | Q conversion: 1st pass  2nd pass | epilogue: 1st pass  2nd pass")
     for mb in range(nb):
         x = st[:, :, 4 * mb:4 * mb + 4, :].reshape(-1, 64)
         n_it = min((mb * 256 + 256 + 63) // 64 + 1 if causal else S // 64 + 1, 53)
-        q1, q2 = (x[:, 58] - x[:, 0]).mean(), (x[:, 1] - x[:, 58]).mean()
+        d0, d1 = (x[:, 56] - x[:, 0]).mean(), (x[:, 55] - x[:, 56]).mean()
+        q1, q2 = (x[:, 58] - x[:, 55]).mean(), (x[:, 1] - x[:, 58]).mean()
         e1, e2 = (x[:, 57] - x[:, 3 + n_it]).mean(), (x[:, 62] - x[:, 57]).mean()
-        print(f"  {mb:7d} | {q1:22.0f} {q2:9.0f} | {e1:18.0f} {e2:9.0f}")
+        print(f"  {mb:7d} | {d0:24.0f} {d1:25.0f} | {q1:22.0f} {q2:9.0f} | {e1:18.0f} {e2:9.0f}")
