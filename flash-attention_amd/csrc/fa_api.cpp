@@ -55,6 +55,7 @@ const fa::Knobs* read_knobs() {
   k->w64_persist = env_int("FA_W64_PERSIST", 1);
   k->strict = env_int("FA_STRICT", 0);
   k->dkdv_prescale = env_int("FA_DKDV_PRESCALE", 0);
+  k->bwd_fuse_delta = env_int("FA_BWD_FUSE_DELTA", 1);
   k->pack_gqa = env_int("FA_PACK_GQA", 1);
   if (k->strict) k->rescale_thr = 0.f;
   return k;
@@ -493,6 +494,23 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   // shapes are handled by the binder, which zero-fills as flash_api.cpp:992-999 does).
   if (a->seqlen_q == 0 || a->seqlen_k == 0 || a->total_q == 0 || a->total_k == 0) return FA_OK;
   const int dk_ = head_dim_kernel(a->d);   // kernel head dim (!= a->d: BwdK::d_chunks)
+  // Round 4: where the 64-rows-per-wave dQ kernel runs (plain attention, head dim 64 / 128, long key loops) it computes softmax_d = rowsum(dO * O) of its own rows
+  // in its prologue and goes FIRST; the dK/dV kernel behind it reads softmax_d from memory as before and the delta pre-pass is not launched
+  // (FA_BWD_FUSE_DELTA=0: the three-launch order).  -2 from the launcher = the schedule does not apply after all: nothing was enqueued, fall through.
+  if (k.dq_nw == 64 && !k.ds_ws && fa::knobs().bwd_fuse_delta) {
+    k.fuse_delta = 1;
+    int rc = fa::launch_bwd_dq_w64(k, bf, a->d, s);
+    if (rc == 0) {
+      fa::last_schedule().bwd_dq_nw = 64;
+      rc = fa::launch_bwd_dkdv(k, bf, dk_, s);
+      fa::last_schedule().bwd_dkdv_nw = a->d > 128 ? 4 : 8;
+      fa::last_schedule().bwd_spill = 0; fa::last_schedule().bwd_list = (k.q_list != nullptr) + 2 * (k.k_list != nullptr);
+      if (rc != 0) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+      return FA_OK;
+    }
+    if (rc != -2) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    k.fuse_delta = 0;
+  }
   int rc = fa::launch_bwd_delta(k, bf, dk_, s);
   if (rc == 0) {
     int dkdv_nw = 64;

@@ -79,7 +79,7 @@ template <typename E, int T> FA_DEVINL void mfma_q_acc(u32x4 a, u32x4 b) {
 
 }  // namespace
 
-template <typename E, int D>
+template <typename E, int D, bool FUSE_DELTA>
 __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
     if (my_row < sq) {
       const int64_t base = p.cu_q ? ((int64_t)h * p.total_q + q_row0) : (((int64_t)b * p.h + h) * p.sq);
       lse_l[qb] = p.lse[base + my_row] * kLog2eW;
-      delta_l[qb] = p.delta[base + my_row];
+      if constexpr (!FUSE_DELTA) delta_l[qb] = p.delta[base + my_row];
     }
   }
 
@@ -177,6 +177,21 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
     const E* qsrc = (const E*)p.q + q_boff + q_row0 * p.q_rs + (int64_t)h * p.q_hs;
     const E* dosrc = (const E*)p.dout + do_boff + q_row0 * p.do_rs + (int64_t)h * p.do_hs;
     constexpr int QDMA = (64 * ROW_BYTES) / 1024;   // pieces per wave and operand
+    // Round 4, fuse_delta: softmax_d = rowsum(dO * O) of this wave's rows, computed HERE instead of by a pre-pass over the whole tensor (fa_bwd_delta_kernel: 55 us
+    // of a 2.0 ms backward at config 3, and a launch).  O is read straight from memory in the dO fragments' layout -- lane (qi, hi) holds the eight channels
+    // 16*ks + 8*hi .. of its row: sixteen 16-byte loads per lane and block, issued before the Q / dO DMA wait -- and meets the dO fragments on their way into the
+    // accumulator registers (v_dot2_f32); the two lane halves of a row are added with one swap.  The dK/dV kernel reads the result from softmax_d: it is launched
+    // behind this kernel (fa_api.cpp: do_bwd).
+    u32x4 ofr[QB * KS];
+    if constexpr (FUSE_DELTA) {
+      const E* osrc = (const E*)p.o + (p.cu_q ? 0 : (int64_t)b * p.o_bs) + q_row0 * p.o_rs + (int64_t)h * p.o_hs;
+      static_for<QB * KS>([&](auto fc) __attribute__((always_inline)) {
+        constexpr int f = decltype(fc)::value, qb = f / KS, ks = f % KS;
+        const int grow = min(w_row0 + 32 * qb + qi, sq - 1);
+        ofr[f] = ld_global_16B(osrc + (int64_t)grow * p.o_rs + 16 * ks + 8 * hi, true);
+      });
+    }
+    float dpart[QB] = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < QDMA; ++i) {
       const int row = wave * 64 + i * RPD + d_row;
@@ -205,7 +220,23 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       }
       acc_write_frag<BW_Q_BASE + 4 * f>(__builtin_bit_cast(u32x4, sc));
       acc_write_frag<BW_DO_BASE + 4 * f>(xd);
+      if constexpr (FUSE_DELTA) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dpart[qb] = dot2_acc<E>(xd[j], ofr[f][j], dpart[qb]);
+      }
     });
+    if constexpr (FUSE_DELTA) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const int my_row = w_row0 + 32 * qb + qi;
+        const float dl = half_sum(dpart[qb]);
+        if (my_row < sq) {
+          delta_l[qb] = dl;
+          const int64_t base = p.cu_q ? ((int64_t)h * p.total_q + q_row0) : (((int64_t)b * p.h + h) * p.sq);
+          if (hi == 0) p.delta[base + my_row] = dl;
+        }
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();   // the K/V rings reuse this LDS
   }
@@ -617,17 +648,22 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
 int launch_bwd_dq_ds(const BwdK&, int, int, hipStream_t) { return -2; }   // not in the default build
 #endif
 
-template <typename E, int D>
-static int launch_bwd_dq_w64_t(const BwdK& p, hipStream_t stream) {
+template <typename E, int D, bool FUSE_DELTA>
+static int launch_bwd_dq_w64_f(const BwdK& p, hipStream_t stream) {
   constexpr int TILE = 64 * D * 2, RINGS = 2 * 3 * TILE, STAGE_IN = 2 * 256 * D * 2, STAGE_OUT = 256 * (D * 2 + 16);
   constexpr int smem = (RINGS > STAGE_IN ? (RINGS > STAGE_OUT ? RINGS : STAGE_OUT) : (STAGE_IN > STAGE_OUT ? STAGE_IN : STAGE_OUT));
-  auto kern = fa_bwd_dq_w64_kernel<E, D>;
+  auto kern = fa_bwd_dq_w64_kernel<E, D, FUSE_DELTA>;
   static std::atomic<unsigned long long> attr_mask{0};
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
   const long long total = p.q_list ? (long long)p.q_bound * p.h : units_grid(p.q_units, p.q_unit_size);
   if (total <= 0) return 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <typename E, int D>
+static int launch_bwd_dq_w64_t(const BwdK& p, hipStream_t stream) {
+  return p.fuse_delta ? launch_bwd_dq_w64_f<E, D, true>(p, stream) : launch_bwd_dq_w64_f<E, D, false>(p, stream);
 }
 
 // 4 waves x 64 query rows per workgroup (the caller sized nmb / the work list for 256-row blocks).  Plain attention only;

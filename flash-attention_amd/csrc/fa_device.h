@@ -9,6 +9,7 @@
 //     columns 4*(i&3)..+3 of a 4x16 block of 16-bit elements; lane i receives column i
 //     (4 elements, rows 0..3) of that block.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -61,6 +62,14 @@ FA_DEVINL float half_sum(float x) {
   const unsigned u = __builtin_bit_cast(unsigned, x);
   const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+// acc + a.x * b.x + a.y * b.y on two packed 16-bit pairs (v_dot2_f32_bf16 / v_dot2_f32_f16: products exact in fp32)
+template <typename E> FA_DEVINL float dot2_acc(unsigned a, unsigned b, float acc) {
+  float r;
+  if constexpr (std::is_same<E, __bf16>::value) asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+  else asm("v_dot2_f32_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+  return r;
 }
 
 // 16-byte global load of 8 consecutive 16-bit elements; zeros when !valid.

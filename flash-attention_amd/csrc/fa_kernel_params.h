@@ -108,6 +108,8 @@ struct BwdK {
                              // dim between the built sizes): the chunks behind them are read as zeros and never stored (as FwdK::d_chunks); the
                              // 4-wave dQ kernel, the dK/dV kernel and the delta pre-pass take it
   int32_t dq_nw;             // dQ schedule: 4 / 8 waves x 32 rows, 64 = 4 waves x 64 rows (nmb and the query work list are sized for it)
+  int32_t fuse_delta;        // 64-rows-per-wave dQ kernel only: 1 = compute softmax_d = rowsum(dO * O) of its own rows in the prologue (and write it for the
+                             // dK/dV kernel, which is then launched BEHIND the dQ kernel); 0 = read it (fa_bwd_delta_kernel ran first)
 };
 
 }  // namespace fa

@@ -23,6 +23,7 @@ struct Knobs {
   int pack_gqa;        // FA_PACK_GQA: 0 = never pack the query heads of a KV group into the rows of a block on the KV-cache path (A/B, tests)
   int dkdv_prescale;   // FA_DKDV_PRESCALE=1: the plain dK/dV kernel pre-scales K by softmax_scale*log2e (rounded to the input dtype; ~3 % faster, fa_bwd.hip: PRE);
                        // default 0 = every score scaled in fp32 (FEAT_EXACT)
+  int bwd_fuse_delta;  // FA_BWD_FUSE_DELTA=0: always run the delta pre-pass (default 1: the 64-rows-per-wave dQ kernel computes softmax_d of its rows itself and runs first)
   int strict;          // FA_STRICT=1: the reference's numerics contract -- rescale on any growth of a row maximum (threshold 0) and
                        // softmax_scale applied in fp32 to every score (never the bf16 pre-scaled Q of the 64-rows-per-wave kernel)
 };

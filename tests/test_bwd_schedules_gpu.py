@@ -41,9 +41,9 @@ def run_bwd(be, q, k, v, do, causal, wl=-1, wr=-1, **feat):
     torch.cuda.manual_seed(11)
     out, lse, _, rng = be.fwd(q, k, v, None, feat.get("alibi"), feat.get("p_drop", 0.0), D ** -0.5, causal, wl, wr, feat.get("softcap", 0.0),
                               False, None)
-    dq, dk, dv, _ = be.bwd(do, q, k, v, out, lse, None, None, None, feat.get("alibi"), feat.get("p_drop", 0.0), D ** -0.5, causal, wl, wr,
-                           feat.get("softcap", 0.0), False, None, rng)
-    return dq, dk, dv, be.last_schedule()
+    dq, dk, dv, delta = be.bwd(do, q, k, v, out, lse, None, None, None, feat.get("alibi"), feat.get("p_drop", 0.0), D ** -0.5, causal, wl, wr,
+                               feat.get("softcap", 0.0), False, None, rng)
+    return dq, dk, dv, be.last_schedule(), delta
 
 
 SHAPES = [  # B, Sq, Sk, H, Hk, causal, wl, wr
@@ -71,8 +71,19 @@ def test_dq_w64_kernel_matches_recomputing_kernel_and_fp32(be, knobs, dtype, sha
     knobs.set("FA_BWD_DQ_NW", 64)
     w = run_bwd(be, q, k, v, do, causal, wl, wr)
     assert a[3]["bwd_dq_nw"] == 4 and w[3]["bwd_dq_nw"] == 64, (a[3], w[3])
-    assert torch.equal(a[1], w[1]) and torch.equal(a[2], w[2])          # dk, dv: same kernel
+    assert torch.equal(a[2], w[2])                                      # dv: same kernel, and dV does not see softmax_d
+    knobs.set("FA_BWD_FUSE_DELTA", 0)                                   # the delta pre-pass for both: then dk is the same kernel on the same inputs too
+    w3 = run_bwd(be, q, k, v, do, causal, wl, wr)
+    knobs.unset("FA_BWD_FUSE_DELTA")
+    assert w3[3]["bwd_dq_nw"] == 64 and torch.equal(a[1], w3[1]) and torch.equal(a[2], w3[2])
     r = ref_grads(q, k, v, do, causal, wl, wr)
+    # round 4: the 64-rows-per-wave dQ kernel computes softmax_d = rowsum(dO * O) of its rows itself (another summation order than the pre-pass): dk and dq
+    # move by rounding, judged against the fp32 reference like dq below
+    for i in (0, 1):
+        e_f, e_3 = float((w[i].float() - r[i]).abs().max()), float((w3[i].float() - r[i]).abs().max())
+        assert e_f <= max(1.5 * e_3, 1e-2 if dtype == torch.bfloat16 else 2e-3), (i, e_f, e_3)
+    # softmax_d as the fused prologue writes it (every row of every block, the caller gets it back) against the pre-pass
+    assert float((w[4] - a[4]).abs().max()) <= 1e-4 * max(1.0, float(a[4].abs().max())), float((w[4] - a[4]).abs().max())
     floor = 1e-2 if dtype == torch.bfloat16 else 2e-3
     e4 = float((a[0].float() - r[0]).abs().max())
     e64 = float((w[0].float() - r[0]).abs().max())
