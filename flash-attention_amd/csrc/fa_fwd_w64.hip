@@ -326,22 +326,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     lim_hi[qb] = (p.wr >= 0) ? min(sk - 1, my_row + shift + p.wr) : sk - 1;
     lim_lo[qb] = (p.wl >= 0) ? max(0, my_row + shift - p.wl) : 0;   // (>= 0: the descending walk's drain step scores the zero tile left of key 0 -- it must not count as visible)
   }
-  // per query block of this wave (32 rows against the 32 keys of a step): the steps whose keys are ALL visible to all of its rows, and the
-  // steps with ANY visible key -- what the cold mask path looks at instead of row / key arithmetic
-  int qb_all_lo[QB], qb_all_hi[QB], qb_any_lo[QB], qb_any_hi[QB];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const int r0 = w_row0 + 32 * qb, r1 = r0 + 31;
-    const int hi0 = (p.wr >= 0) ? min(sk - 1, r0 + shift + p.wr) : sk - 1, hi1 = (p.wr >= 0) ? min(sk - 1, r1 + shift + p.wr) : sk - 1;
-    const int lo0 = (p.wl >= 0) ? (r0 + shift - p.wl) : 0, lo1 = (p.wl >= 0) ? (r1 + shift - p.wl) : 0;
-    qb_all_lo[qb] = (lo1 - key_base + 31) >> 5;  qb_all_hi[qb] = (hi0 - 31 - key_base) >> 5;   // k0 >= lo1 and k0 + 31 <= hi0
-    qb_any_lo[qb] = (lo0 - 31 - key_base + 31) >> 5;  qb_any_hi[qb] = (hi1 - key_base) >> 5;   // k0 + 31 >= lo0 and k0 <= hi1
-  }
-  auto step_needs_mask = [&](int i) __attribute__((always_inline)) {
-    const int k0 = key_base + 32 * i;
-    return (k0 + 31 > w_full_hi) || (k0 < w_full_lo);
-  };
-
   // ---- K/V tiles: global -> LDS by DMA through a buffer descriptor.  The LDS image is lane-linear, so the XOR swizzles
   // are applied to the per-lane SOURCE chunk.  A wave issues its DPW pieces of a tile from ONE statement: M0 = LDS base
   // of piece 0, pieces 1.. by the instruction offset (added to the LDS AND the memory address, hence the -1024*i folded
