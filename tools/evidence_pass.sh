@@ -8,7 +8,7 @@ timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider > $O/pytest_gpu
 tail -3 $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 ( time python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_err.txt ) 2> $O/bench_time.txt
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/kt -o p -- python $R/bench.py --steps 20 --warmup 5 --no-cpu --no-traffic --no-parity > $O/bench_line_profiled.json 2> $O/bench_prof_err.txt )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/kt -o p -- python $R/bench.py --steps 20 --warmup 5 --no-cpu --no-traffic --no-parity --no-sweep > $O/bench_line_profiled.json 2> $O/bench_prof_err.txt )
 python tools/rocpd_summary.py $O/kt/p_results.db > $O/bench_kernel_stats.txt 2>&1
 head -30 $O/bench_kernel_stats.txt
 [ -f $R/gpurun_abl/libfa_abl_2048.so ] && FA_GFX950_LIB=$R/gpurun_abl/libfa_abl_2048.so python tools/w64_stamps.py > $O/w64_stamps.txt 2>&1

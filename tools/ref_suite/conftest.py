@@ -16,6 +16,7 @@ import pytest
 PER_FN = int(os.environ.get("REF_SUITE_PER_FN", "250"))
 FUNCS = [f for f in os.environ.get("REF_SUITE_FUNCS", "").split(",") if f]
 OUT = os.environ.get("REF_SUITE_OUT", "ref_suite_result.jsonl")
+SEED = os.environ.get("REF_SUITE_SEED", "")   # a different string picks a different (equally deterministic) sample
 DESELECT = os.environ.get("REF_SUITE_DESELECT") or None   # regex over node ids: cases that do not apply to a ROCm backend (stated in run.sh)
 CAPABILITY = os.environ.get("REF_SUITE_FAKE_CAPABILITY")   # collection on a box without a GPU (counting cases only)
 if CAPABILITY:
@@ -43,7 +44,7 @@ def pytest_collection_modifyitems(config, items):
         stride = max(1, len(its) // PER_FN)
         n = 0
         for it in its:
-            if zlib.crc32(it.nodeid.encode()) % stride == 0:
+            if zlib.crc32((it.nodeid + SEED).encode()) % stride == 0:
                 keep.append(it); n += 1
             else:
                 drop.append(it)
@@ -83,4 +84,4 @@ def pytest_sessionfinish(session, exitstatus):
     if hasattr(session.config, "workerinput"):
         return   # xdist worker: the controller aggregates
     with open(OUT, "a") as f:
-        f.write(json.dumps({"totals": getattr(session.config, "_ref_totals", {}), "counts": _counts, "failures": _fail[:200], "not_applicable": getattr(session.config, "_ref_not_applicable", 0), "deselect": DESELECT, "exit": int(exitstatus)}) + "\n")
+        f.write(json.dumps({"totals": getattr(session.config, "_ref_totals", {}), "counts": _counts, "failures": _fail[:200], "not_applicable": getattr(session.config, "_ref_not_applicable", 0), "deselect": DESELECT, "seed": SEED, "exit": int(exitstatus)}) + "\n")
