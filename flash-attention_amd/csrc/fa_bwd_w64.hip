@@ -33,6 +33,9 @@
 #ifndef FA_BW64_WAIT2
 #define FA_BW64_WAIT2 1
 #endif
+#ifndef FA_BW64_CARRY
+#define FA_BW64_CARRY 1   // as FA_W64_CARRY in fa_fwd_w64.hip: the first operand reads of an iteration's second step are issued in the last gaps of its first step
+#endif
 #ifndef FA_BW64_AH
 #define FA_BW64_AH 2   // (3 with the paired waits costs five spilled registers; the forward measured no difference between 1 and 4)
 #endif
@@ -454,14 +457,14 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   //   pieces in the odd gaps 1, 3, ...  The score chains end 16 MFMAs before the next step reads them.
   auto fast_step = [&](auto halfc, auto maskc, int i_cur, f32x16 (&s_cur)[QB], f32x16 (&dp_cur)[QB], f32x16 (&s_nxt)[QB],
                        f32x16 (&dp_nxt)[QB], const u32x4 (&f_prev)[QB][2], u32x4 (&f_cur)[QB][2], const u32x4& dma_srd,
-                       const unsigned (&dma_off)[DPW], unsigned dma_toff, unsigned dma_dst) __attribute__((always_inline)) {
+                       const unsigned (&dma_off)[DPW], unsigned dma_toff, unsigned dma_dst, u32x4 (&fr)[FA_BW64_AH + 1]) __attribute__((always_inline)) {
     constexpr int half = decltype(halfc)::value;
     constexpr bool MASK = decltype(maskc)::value != 0;
     constexpr int HOFF = half * 32 * ROW_BYTES;
     constexpr int QKG = 2 * KS, DQG = 4 * DB, NG = 2 * QKG + DQG;
     constexpr int AH = FA_BW64_AH, RNG = AH + 1;     // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
     constexpr int NF = 2 * KS + 2 * DB;     // fragment slots: KS K rows, KS V rows, 2*DB transposed K
-    u32x4 fr[RNG];
+    static_assert(RNG == FA_BW64_AH + 1, "the fragment ring is the caller's (carried from a first step to its second step)");
     if (FA_BW64_ABL & 2) {
 #pragma unroll
       for (int f = 0; f < RNG; ++f) fr[f] = f_prev[0][0];
@@ -486,8 +489,10 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) { rel_hi[qb] = lim_hi[qb] - k0 - 4 * hi; rel_lo[qb] = lim_lo[qb] - k0 - 4 * hi; }
     }
+    if constexpr (!(FA_BW64_CARRY && half == 1)) {   // (second step: requested by the first step's last gaps)
 #pragma unroll
-    for (int f = 0; f < AH; ++f) rd_frag(f);
+      for (int f = 0; f < AH; ++f) rd_frag(f);
+    }
     __builtin_amdgcn_sched_barrier(0);
     static_for<NG>([&](auto xc) __attribute__((always_inline)) {
       constexpr int x = decltype(xc)::value;
@@ -543,6 +548,11 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
           f_cur[cq][r >> 3][(r & 7) >> 1] = pw;
         }
       }
+      // carry (fa_fwd_w64.hip): behind this step's last LDS wait the ring is free -- the first AH K-row fragments of the second step (half 1 of the same tile)
+      if constexpr (FA_BW64_CARRY && half == 0 && x >= NG - AH && !(FA_BW64_ABL & 2)) {
+        constexpr int fn = x - (NG - AH);
+        fr[fn % RNG] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[fn] + 32 * ROW_BYTES);
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -597,10 +607,11 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       const unsigned toff_k = (unsigned)(n_min + uu + 1) * (unsigned)(BN * 2) * (unsigned)p.k_rs;
       const unsigned toff_v = (unsigned)(n_min + uu + 1) * (unsigned)(BN * 2) * (unsigned)p.v_rs;
       // (a tile past the last one lands in the slot nobody reads again; rows past the descriptor's range are never a fault)
+      u32x4 fring[FA_BW64_AH + 1];   // operand ring of the two steps (the second step's first fragments are requested by the first)
       fast_step(ICw<0>{}, maskc, 2 * uu - 1, sA, dpA, sB, dpB, fA, fB, k_srd, koff_l, toff_k,
-                __builtin_amdgcn_readfirstlane((unsigned)(nslot * TILE_BYTES) + wave_dst));
+                __builtin_amdgcn_readfirstlane((unsigned)(nslot * TILE_BYTES) + wave_dst), fring);
       fast_step(ICw<1>{}, maskc, 2 * uu, sB, dpB, sA, dpA, fB, fA, v_srd, voff_l, toff_v,
-                __builtin_amdgcn_readfirstlane((unsigned)(V_RING + nslot * TILE_BYTES) + wave_dst));
+                __builtin_amdgcn_readfirstlane((unsigned)(V_RING + nslot * TILE_BYTES) + wave_dst), fring);
       have_prev = step_active(2 * uu);
       have_cur = step_active(2 * uu + 1);
       iter_tail();

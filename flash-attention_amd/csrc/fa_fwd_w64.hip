@@ -83,6 +83,9 @@
 #ifndef FA_W64_STAG_GS
 #define FA_W64_STAG_GS 1
 #endif
+#ifndef FA_W64_CARRY
+#define FA_W64_CARRY 1   // the first operand reads of an iteration's SECOND step (the other half of the same K tile: already in LDS) are issued in the last gaps of its first step
+#endif                   // instead of at the second step's head, where the first MFMA waits out their LDS round trip (A/B: profiles/r04_fwd_w64_carry.txt)
 #ifndef FA_W64_KV_POLN
 #define FA_W64_KV_POLN 0   // cache-policy bits of the K/V tile DMAs, bit mask: 1 sc0, 2 sc1, 4 nt (A/B in profiles/r04_fwd_w64_dma.txt)
 #endif
@@ -643,14 +646,14 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   //   checked in the ISA by tools/isa_blocks.py --m0).
   auto fast_step = [&](auto halfc, auto parc, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
                        const u32x4 (&pf_prev)[QB][2], u32x4 (&pf_cur)[QB][2], const u32x4& dma_srd, const unsigned (&dma_off)[DPW],
-                       unsigned dma_toff, unsigned dma_dst) __attribute__((always_inline)) {
+                       unsigned dma_toff, unsigned dma_dst, u32x4 (&kfr)[FA_W64_AH + 1]) __attribute__((always_inline)) {
     constexpr int half = decltype(halfc)::value, par = decltype(parc)::value;
     constexpr int QKG = 2 * KS, PVG = 4 * DB, NG = QKG + PVG;
     constexpr int KOFF = par * TILE_BYTES + half * 32 * ROW_BYTES;                       // K_u: buffer u & 1
     constexpr int VOFF = (2 + (par ^ 1)) * TILE_BYTES + half * 32 * ROW_BYTES;           // V_{u-1}: buffer (u - 1) & 1
     constexpr int AH = FA_W64_AH, RING = AH + 1;  // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
     constexpr int NF = KS + 2 * DB;       // fragment slots per step: KS K fragments, then 2*DB V fragments
-    u32x4 kfr[RING];
+    static_assert(RING == FA_W64_AH + 1, "the K fragment ring is the caller's (carried from a first step to its second step)");
     s16x4 vlo[RING], vhi[RING];
     if (FA_W64_ABL & 128) {
 #pragma unroll
@@ -680,8 +683,10 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     constexpr int UPG = PVG >= 16 ? 1 : 2;        // max3 units per gap
     auto tree_g0 = [](int mq) constexpr { return 1 + mq; };   // the chain of block mq retired at gap QKG - 2 + mq
     auto hm_gap = [&](int mq) constexpr { return tree_g0(mq) + 8 / UPG; };           // cross-half combine right after the tree
+    if constexpr (!(FA_W64_CARRY && half == 1)) {   // (second step: its first AH fragments were requested by the first step, see the end of the gap loop)
 #pragma unroll
-    for (int f = 0; f < AH; ++f) rd_frag(f);
+      for (int f = 0; f < AH; ++f) rd_frag(f);
+    }
     __builtin_amdgcn_sched_barrier(0);
     static_for<NG>([&](auto xc) __attribute__((always_inline)) {
       constexpr int x = decltype(xc)::value;
@@ -800,6 +805,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
             asm volatile("v_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(tmax[mq]), "+v"(tcopy[mq]));
         }
       }
+      // carry: behind this step's last LDS wait (gap NG - 4: slot NF - 2, everything landed) the K ring is free -- request the first AH fragments of the SECOND
+      // step's score chain (half 1 of the same K tile), one per gap; that step's waits count them exactly as if it had issued them itself
+      if constexpr (FA_W64_CARRY && half == 0 && x >= NG - AH && !(FA_W64_ABL & 128)) {
+        constexpr int fn = x - (NG - AH);
+        kfr[fn % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[fn] + par * TILE_BYTES + 32 * ROW_BYTES);
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
     if (FA_W64_LAGADD && !(FA_W64_ABL & 2)) {   // the last gap's elements
@@ -873,6 +884,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     // and made cheap: carried offsets, constant descriptors (37 scalar instructions per iteration in round 2's form of this, ~175 clocks of
     // a 3300-clock iteration).
     q_trickle();
+    u32x4 kring[FA_W64_AH + 1];   // K fragment ring of the two steps (the second step's first fragments are requested by the first)
     const int us = __builtin_amdgcn_readfirstlane(u);   // (uniform by construction; said so)
     unsigned dst_k = (unsigned)((par ^ 1) * TILE_BYTES) + wave_dst, dst_v = (unsigned)((2 + par) * TILE_BYTES) + wave_dst;
     // (two scalar multiplies: carried offsets end up in vector registers.  Walking downwards the tile before the first one has a "negative" offset:
@@ -890,19 +902,19 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     // traffic in the copies and eight more pad s_nop in the hot steps.)
     if (__builtin_expect(masked(), 0)) {
       set_mask(2 * u);
-      fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
+      fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k, kring);
       set_mask(2 * u + 1);
-      fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
+      fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v, kring);
       clear_mask(2 * u + 2);
     } else {
-      fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
-      fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
+      fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k, kring);
+      fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v, kring);
     }
 #else
     if (__builtin_expect(masked(), 0)) set_mask(2 * u);
-    fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k);
+    fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k, kring);
     if (__builtin_expect(masked(), 0)) set_mask(2 * u + 1);
-    fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v);
+    fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v, kring);
     if (__builtin_expect(masked(), 0)) clear_mask(2 * u + 2);
 #endif
     iter_end();

@@ -10,7 +10,7 @@ if [ "$1" != "run" ]; then
   mkdir -p gpurun_abl
   for m in $MASKS; do
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -DFA_BW64_ABL=$m $EXTRA -c $PKG/csrc/fa_bwd_w64.hip -o gpurun_abl/bw64_$m.o &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_bwabl_$m.so $PKG/csrc/fa_fwd_bf16.o $PKG/csrc/fa_fwd_f16.o $PKG/csrc/fa_fwd_il.o $PKG/csrc/fa_fwd_w64_bf16.o $PKG/csrc/fa_fwd_w64_f16.o $PKG/csrc/fa_bwd_dkdv.o $PKG/csrc/fa_bwd_dq.o gpurun_abl/bw64_$m.o $PKG/csrc/fa_bwd_dkdv64.o $PKG/csrc/fa_api.o && rm gpurun_abl/bw64_$m.o ) &
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_bwabl_$m.so $PKG/csrc/fa_fwd_bf16.o $PKG/csrc/fa_fwd_f16.o $PKG/csrc/fa_fwd_il.o $PKG/csrc/fa_fwd_w64_bf16.o $PKG/csrc/fa_fwd_w64_f16.o $PKG/csrc/fa_bwd_dkdv.o $PKG/csrc/fa_bwd_dq.o gpurun_abl/bw64_$m.o $PKG/csrc/fa_api.o && rm gpurun_abl/bw64_$m.o ) &
   done
   wait
   ls -la gpurun_abl
