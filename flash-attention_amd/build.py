@@ -55,10 +55,10 @@ def _sources(names):
 def build_lib(force=False):
     hdrs = _sources(["fa_device.h", "fa_kernel_params.h", "fa_launch.h"]) + [os.path.join(ROOT, "include", "fa_gfx950.h")]
     # (source, object, extra flags).  fa_fwd.hip, fa_fwd_w64.hip and fa_bwd.hip are compiled twice each, side by side (bf16 / fp16 instantiations of the
-    # forwards: FA_FWD_PART, FA_W64_PART; dK/dV half / dQ half of the backward: FA_BWD_PART): they are the slowest units of the build.  The 64-per-wave units place their row-sum adds by hand (see the note on asm
+    # forwards: FA_FWD_PART, FA_W64_PART; dK/dV part / dQ part / fused backward: FA_BWD_PART): they are the slowest units of the build.  The 64-per-wave units place their row-sum adds by hand (see the note on asm
     # helpers in fa_w64_asm.h), hence -fno-slp-vectorize there.
     units = [("fa_fwd.hip", "fa_fwd_bf16.o", ["-DFA_FWD_PART=1"]), ("fa_fwd.hip", "fa_fwd_f16.o", ["-DFA_FWD_PART=2"]), ("fa_fwd_il.hip", "fa_fwd_il.o", []), ("fa_fwd_w64.hip", "fa_fwd_w64_bf16.o", ["-fno-slp-vectorize", "-DFA_W64_PART=1"]), ("fa_fwd_w64.hip", "fa_fwd_w64_f16.o", ["-fno-slp-vectorize", "-DFA_W64_PART=2"]),
-             ("fa_bwd.hip", "fa_bwd_dkdv.o", ["-DFA_BWD_PART=1"]), ("fa_bwd.hip", "fa_bwd_dq.o", ["-DFA_BWD_PART=2"]),
+             ("fa_bwd.hip", "fa_bwd_dkdv.o", ["-DFA_BWD_PART=1"]), ("fa_bwd.hip", "fa_bwd_dq.o", ["-DFA_BWD_PART=2"]), ("fa_bwd.hip", "fa_bwd_fused.o", ["-DFA_BWD_PART=3"]),
              ("fa_bwd_w64.hip", "fa_bwd_w64.o", ["-fno-slp-vectorize"]), ("fa_api.cpp", "fa_api.o", [])]
     hdrs += _sources(["fa_w64_asm.h", "fa_fwd_w64_regs.h"])
     objs, cmds = [], []

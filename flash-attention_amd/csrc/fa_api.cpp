@@ -51,6 +51,7 @@ const fa::Knobs* read_knobs() {
   k->bwd_mode = env_int("FA_BWD_MODE", 0);
   k->bwd_dkdv = env_int("FA_BWD_DKDV", 0);
   k->bwd_ds_cap_mb = env_int("FA_BWD_DS_CAP_MB", 8192);
+  k->fz_line = std::max(1, std::min(64, env_int("FA_FZ_LINE", 32)));
   k->lds_pad = env_int("FA_IL_LDS_PAD", 0);
   k->w64_persist = env_int("FA_W64_PERSIST", 1);
   k->strict = env_int("FA_STRICT", 0);
@@ -452,10 +453,42 @@ int64_t bwd_ds_bytes(const FaBwdParams* a) {
   return bytes > ((int64_t)fa::knobs().bwd_ds_cap_mb << 20) ? 0 : bytes;
 }
 
+// Fused backward (FA_BWD_MODE=3, fa_bwd.hip fa_bwd_fused_kernel): bytes of the dS workspace (256-B aligned) when the call qualifies, else 0; the sync
+// area (fa_kernel_params.h FZ_*) sits behind it.  Same conditions as launch_bwd_fused.
+int64_t bwd_fused_ds_bytes(const FaBwdParams* a) {
+  if (fa::knobs().bwd_mode != 3 || a->cu_seqlens_q || a->cu_seqlens_k || a->seqused_q || a->seqused_k || (a->d != 128 && a->d != 64)) return 0;
+  if (a->seqlen_q <= 0 || a->seqlen_k < a->seqlen_q || a->window_left >= 0 || a->softcap > 0.f || a->alibi_slopes || a->p_dropout > 0.f) return 0;
+  const int64_t bytes = (int64_t)a->b * a->h * ((a->seqlen_q + 31) / 32) * ((a->seqlen_k + 31) / 32) * 2048;
+  return bytes > ((int64_t)fa::knobs().bwd_ds_cap_mb << 20) ? 0 : ((bytes + 255) & ~(int64_t)255);
+}
+int64_t bwd_fused_sync_bytes(const FaBwdParams* a) {
+  return fa::fz_sync_words((int64_t)a->b * a->h * ((a->seqlen_q + 255) / 256), fa::knobs().fz_line) * 4;
+}
+
 int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   fa::BwdK k;
   if (int rc = fill_bwd(a, varlen, k)) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (const int64_t fz = varlen ? 0 : bwd_fused_ds_bytes(a); fz > 0 && a->workspace && a->workspace_bytes >= fz + bwd_fused_sync_bytes(a) && a->total_q != 0) {
+    // delta pre-pass, then ONE launch: dK / dV and dQ = dS.K
+    k.ds_ws = a->workspace;
+    k.ds_nq32 = (a->seqlen_q + 31) / 32;
+    k.ds_nk32 = (a->seqlen_k + 31) / 32;
+    k.nmb = (a->seqlen_q + 255) / 256;
+    k.fuse_sync = (int32_t*)((char*)a->workspace + fz);
+    k.fuse_items = a->b * a->h * k.nmb;
+    k.fuse_line = fa::knobs().fz_line;
+    const int bf = a->dtype == FA_DTYPE_BF16;
+    int rc = fa::launch_bwd_delta(k, bf, a->d, s);
+    if (rc == 0) rc = fa::launch_bwd_fused(k, bf, a->d, s);
+    if (rc == 0) {
+      fa::LastSchedule& ls = fa::last_schedule();
+      ls.bwd_dkdv_nw = 8; ls.bwd_dq_nw = 8; ls.bwd_spill = 3; ls.bwd_list = 0;
+      return FA_OK;
+    }
+    if (rc != -2) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (int rc2 = fill_bwd(a, varlen, k)) return rc2;   // does not apply after all: the default path, from a clean parameter block
+  }
   const int64_t ds_bytes = varlen ? 0 : bwd_ds_bytes(a);
   if (ds_bytes > 0 && a->workspace && a->workspace_bytes >= ds_bytes) {
     k.ds_ws = a->workspace;
@@ -640,6 +673,7 @@ int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {
   if (!params) return 0;
   int64_t qe, ke;
   bwd_list_entries(params, qe, ke);
+  if (const int64_t fz = bwd_fused_ds_bytes(params); fz > 0) return fz + bwd_fused_sync_bytes(params);
   return (qe ? (qe + 1) * 8 : 0) + (ke ? (ke + 1) * 8 : 0) + bwd_ds_bytes(params);   // (work lists: varlen only; dS: fixed-length only)
 }
 int fa_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, false); }

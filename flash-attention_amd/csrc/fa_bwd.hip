@@ -52,6 +52,15 @@ static __device__ __forceinline__ void wait_lgkm_le(int n) {
 #ifndef FA_EXPERIMENTS
 #define FA_EXPERIMENTS 0
 #endif
+#ifndef FA_FZ_STATS
+#define FA_FZ_STATS 0    // 1 = the fused backward adds up cycle counts of its parts in the sync area (tools/bwd_fused_check.py --stats)
+#endif
+#ifndef FA_FZ_ABL
+#define FA_FZ_ABL 0      // timing ablations of the fused backward (results become wrong; tools/ablate_fused.sh): 1 no dQ work, 2 plain dS stores, 4 no tickets, 8 no acquire, 16 no waiting at the end, 32 no dS DMA / 64 no K DMA after a dQ item's first two tiles, 128 one MFMA per dQ sub-tile
+#endif
+#ifndef FA_BWD_PART
+#define FA_BWD_PART 0    // build.py compiles this file three times side by side: 1 = delta + dK/dV, 2 = dQ, 3 = the fused backward; 0 = everything
+#endif
 #ifndef FA_DKDV_PRESCALE
 #define FA_DKDV_PRESCALE 1  // 0 = the plain dK/dV kernel subtracts LSE and delta on the vector ALU like the feature variants (A/B)
 #endif
@@ -111,8 +120,10 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
 // ------------------------------------------------------------------------------------------------
 // dK / dV
 // ------------------------------------------------------------------------------------------------
-template <typename E, int D, int DV, int FEAT>
-__global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_dkdv_kernel(const BwdK p) {
+// The kernel's text is a device function so that the fused backward (fa_bwd_fused_kernel below, FUSED = true) can run the dQ contractions of finished
+// query blocks behind it in the same workgroup; `bid` = the workgroup's position in the 1-D grid.
+template <typename E, int D, int DV, int FEAT, bool FUSED>
+static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int bid) {
   constexpr bool XFORM = (FEAT & (FEAT_CAP | FEAT_ALIBI)) != 0;  // scores pass through the scaled domain
   constexpr bool F_CAP = (FEAT & FEAT_CAP) != 0, F_ALIBI = (FEAT & FEAT_ALIBI) != 0, F_DROP = (FEAT & FEAT_DROP) != 0;
   using T = ElemTraits<E>;
@@ -148,7 +159,10 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char FA_LDS* lds = (char FA_LDS*)smem;
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid_ = threadIdx.x;
+  if constexpr (FUSED) asm volatile("" : "+v"(tid_));   // (inside the persistent loop of fa_bwd_fused_kernel: keeps everything derived from the thread index -- both
+                                                        // parts' address arithmetic -- from being hoisted out of that loop and held in registers across the other part)
+  const int tid = tid_, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, ki = lane & 31;
 
@@ -158,9 +172,9 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   // Within a head the low key blocks come first: they see the most queries under a causal mask.
   int b, hk, n_block;
   if (p.k_list) {  // varlen: non-empty key blocks only, heaviest first
-    if (!work_list_item(p.k_list, blockIdx.x, p.h_k, p.h_k, b, hk, n_block)) return;
+    if (!work_list_item(p.k_list, bid, p.h_k, p.h_k, b, hk, n_block)) return;
   } else {
-    const int w = xcd_interleave(blockIdx.x, p.k_units, p.k_unit_size, p.k_unit_hpx);
+    const int w = xcd_interleave(bid, p.k_units, p.k_unit_size, p.k_unit_hpx);
     if (w < 0) return;
     const int bhk = w / p.nnb;
     n_block = w - bhk * p.nnb;
@@ -491,8 +505,13 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
         for (int j = 0; j < 8; ++j) { dsfrag[0][j] = (E)0.f; dsfrag[1][j] = (E)0.f; }
       }
       E* dst = (E*)p.ds_ws + (((((int64_t)b * p.h + item_head(it)) * p.ds_nq32 + (q0 >> 5)) * p.ds_nk32 + (wk0 >> 5)) << 10) + ds_slot(ki, hi) * 8;
-      *(u32x4*)dst = __builtin_bit_cast(u32x4, dsfrag[0]);
-      *(u32x4*)(dst + 512) = __builtin_bit_cast(u32x4, dsfrag[1]);
+      if constexpr (FUSED && !(FA_FZ_ABL & 2)) {   // read by another workgroup of the SAME launch: written through (sc1), see fa_bwd_fused_kernel
+        st_global_16B_sc1(dst, __builtin_bit_cast(u32x4, dsfrag[0]));
+        st_global_16B_sc1(dst + 512, __builtin_bit_cast(u32x4, dsfrag[1]));
+      } else {
+        *(u32x4*)dst = __builtin_bit_cast(u32x4, dsfrag[0]);
+        *(u32x4*)(dst + 512) = __builtin_bit_cast(u32x4, dsfrag[1]);
+      }
     }
   };
 
@@ -533,6 +552,24 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
     }
   };
 
+  // FUSED: per (batch, head, 256-query block) arrival counters.  The workgroup whose ticket is the last one expected for a block puts the block on
+  // the ready queue of dQ items (fa_bwd_fused_kernel).  State of thread 0 only.
+  constexpr int FZ_TPB = 256 / BMQ;   // streamed tiles per dQ block
+  int fz_item = -1, fz_old = 0, fz_exp = 0;
+  auto fz_settle = [&]() __attribute__((always_inline)) {
+    if (fz_item >= 0) {
+      if (fz_old == fz_exp - 1) {
+        // publish on this XCD's queue: slot <- item + 1 (an exchange: its return proves the word is in memory), THEN one more available item
+        int32_t* ctrl = p.fuse_sync + FZ_CTRL + (bid & 7) * FZ_CTRL_STRIDE;
+        const int slot = __hip_atomic_fetch_add(ctrl + FZ_TAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int was = __hip_atomic_exchange(p.fuse_sync + FZ_COUNTERS + (int64_t)p.fuse_items * p.fuse_line + (int64_t)(bid & 7) * p.fuse_items + slot, fz_item + 1, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" : "+v"(was));   // (the increment below must not be issued before the exchange has returned)
+        __hip_atomic_fetch_add(ctrl + FZ_AVAIL, was == 0x7fffffff ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      fz_item = -1;
+    }
+  };
   using Q0 = std::integral_constant<int, 0>;
   using Q1 = std::integral_constant<int, 1>;
   // Every wave in lock step, one barrier per item.
@@ -550,6 +587,23 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
     if (FA_DKDV_ABL & 8) return;
     lds_dma_wait_all();
     __syncthreads();
+    if constexpr (FUSED) {
+      // Every wave's dS stores of this item are acknowledged (the vmcnt(0) above, in every wave, then the barrier).  Thread 0 settles the ticket it
+      // drew one item ago (its return value has long arrived: no wait) and draws one for the query block this item completed, if any.
+      if (tid == 0 && !(FA_FZ_ABL & 4)) {
+        fz_settle();
+        const int mt = item_m0(it) / BMQ;
+        const bool block_done = walk_down ? ((mt % FZ_TPB) == 0 || mt == m_lo) : ((mt % FZ_TPB) == FZ_TPB - 1 || mt == m_lo + nm - 1);
+        if (block_done) {
+          const int mb = mt / FZ_TPB;
+          const int blr = min(256 * mb + 255, sq - 1);                    // last row of the block
+          const int nnbv = (sk + BNK - 1) / BNK;                          // key blocks that exist
+          fz_exp = (p.wr >= 0) ? min(nnbv, (blr + shift + p.wr) / BNK + 1) : nnbv;   // key blocks that visit it (launch_bwd_fused: no left window, sk >= sq)
+          fz_item = ((int)b * p.h + item_head(it)) * p.nmb + mb;
+          fz_old = __hip_atomic_fetch_add(p.fuse_sync + FZ_COUNTERS + (int64_t)fz_item * p.fuse_line, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
   };
   for (int it = 0; it < n_items; it += 2) {
     item(Q0{}, it);
@@ -557,6 +611,9 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
     if (it + 1 < n_items) { item(Q1{}, it + 1); item_done(); }
   }
 
+  if constexpr (FUSED) {
+    if (tid == 0) fz_settle();
+  }
   // ---- epilogue: dK = scale * acc, dV = acc; every key row of the block is written (zeros included) --
   if (!wave_valid) return;
   // dK / dV tiles through the freed Q/dO buffers: whole-row stores (fa_device.h store_tile_via_lds); every key row of the
@@ -569,6 +626,306 @@ __global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_d
   store_tile_via_lds<E, D, DV>(stage, dv_acc, dv_scale, dvtile, p.dv_rs, sk - wk0, lane, cvr);
 }
 
+template <typename E, int D, int DV, int FEAT>
+__global__ void __launch_bounds__(D > 128 ? 256 : 512, D > 128 ? 1 : 2) fa_bwd_dkdv_kernel(const BwdK p) {
+  fa_bwd_dkdv_body<E, D, DV, FEAT, false>(p, blockIdx.x);
+}
+
+#if FA_BWD_PART == 0 || FA_BWD_PART == 3
+// ------------------------------------------------------------------------------------------------
+// Fused backward (FA_BWD_MODE=3): 5 contractions per tile, deterministic, one launch
+// ------------------------------------------------------------------------------------------------
+// Opt-in (measured: +4 % at the headline backward shape, +14 ... +27 % at causal S = 2k / 1k, -4 % non-causal at S = 4k, worse at head dim 64, and it needs
+// B*H*Sq*Sk*2 bytes of workspace -- profiles/r04_bwd_fused.txt; the default stays the scratch-free 7-contraction pair).
+// The dK/dV part writes every dS sub-tile it forms (rounded to the input dtype, as it enters the dK contraction) to a workspace and counts, per
+// (batch, head, 256-query block), the key blocks that have passed that query block.  The key block that brings a counter to its expected value puts the
+// query block on its XCD's ready queue; a workgroup, once its own key block is finished (registers and LDS free), takes query blocks off the queue until
+// it is empty and computes dQ = dS . K for them -- ONE contraction, where the recomputing dQ kernels spend three.  Nobody ever waits for a consumer (the
+// last arrival is the one that publishes, and whoever publishes drains the queue itself afterwards), so correctness needs no assumption about dispatch
+// order or residency, and the order of every accumulation is fixed: results are bitwise reproducible, dK / dV bitwise equal to the default path's.  Under
+// a causal mask all key blocks of a head walk the query tiles downwards together, so a query block's dS is consumed shortly after it was written.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): dS stores are written through (sc1) and acknowledged (vmcnt(0) in every wave + barrier) before
+// thread 0 draws the ticket (relaxed agent-scope atomic); the consumer takes the item, runs ONE agent-scope acquire, then a barrier, then plain loads.
+//
+// dQ^T[d][query] = sum_key K^T[d][key] . dS^T[key][query] for one 256-row block: 8 waves x 32 rows; K tiles (64 keys) shared through LDS, each wave's dS
+// sub-tiles DMA'd into its private LDS rows and read back transposed (ds_read_b64_tr_b16 turns the writer's lane = key image into the lane = query B
+// operand; fa_device.h ds_slot).
+template <typename E, int D>
+static __device__ __forceinline__ void fa_bwd_dq_from_ds(const BwdK& p, char FA_LDS* lds, const int b, const int h, const int m_block) {
+  using T = ElemTraits<E>;
+  using V8 = typename T::v8;
+  constexpr int NW = 8, BM = NW * 32, BN = 64, CPR = D / 8;
+  constexpr int ROW_BYTES = D * 2, TILE_BYTES = BN * ROW_BYTES, DB = D / 32;
+  constexpr int DS_WAVE = 2 * 2048;        // per wave and tile: the two 32-key sub-tiles of its 32 rows (contiguous in the workspace)
+  constexpr int DS_BUF = NW * DS_WAVE;
+  // LDS: K0 | K1 | K2 | dS0 | dS1 | dS2 -- a ring of three tiles, two of them in flight while one is computed on: the loop moves 48 KB per tile and
+  // 16 MFMAs per wave, so it runs at what the memory system returns per CU, i.e. bytes in flight / latency (one tile in flight: 1.4 us per tile measured)
+  constexpr int NST = 3;
+  constexpr int OFF_DS = NST * TILE_BYTES;
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));   // (not hoisted out of the persistent loop, see fa_bwd_dkdv_body)
+  const int tid = tid_, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int hk = h / p.hk_ratio;
+  const int sq = p.sq, sk = p.sk;
+  const int m0 = m_block * BM;
+  const E* __restrict__ kp = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
+  const int shift = sk - sq;
+  const int blk_last = min(m0 + BM, sq) - 1;
+  int kmax = sk - 1, kmin = 0;
+  if (p.wr >= 0) kmax = min(kmax, blk_last + shift + p.wr);
+  if (p.wl >= 0) kmin = max(0, m0 + shift - p.wl);
+  const int n_min = kmin / BN;
+  const int n_max = (kmax >= kmin) ? (kmax / BN + 1) : n_min;
+  const int w_row0 = m0 + wave * 32;
+  const bool wave_valid = w_row0 < sq;
+  const E* __restrict__ ds_row = (const E*)p.ds_ws + (((((int64_t)b * p.h + h) * p.ds_nq32) + (w_row0 >> 5)) * p.ds_nk32 << 10) + lane * 8;
+
+  constexpr int RPD = 1024 / ROW_BYTES, NDMA = TILE_BYTES / 1024, DPW = NDMA / NW;
+  static_assert(NDMA % NW == 0 && DPW >= 1, "tile does not divide over the waves");
+  // every wave issues the same number of DMA instructions per tile (DPW for K, + 4 for its dS when its rows exist), so "tile n has landed" is a
+  // literal vmcnt: sub-tiles past the last key block are fetched from the last one that exists (they are inactive and never read from LDS)
+  auto load_tile = [&](int n, int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int idx = wave * DPW + i;
+      const int row = idx * RPD + lane / CPR;
+      const int c = (lane % CPR) ^ swz16<D>(row);
+      const int key = min(n * BN + row, sk - 1);   // rows past the last key: clamped copies, their dS is zero
+      if (!((FA_FZ_ABL & 64) && n > n_min + 1)) lds_dma_16B(kp + (int64_t)key * p.k_rs + c * 8, lds + st * TILE_BYTES + idx * 1024);
+    }
+    if (wave_valid) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k32 = min(2 * n + (j >> 1), p.ds_nk32 - 1);
+        if (!((FA_FZ_ABL & 32) && n > n_min + 1)) lds_dma_16B(ds_row + ((int64_t)k32 << 10) + (j & 1) * 512, lds + OFF_DS + st * DS_BUF + wave * DS_WAVE + j * 1024);
+      }
+    }
+  };
+  auto wait_tile = [&](bool next_in_flight) __attribute__((always_inline)) {   // this wave's DMA of the current tile has landed
+    if (!next_in_flight || (FA_FZ_ABL & (32 | 64))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (wave_valid) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 4) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+  };
+  // transposed K fragments (as fa_bwd_dq_kernel) and transposed dS fragments
+  const int tr_i = lane & 15, tr_half = (lane >> 4) & 1, tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
+  int tr_base[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int row = 8 * s2 + 4 * hi + tr_rr;
+    tr_base[s2] = tile_off<D>(row, 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
+  }
+  // dS sub-tile image: half (queries 16*tr_half ..) * 1024 + slot(key = 16t + 8s + 4hi + rr, writer half = cc & 1) * 16 + (cc >> 1) * 8
+  const int ds_lane = tr_half * 1024 + hi * 128 + (tr_cc & 1) * 64 + tr_rr * 16 + (tr_cc >> 1) * 8 + OFF_DS + wave * DS_WAVE;
+
+  f32x16 dq_acc[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq_acc[i][r] = 0.f;
+
+  if (n_min < n_max) load_tile(n_min, 0);
+  if (n_min + 1 < n_max) load_tile(n_min + 1, 1);
+  auto tile = [&](auto curc, int n) __attribute__((always_inline)) {
+    constexpr int cur = decltype(curc)::value;
+    wait_tile(n + 1 < n_max);
+    __syncthreads();   // tile n is in LDS for every wave, and every wave is done with tile n - 1, whose stage the next load overwrites
+    if (n + 2 < n_max) load_tile(n + 2, (cur + 2) % NST);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int k0 = n * BN + 32 * kb;
+      if (!(wave_valid && ds_tile_active(w_row0, k0, sq, sk, shift, p.wl, p.wr))) continue;
+      V8 f[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int a = ds_lane + cur * DS_BUF + kb * 2048 + t * 512;
+        const s16x4 lo = lds_read_tr16(lds + a), hi4 = lds_read_tr16(lds + a + 256);
+        f[t] = combine_tr<V8>(lo, hi4);
+      }
+      constexpr int NOPS = 2 * DB, PFT = 3;
+      s16x4 tlo[PFT], thi[PFT];
+      auto rd = [&](int i) __attribute__((always_inline)) {
+        const int db = i % DB, t = i / DB;
+        const int base = cur * TILE_BYTES + kb * 32 * ROW_BYTES + 16 * t * ROW_BYTES;
+        tlo[i % PFT] = lds_read_tr16(lds + base + (tr_base[0] ^ (db << 6)));
+        thi[i % PFT] = lds_read_tr16(lds + base + (tr_base[1] ^ (db << 6)));
+      };
+#pragma unroll
+      for (int i = 0; i < PFT - 1; ++i) rd(i);
+#pragma unroll
+      for (int i = 0; i < NOPS; ++i) {
+        if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
+        if ((FA_FZ_ABL & 128) && i >= 1) continue;
+        dq_acc[i % DB] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), f[i / DB], dq_acc[i % DB]);
+      }
+    }
+  };
+  for (int n = n_min; n < n_max; n += NST) {
+    tile(std::integral_constant<int, 0>{}, n);
+    if (n + 1 < n_max) tile(std::integral_constant<int, 1>{}, n + 1);
+    if (n + 2 < n_max) tile(std::integral_constant<int, 2>{}, n + 2);
+  }
+  __syncthreads();   // every wave is done with the tiles: the staging below reuses their LDS
+  if (!wave_valid) return;
+  E* dqtile = (E*)p.dq + (int64_t)b * p.dq_bs + (int64_t)w_row0 * p.dq_rs + (int64_t)h * p.dq_hs;
+  store_tile_via_lds<E, D>(lds + wave * 32 * (ROW_BYTES + 16), dq_acc, p.scale, dqtile, p.dq_rs, sq - w_row0, lane);
+}
+
+// Take one ready dQ item off queue `ctrl` / `slots` (thread 0): -1 = nothing published at the moment.  A counting semaphore (FZ_AVAIL: published and
+// unclaimed items) in front of a ticket (FZ_HEAD), all of it returning atomic adds: a claim costs two of them whatever the contention.  (Measured and
+// replaced, profiles/r04_bwd_fused.txt: head < tail checked with loads + compare-exchange -- loads of these words may be served from this XCD's L2 with a
+// value another XCD has long replaced, and with up to 256 workgroups finishing together the compare-exchange took 60-140 retries per item.)  A workgroup
+// whose decrement finds nothing gives it back; if the word is positive after giving back (a publication slipped in between), it tries again -- so of the
+// workgroups that fail around a publication the last one to give back always sees it, and nothing is left behind.  Every loop is bounded: a claimed slot
+// whose content does not appear (its publisher is between its two atomics) is polled with read-modify-writes; the error flag instead of a hang.
+static __device__ __forceinline__ int fz_pop(int32_t* z, int32_t* ctrl, int32_t* slots, int (&st)[4]) {
+  for (int spin = 0; spin < (1 << 12); ++spin) {
+    if (__hip_atomic_fetch_add(ctrl + FZ_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+      const int hd = __hip_atomic_fetch_add(ctrl + FZ_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int tries = 0; tries < (1 << 18); ++tries) {
+        const int v = __hip_atomic_fetch_add(slots + hd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 0) return v - 1;
+        if (FA_FZ_STATS) ++st[1];
+        __builtin_amdgcn_s_sleep(4);
+      }
+      __hip_atomic_store(z + FZ_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return -1;
+    }
+    if (__hip_atomic_fetch_add(ctrl + FZ_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) return -1;   // still nothing after giving back
+    if (FA_FZ_STATS) ++st[0];
+  }
+  return -1;
+}
+
+template <int D> constexpr int fused_smem_bytes() {
+  constexpr int DKDV = 8 * 32 * D * 2 + 4 * 64 * D * 2 + 4 * 64 * 4, DQ = 3 * 64 * D * 2 + 3 * 8 * 4096, STAGE = 256 * (D * 2 + 16);
+  return (DKDV > DQ ? (DKDV > STAGE ? DKDV : STAGE) : (DQ > STAGE ? DQ : STAGE));
+}
+
+// One workgroup per CU, resident for the whole launch.  Workgroup w serves XCD w % 8 (where it is observed to run; performance only): it takes the next
+// key-block item of that XCD (x + 8k, the order the dK/dV kernel's grid is dealt in), runs the dK/dV part, then computes dQ for every block on the XCD's
+// ready queue, and repeats; once the key blocks are handed out it stays until the XCD's last key block is finished and the queue is empty.  (As a grid of
+// one workgroup per key block -- the first version -- the hardware dispatcher deals workgroups to the XCDs strictly in turn, so an XCD that fell behind
+// stalled the hand-out to all eight: 14-17 % of the CUs idle mid-launch, and the CUs of finished workgroups were lost to the tail, profiles/r04_bwd_fused.txt.)
+template <typename E, int D>
+__global__ void __launch_bounds__(512, 2) fa_bwd_fused_kernel(const BwdK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char FA_LDS* lds = (char FA_LDS*)smem;
+  constexpr int OFF_ITEM = fused_smem_bytes<D>();   // one word behind everything either part uses
+  int st[4] = {0, 0, 0, 0};                         // (FA_FZ_STATS) semaphore retries, publication polls, dQ items taken, key-block items taken
+  const int qx = blockIdx.x & 7;
+  int32_t* ctrl = p.fuse_sync + FZ_CTRL + qx * FZ_CTRL_STRIDE;
+  int32_t* slots = p.fuse_sync + FZ_COUNTERS + (int64_t)p.fuse_items * p.fuse_line + (int64_t)qx * p.fuse_items;
+  const int total_x = (p.fuse_total - qx + 7) >> 3;   // key-block items of this XCD
+#if FA_FZ_STATS
+  const unsigned long long w_begin = __builtin_amdgcn_s_memrealtime();
+  long long t_kv = 0, t_pop = 0, t_dq = 0;
+#endif
+  for (;;) {
+    __syncthreads();   // the part before is done with the LDS
+    if (threadIdx.x == 0) *(int FA_LDS*)(lds + OFF_ITEM) = __hip_atomic_fetch_add(ctrl + FZ_NEXT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int kx = __builtin_amdgcn_readfirstlane(*(const int FA_LDS*)(lds + OFF_ITEM));
+    const bool have_kv = kx < total_x;
+#if FA_FZ_STATS
+    const long long t0 = __builtin_readcyclecounter();
+#endif
+    if (have_kv) {
+      if (FA_FZ_STATS) ++st[3];
+      fa_bwd_dkdv_body<E, D, D, FEAT_EXACT, true>(p, qx + 8 * kx);
+      if (threadIdx.x == 0) {   // this key block is over: everything it publishes is published (its atomics have returned)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctrl + FZ_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#if FA_FZ_STATS
+    t_kv += __builtin_readcyclecounter() - t0;
+#endif
+    for (;;) {   // dQ for whatever is ready
+      __syncthreads();
+#if FA_FZ_STATS
+      const long long t1 = __builtin_readcyclecounter();
+#endif
+      if (threadIdx.x == 0) {
+        int item = fz_pop(p.fuse_sync, ctrl, slots, st);
+        // no key block left to take: stay until the XCD's last key block is finished and the queue is empty (bounded, ~2 ms).  Nobody waits for a waiter --
+        // publishers never depend on consumers -- and correctness never depends on the waiting: a publisher drains the queue itself.
+        if (item < 0 && !have_kv && !(FA_FZ_ABL & 16)) {
+          for (int w = 0; w < 512; ++w) {
+            const int done = __hip_atomic_fetch_add(ctrl + FZ_DONE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            item = fz_pop(p.fuse_sync, ctrl, slots, st);
+            if (item >= 0 || done >= total_x) break;
+            __builtin_amdgcn_s_sleep(96);
+          }
+        }
+        if (item >= 0 && !(FA_FZ_ABL & 8)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *(int FA_LDS*)(lds + OFF_ITEM) = item;
+      }
+      __syncthreads();
+      const int item = __builtin_amdgcn_readfirstlane(*(const int FA_LDS*)(lds + OFF_ITEM));
+#if FA_FZ_STATS
+      const long long t2 = __builtin_readcyclecounter();
+      t_pop += t2 - t1;
+#endif
+      if (item < 0) break;
+      if (FA_FZ_STATS) ++st[2];
+      const int bh = item / p.nmb;
+      if (FA_FZ_ABL & 1) continue;
+      fa_bwd_dq_from_ds<E, D>(p, lds, bh / p.h, bh % p.h, item - bh * p.nmb);
+#if FA_FZ_STATS
+      t_dq += __builtin_readcyclecounter() - t2;
+#endif
+    }
+    if (!have_kv) break;
+  }
+#if FA_FZ_STATS
+  if (threadIdx.x == 0) {
+    unsigned long long* sw = (unsigned long long*)(p.fuse_sync + FZ_STATS);
+    atomicAdd(sw + 0, (unsigned long long)t_kv);
+    atomicAdd(sw + 1, (unsigned long long)t_pop);
+    atomicAdd(sw + 2, (unsigned long long)t_dq);
+    atomicAdd(sw + 3, (unsigned long long)st[0]);
+    atomicAdd(sw + 4, (unsigned long long)st[1]);
+    atomicAdd(sw + 5, (unsigned long long)st[2]);
+    atomicAdd(sw + 6, 1ull);
+    atomicMax(sw + 7, (unsigned long long)t_pop);
+  }
+#endif
+}
+
+template <typename E, int D>
+static int launch_fused_t(const BwdK& p, hipStream_t stream) {
+  constexpr int smem = fused_smem_bytes<D>() + 16;
+  auto kern = fa_bwd_fused_kernel<E, D>;
+  static std::atomic<unsigned long long> attr_mask{0};
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
+  if (hipMemsetAsync(p.fuse_sync, 0, (size_t)fz_sync_words(p.fuse_items, p.fuse_line) * 4, stream) != hipSuccess) return -1;
+  const long long total = units_grid(p.k_units, p.k_unit_size);
+  static const int n_cu = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+  BwdK q = p;
+  q.fuse_total = (int)total;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(total < n_cu ? total : n_cu)), dim3(512), smem, stream, q);   // one workgroup per CU (the LDS footprint admits no second one)
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// The fused backward applies to plain attention (no softcap / ALiBi / dropout), fixed-length batches, head dim 64 / 128, no left window, sk >= sq
+// (fa_api.cpp bwd_fused_bytes checks the same and sizes the workspace); -2 = does not apply, nothing enqueued.
+int launch_bwd_fused(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
+  if (!p.ds_ws || !p.fuse_sync || p.cu_q || p.cu_k || p.seqused_q || p.seqused_k || p.k_list || p.d_chunks > 0) return -2;
+  if (p.softcap > 0.f || p.alibi || p.rng || p.wl >= 0 || p.sk < p.sq) return -2;
+  if (dtype_bf16) {
+    if (d == 128) return launch_fused_t<__bf16, 128>(p, stream);
+    if (d == 64) return launch_fused_t<__bf16, 64>(p, stream);
+  } else {
+    if (d == 128) return launch_fused_t<_Float16, 128>(p, stream);
+    if (d == 64) return launch_fused_t<_Float16, 64>(p, stream);
+  }
+  return -2;
+}
+#endif  // FA_BWD_PART == 0 || FA_BWD_PART == 3
+
+#if FA_BWD_PART != 3
 // ------------------------------------------------------------------------------------------------
 // dQ
 // ------------------------------------------------------------------------------------------------
@@ -855,21 +1212,19 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   store_tile_via_lds<E, D, DV>(lds + wave * 32 * (ROW_BYTES + 16), dq_acc, p.scale, dqtile, p.dq_rs, sq - w_row0, lane, cvr);
 }
 
+#endif  // FA_BWD_PART != 3
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 // query rows per dQ workgroup for the schedule BwdK::dq_nw: 4 | 8 waves x 32 rows, or 64 = 4 waves x 64 rows (fa_bwd_w64.hip)
 // The launchers come in two halves so that build.py can compile this file twice side by side (-DFA_BWD_PART=1: delta + dK/dV,
 // =2: dQ; 0 = everything in one object): the dK/dV and dQ instantiations are independent and dominate the library's build time.
-#ifndef FA_BWD_PART
-#define FA_BWD_PART 0
-#endif
-#if FA_BWD_PART != 1
+#if FA_BWD_PART == 0 || FA_BWD_PART == 2
 int bwd_block_m(int nw) { return (nw == 8 || nw == 64) ? 256 : 128; }
 #else
 int bwd_block_m(int nw);
 #endif
-#if FA_BWD_PART != 2
+#if FA_BWD_PART == 0 || FA_BWD_PART == 1
 int bwd_block_n(int d) { return d > 128 ? 128 : 256; }
 
 template <typename E, int D, int DV>
@@ -914,8 +1269,8 @@ static int launch_dkdv_t(const BwdK& p, hipStream_t stream) {
   }
 }
 
-#endif  // FA_BWD_PART != 2
-#if FA_BWD_PART != 1
+#endif  // FA_BWD_PART == 0 || FA_BWD_PART == 1
+#if FA_BWD_PART == 0 || FA_BWD_PART == 2
 template <typename E, int D, int DV, int NW, int FEAT>
 static int launch_dq_nw(const BwdK& p, hipStream_t stream) {
   constexpr int smem = 4 * 64 * D * 2 + NW * 32 * 16;  // K/V double buffers (+ the row padding of the staged dQ epilogue)
@@ -949,7 +1304,7 @@ static int launch_dq_t(const BwdK& p, hipStream_t stream) {
   }
 }
 
-#endif  // FA_BWD_PART != 1
+#endif  // FA_BWD_PART == 0 || FA_BWD_PART == 2
 
 #define FA_BWD_DISPATCH_E(fn, E)                                       \
   switch (d) {                                                         \
@@ -964,11 +1319,11 @@ static int launch_dq_t(const BwdK& p, hipStream_t stream) {
 #define FA_BWD_DISPATCH(fn)                                            \
   if (dtype_bf16) { FA_BWD_DISPATCH_E(fn, __bf16) } else { FA_BWD_DISPATCH_E(fn, _Float16) }
 
-#if FA_BWD_PART != 2
+#if FA_BWD_PART == 0 || FA_BWD_PART == 1
 int launch_bwd_delta(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_delta_t) }
 int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_dkdv_t) }
 #endif
-#if FA_BWD_PART != 1
+#if FA_BWD_PART == 0 || FA_BWD_PART == 2
 int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   LastSchedule& ls = last_schedule();
   const bool trimmed = (d == 32 || d == 96 || d == 192);

@@ -79,6 +79,10 @@ FA_DEVINL u32x4 ld_global_16B(const void* p, bool valid) {
   return z;
 }
 
+// 16-byte global store written through the XCD's L2 (sc1): for data another workgroup of the same launch reads back behind an agent-scope counter
+// (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload -> s_waitcnt vmcnt(0) -> flag).  Invisible to hipcc's waitcnt pass, like lds_dma_16B.
+FA_DEVINL void st_global_16B_sc1(void* p, u32x4 x) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory"); }
+
 template <typename V> FA_DEVINL V bitcast_u32x4(u32x4 x) { return __builtin_bit_cast(V, x); }
 
 // LDS transpose read: returns the 4 x 16-bit column this lane owns (see header comment).

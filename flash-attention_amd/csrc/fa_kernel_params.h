@@ -59,6 +59,14 @@ struct FwdK {
   float rp_keep;             // 1 / (1 - p_dropout)
 };
 
+// Fused backward (BwdK::fuse_sync, fa_bwd.hip fa_bwd_fused_kernel): int32 words of the sync area.  An error flag, 16 words of statistics (FA_FZ_STATS
+// builds), then eight control blocks -- one per XCD x, whose key-block items are those numbered x + 8k: the ready queue's tail, head and count of published
+// and unclaimed dQ items, the count of key-block items finished, the next key-block item to hand out, a 128-byte line each -- then one arrival counter per
+// dQ item (batch, head, 256-query block), BwdK::fuse_line words apart (32 = a line each), then the eight queues (item + 1; 0 = not published yet),
+// fuse_items words each.  Zeroed before every launch.
+enum { FZ_ERR = 0, FZ_STATS = 32, FZ_CTRL = 64, FZ_CTRL_STRIDE = 160, FZ_TAIL = 0, FZ_HEAD = 32, FZ_AVAIL = 64, FZ_DONE = 96, FZ_NEXT = 128, FZ_COUNTERS = FZ_CTRL + 8 * FZ_CTRL_STRIDE };
+inline constexpr long long fz_sync_words(long long items, int line) { return FZ_COUNTERS + items * line + 8 * items; }
+
 struct BwdK {
   const void* dout;
   const void* q;
@@ -108,6 +116,10 @@ struct BwdK {
                              // dim between the built sizes): the chunks behind them are read as zeros and never stored (as FwdK::d_chunks); the
                              // 4-wave dQ kernel, the dK/dV kernel and the delta pre-pass take it
   int32_t dq_nw;             // dQ schedule: 4 / 8 waves x 32 rows, 64 = 4 waves x 64 rows (nmb and the query work list are sized for it)
+  int32_t* fuse_sync;        // fused backward (FA_BWD_MODE=3): sync area behind the dS workspace (FZ_* above), NULL otherwise
+  int32_t fuse_items;        // dQ items of the fused backward = b * h * nmb (256-row blocks)
+  int32_t fuse_line;         // words between two arrival counters of the sync area
+  int32_t fuse_total;        // key-block items of the fused backward (= the dK/dV kernel's grid)
   int32_t fuse_delta;        // 64-rows-per-wave dQ kernel only: 1 = compute softmax_d = rowsum(dO * O) of its own rows in the prologue (and write it for the
                              // dK/dV kernel, which is then launched BEHIND the dQ kernel); 0 = read it (fa_bwd_delta_kernel ran first)
 };

@@ -170,3 +170,51 @@ def test_prescaled_k_variant_stays_inside_the_budget_of_the_default(be, knobs, s
         e_f = float((fast[i].float() - r[i]).abs().max())
         assert e_f <= max(2 * e_d, 1e-2), (i, e_f, e_d)
     assert not torch.equal(fast[1], default[1]) or Sk < 64   # (the knob does select another kernel)
+
+
+# Round 4: the fused backward (FA_BWD_MODE=3, opt-in): dK / dV and dQ = dS.K in one persistent launch, dS handed over through a workspace
+# (fa_bwd.hip fa_bwd_fused_kernel; reference: the 5-contraction compute_dq_dk_dv_1colblock, flash_bwd_kernel.h:457-733).
+FUSED_SHAPES = [  # B, Sq, Sk, H, Hk, causal
+    (1, 256, 256, 2, 2, False), (2, 1024, 1024, 4, 4, True), (1, 300, 333, 2, 2, True), (1, 1, 500, 2, 2, False), (1, 200, 1000, 4, 1, True),
+    (3, 512, 512, 32, 32, True), (2, 1024, 1024, 32, 8, True), (7, 640, 640, 6, 6, True), (1, 2048, 2048, 8, 2, False),
+]
+
+
+@pytest.mark.parametrize("d", [128, 64])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", FUSED_SHAPES, ids=lambda s: "B%d_Sq%d_Sk%d_H%d_%d_c%d" % s)
+def test_fused_backward_matches_default_and_fp32(be, knobs, dtype, shape, d):
+    B, Sq, Sk, H, Hk, causal = shape
+    torch.manual_seed(0)
+    q = torch.randn(B, Sq, H, d, device="cuda", dtype=dtype)
+    k = torch.randn(B, Sk, Hk, d, device="cuda", dtype=dtype)
+    v = torch.randn_like(k)
+    do = torch.randn_like(q)
+    knobs.set("FA_BWD_FUSE_DELTA", 0)   # softmax_d from the pre-pass on both sides: dK / dV come from the same arithmetic on the same inputs
+    a = run_bwd(be, q, k, v, do, causal)
+    knobs.set("FA_BWD_MODE", 3)
+    f = run_bwd(be, q, k, v, do, causal)
+    f2 = run_bwd(be, q, k, v, do, causal)
+    assert a[3]["bwd_spill"] == 0 and f[3]["bwd_spill"] == 3, (a[3], f[3])
+    assert torch.equal(a[1], f[1]) and torch.equal(a[2], f[2])                    # dk, dv bit for bit
+    assert all(torch.equal(x, y) for x, y in zip(f[:3], f2[:3]))                  # no atomics on data: run-to-run bitwise
+    r = ref_grads(q, k, v, do, causal, -1, -1)
+    floor = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    e0, e3 = float((a[0].float() - r[0]).abs().max()), float((f[0].float() - r[0]).abs().max())
+    assert torch.isfinite(f[0].float()).all() and e3 <= max(2 * e0, floor), (e3, e0)
+
+
+def test_fused_backward_declines_what_it_does_not_cover(be, knobs):
+    knobs.set("FA_BWD_MODE", 3)
+    torch.manual_seed(1)
+    q = torch.randn(1, 640, 2, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(1, 640, 2, 128, device="cuda", dtype=torch.bfloat16)
+    v, do = torch.randn_like(k), torch.randn_like(q)
+    for kw in (dict(wl=300, wr=-1), dict(softcap=20.0), dict(p_drop=0.1)):   # left window, softcap, dropout: the default kernels
+        wl, wr = kw.pop("wl", -1), kw.pop("wr", -1)
+        f = run_bwd(be, q, k, v, do, False, wl, wr, **kw)
+        assert f[3]["bwd_spill"] == 0, (kw, f[3])
+    f = run_bwd(be, q[:, :200], k, v, do[:, :200], True)                       # sk > sq is covered, sq > sk is not
+    assert f[3]["bwd_spill"] == 3
+    f = run_bwd(be, q, k[:, :200], v[:, :200], do, True)
+    assert f[3]["bwd_spill"] == 0

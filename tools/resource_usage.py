@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "flash-attention_amd", "csrc")
 UNITS = [("fa_fwd.hip", ["-DFA_FWD_PART=1"]), ("fa_fwd.hip", ["-DFA_FWD_PART=2"]), ("fa_fwd_il.hip", []), ("fa_fwd_w64.hip", ["-fno-slp-vectorize", "-DFA_W64_PART=1"]),
-         ("fa_fwd_w64.hip", ["-fno-slp-vectorize", "-DFA_W64_PART=2"]), ("fa_bwd.hip", ["-DFA_BWD_PART=1"]), ("fa_bwd.hip", ["-DFA_BWD_PART=2"]),
+         ("fa_fwd_w64.hip", ["-fno-slp-vectorize", "-DFA_W64_PART=2"]), ("fa_bwd.hip", ["-DFA_BWD_PART=1"]), ("fa_bwd.hip", ["-DFA_BWD_PART=2"]), ("fa_bwd.hip", ["-DFA_BWD_PART=3"]),
          ("fa_bwd_w64.hip", ["-fno-slp-vectorize"])]
 def unit(u):
     src, extra = u
