@@ -24,7 +24,7 @@ def main():
     cmds = [base + extra + ["-c", src, "-o", os.path.join(OUT, obj)] for src, obj, extra in units]
     with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
         list(ex.map(subprocess.check_call, cmds))
-    reuse = [os.path.join(CSRC, o) for o in ("fa_fwd_bf16.o", "fa_fwd_f16.o", "fa_fwd_il.o", "fa_fwd_w64_bf16.o", "fa_fwd_w64_f16.o", "fa_bwd_dq.o")]
+    reuse = [os.path.join(CSRC, o) for o in ("fa_fwd_bf16.o", "fa_fwd_f16.o", "fa_fwd_il.o", "fa_fwd_w64_bf16.o", "fa_fwd_w64_f16.o", "fa_bwd_dq.o", "fa_bwd_fused.o")]
     lib = os.path.join(HERE, "libfa_gfx950_experiments.so")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + reuse + [os.path.join(OUT, o) for _, o, _ in units])
     print("built", lib)
