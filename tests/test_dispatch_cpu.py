@@ -121,3 +121,40 @@ def test_backward_dq_schedule(lib, monkeypatch):
     monkeypatch.setenv("FA_BWD_DQ_NW", "64"); lib.fa_knobs_reload()
     assert dq(bp(4, 4096, 32, 96)) == 4                                 # trimmed head dims only have the 4-wave kernel, whatever the knob says
     assert dq(bp(4, 512, 8, 128)) == 64
+
+
+def test_fused_backward_workspace_and_conditions(lib, monkeypatch):
+    """FA_BWD_MODE=3 (opt-in, fa_api.cpp bwd_fused_ds_bytes): the workspace is the dS matrix of every (batch, head) in 2-KB sub-tiles plus the sync area
+    (fa_kernel_params.h fz_sync_words: 1344 words of control blocks, one 128-byte line per arrival counter, eight queues); calls it does not cover ask for
+    nothing, and so does every call without the knob."""
+    def bp(B, Sq, Sk, H, Hk, D, **kw):
+        a = _cabi.FaBwdParams()
+        a.b, a.h, a.h_k, a.d = B, H, Hk, D
+        a.seqlen_q, a.seqlen_k, a.total_q, a.total_k = Sq, Sk, B * Sq, B * Sk
+        a.dtype = 1
+        a.softmax_scale = D ** -0.5
+        a.window_left = a.window_right = -1
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return a
+    ws = lambda a: lib.fa_bwd_workspace_bytes(C.byref(a))
+    assert ws(bp(4, 4096, 4096, 32, 32, 128)) == 0                        # default: the scratch-free 7-contraction pair
+    monkeypatch.setenv("FA_BWD_MODE", "3"); lib.fa_knobs_reload()
+    try:
+        def expect(B, Sq, Sk, H):
+            ds = (B * H * ((Sq + 31) // 32) * ((Sk + 31) // 32) * 2048 + 255) & ~255
+            items = B * H * ((Sq + 255) // 256)
+            return ds + (1344 + items * 32 + 8 * items) * 4
+        assert ws(bp(4, 4096, 4096, 32, 32, 128)) == expect(4, 4096, 4096, 32)    # config 3: 4.3 GB
+        assert ws(bp(1, 256, 256, 2, 2, 128)) == expect(1, 256, 256, 2)
+        assert ws(bp(2, 1000, 1024, 32, 8, 64, is_causal=1)) == expect(2, 1000, 1024, 32)
+        assert ws(bp(1, 16384, 16384, 32, 32, 128)) == 0                    # 17 GB > FA_BWD_DS_CAP_MB (8192)
+        assert ws(bp(4, 4096, 4096, 32, 32, 256)) == 0                      # head dim
+        assert ws(bp(4, 4096, 4096, 32, 32, 128, window_left=1000)) == 0    # left window
+        assert ws(bp(4, 4096, 4096, 32, 32, 128, softcap=30.0)) == 0
+        assert ws(bp(4, 4096, 4096, 32, 32, 128, p_dropout=0.1)) == 0
+        assert ws(bp(4, 4096, 1024, 32, 32, 128, is_causal=1)) == 0          # sk < sq
+        monkeypatch.setenv("FA_BWD_DS_CAP_MB", "1024"); lib.fa_knobs_reload()
+        assert ws(bp(4, 4096, 4096, 32, 32, 128)) == 0 and ws(bp(16, 1024, 1024, 32, 32, 128)) == expect(16, 1024, 1024, 32)
+    finally:
+        monkeypatch.delenv("FA_BWD_MODE", raising=False); monkeypatch.delenv("FA_BWD_DS_CAP_MB", raising=False); lib.fa_knobs_reload()
