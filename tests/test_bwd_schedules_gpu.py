@@ -214,7 +214,7 @@ def test_fused_backward_declines_what_it_does_not_cover(be, knobs):
         wl, wr = kw.pop("wl", -1), kw.pop("wr", -1)
         f = run_bwd(be, q, k, v, do, False, wl, wr, **kw)
         assert f[3]["bwd_spill"] == 0, (kw, f[3])
-    f = run_bwd(be, q[:, :200], k, v, do[:, :200], True)                       # sk > sq is covered, sq > sk is not
+    f = run_bwd(be, q[:, :200].contiguous(), k, v, do[:, :200].contiguous(), True)   # sk > sq is covered, sq > sk is not
     assert f[3]["bwd_spill"] == 3
-    f = run_bwd(be, q, k[:, :200], v[:, :200], do, True)
+    f = run_bwd(be, q, k[:, :200].contiguous(), v[:, :200].contiguous(), do, True)
     assert f[3]["bwd_spill"] == 0
