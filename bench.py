@@ -6,7 +6,7 @@ Workload (BASELINE.json): config 3 -- B=4 H=32 S=4096 D=128 bf16 causal, synthet
 resident in HBM.  One "step" = one forward pass of the hot path (fa_fwd through the C ABI); the
 forward+backward rate on the same config, the reference's seqlen sweep (S = 512 .. 16k at D = 128 and D = 64, causal and not), BASELINE's
 configs 2 / 4 / 5 at their real shapes (`configs`) and the error table of the timed workload against PyTorch fp32 / bf16 / an fp64 sample
-(`parity`, default and FA_STRICT numerics) are reported as extra keys, `roofline.kernel` is what fa_last_schedule() says the C ABI launched, `roofline.traffic` comes from
+(`parity`, default and FA_STRICT numerics) and the opt-in fused backward next to the default one (`bwd_fused`, timed in a child process under a timeout) are reported as extra keys, `roofline.kernel` is what fa_last_schedule() says the C ABI launched, `roofline.traffic` comes from
 two rocprofv3 --pmc passes run from here (outside the timed region).  FLOP convention = the reference's (benchmarks/benchmark_flash_attention.py:
 27-30): fwd = 4*B*H*S^2*D (/2 causal), bwd = 2.5x, fwd+bwd = 3.5x.
 Timing: an untimed clock ramp (>= --preroll-ms of the same launch), W counted warm-up launches, then --windows regions of EXACTLY K
@@ -160,6 +160,52 @@ def sweep(be, dev, sync, D=128):
             rows.append({"seqlen": S, "batch": B, "causal": causal, "fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
                          "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name})
     return {"head_dim": D, "heads": H, "dtype": "bf16", "rows": rows}
+
+
+def fused_bwd_rows(be, dev, sync):
+    """Extra key `bwd_fused`: the opt-in fused 5-contraction backward (FA_BWD_MODE=3, fa_bwd.hip fa_bwd_fused_kernel; profiles/r04_bwd_fused.txt) next
+    to the default backward, timed alternately in this process: the headline shape and two shorter causal rows of the sweep.  Never fatal: a failure is
+    reported in the key; the knob is restored whatever happens."""
+    rows = []
+    try:
+        for (B, H, S, D, causal) in ((4, 32, 4096, 128, True), (8, 16, 2048, 128, True), (16, 16, 1024, 128, True)):
+            q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
+            k, v = torch.randn_like(q), torch.randn_like(q)
+            sc = D ** -0.5
+            o, l = be.fwd(q, k, v, None, None, 0.0, sc, causal, -1, -1, 0.0, False, None)[:2]
+            g = torch.randn_like(o)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            h = lambda: be.bwd(g, q, k, v, o, l, dq, dk, dv, None, 0.0, sc, causal, -1, -1, 0.0, False, None, None)
+            fl = 2.5 * fwd_flops(B, H, S, D, causal)
+            row = {"batch": B, "heads": H, "seqlen": S, "head_dim": D, "causal": causal}
+            for mode, key in (("0", "default"), ("3", "fused"), ("0", "default_again"), ("3", "fused_again")):
+                os.environ["FA_BWD_MODE"] = mode
+                be.reload_knobs()
+                _, mb = time_kernel(h, 8, 2, sync)
+                row[key + "_bwd_tflops"] = round(fl / mb / 1e9, 1)
+                if mode == "3":
+                    row["fused_launched"] = be.last_schedule().get("bwd_spill") == 3
+            row["workspace_gb"] = round(B * H * (S // 32) ** 2 * 2048 / 2 ** 30, 2)
+            rows.append(row)
+        return {"rows": rows, "note": "FA_BWD_MODE=3 is opt-in: O(S^2) dS workspace"}
+    except Exception as e:  # noqa: BLE001
+        return {"rows": rows, "error": repr(e)[:300]}
+    finally:
+        os.environ.pop("FA_BWD_MODE", None)
+        be.reload_knobs()
+
+
+def fused_bwd_probe(timeout=120):
+    """Runs fused_bwd_rows in a child process under a timeout: an opt-in path must not be able to take the contract line down with it."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--fused-probe"], capture_output=True, text=True, timeout=timeout)
+        for line in r.stdout.splitlines():
+            if line.startswith("FUSED_PROBE "):
+                return json.loads(line[len("FUSED_PROBE "):])
+        return {"rows": [], "error": "no result (exit code %d): %s" % (r.returncode, (r.stderr or "")[-200:])}
+    except Exception as e:  # noqa: BLE001  (TimeoutExpired included: subprocess.run has killed the child by then)
+        return {"rows": [], "error": repr(e)[:300]}
 
 
 def feature_rows(be, dev, sync, B, H, S, D):
@@ -402,6 +448,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-parity", action="store_true", help="skip the error table of the timed workload (extra key `parity`)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes behind roofline.traffic")
     ap.add_argument("--one-launch", action="store_true", help="(internal) a few forward launches of the workload, for the PMC passes")
+    ap.add_argument("--fused-probe", action="store_true", help="(internal) time the opt-in fused backward next to the default one and print the rows as JSON")
     ap.add_argument("--stub-workload", action="store_true",
                     help="(tests only) CPU + gloo run of the launcher / timing / aggregation code with a sleep in place of the kernel; the line says so")
     return ap.parse_args(argv)
@@ -436,6 +483,9 @@ def main(argv=None):
             for _ in range(3):
                 be.fwd(q, k, v, None, None, 0.0, scale, causal, -1, -1, 0.0, False, None)
             torch.cuda.synchronize(dev)
+            return
+        if a.fused_probe:
+            print("FUSED_PROBE " + json.dumps(fused_bwd_rows(be, dev, lambda: torch.cuda.synchronize(dev))), flush=True)
             return
         rank, world = dist_setup("nccl", dev)
         torch.manual_seed(rank)
@@ -516,6 +566,7 @@ def main(argv=None):
             res["sweep_d64"] = sweep(be, dev, dev_sync, 64)
             res["configs"] = config_rows(be, dev, dev_sync)
             res["features"] = feature_rows(be, dev, dev_sync, B, H, S, D)
+            res["bwd_fused"] = fused_bwd_probe()
         if world == 1 and not a.no_parity:
             res["parity"] = parity_report(be, dev, q, k, v, causal)
         if world == 1 and not a.no_cpu:
