@@ -199,9 +199,12 @@ def test_fused_backward_matches_default_and_fp32(be, knobs, dtype, shape, d):
     assert torch.equal(a[1], f[1]) and torch.equal(a[2], f[2])                    # dk, dv bit for bit
     assert all(torch.equal(x, y) for x, y in zip(f[:3], f2[:3]))                  # no atomics on data: run-to-run bitwise
     r = ref_grads(q, k, v, do, causal, -1, -1)
-    floor = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    # dQ: the same dS (rounded to the input dtype) contracted with K in another order -- within a few ulps of the default's dQ (measured over 76 shapes,
+    # profiles/r04_bwd_fused.txt: <= 1e-3 fp16, <= 4e-3 bf16 up to S = 2k) and as close to the fp32 reference as the default is
+    floor = 2e-2 if dtype == torch.bfloat16 else 4e-3
     e0, e3 = float((a[0].float() - r[0]).abs().max()), float((f[0].float() - r[0]).abs().max())
     assert torch.isfinite(f[0].float()).all() and e3 <= max(2 * e0, floor), (e3, e0)
+    assert float((a[0].float() - f[0].float()).abs().max()) <= floor * max(1.0, float(a[0].float().abs().max())), "dq against the default path"
 
 
 def test_fused_backward_declines_what_it_does_not_cover(be, knobs):
