@@ -199,7 +199,7 @@ def test_fused_backward_matches_default_and_fp32(be, knobs, dtype, shape, d):
     assert torch.equal(a[1], f[1]) and torch.equal(a[2], f[2])                    # dk, dv bit for bit
     assert all(torch.equal(x, y) for x, y in zip(f[:3], f2[:3]))                  # no atomics on data: run-to-run bitwise
     r = ref_grads(q, k, v, do, causal, -1, -1)
-    # dQ: the same dS (rounded to the input dtype) contracted with K in another order -- within a few ulps of the default's dQ (measured over 76 shapes,
+    # dQ: the same dS (rounded to the input dtype) contracted with K in another order -- within a few ulps of the default's dQ (measured over 80 cases,
     # profiles/r04_bwd_fused.txt: <= 1e-3 fp16, <= 4e-3 bf16 up to S = 2k) and as close to the fp32 reference as the default is
     floor = 2e-2 if dtype == torch.bfloat16 else 4e-3
     e0, e3 = float((a[0].float() - r[0]).abs().max()), float((f[0].float() - r[0]).abs().max())
