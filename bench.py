@@ -162,6 +162,30 @@ def sweep(be, dev, sync, D=128):
     return {"head_dim": D, "heads": H, "dtype": "bf16", "rows": rows}
 
 
+def compact_sweep(sw):
+    """Numbers-only form of a sweep for the contract line: TFLOP/s by seqlen, non-causal / causal."""
+    out = {"seqlen": sorted({r["seqlen"] for r in sw["rows"]}), "heads": sw["heads"]}
+    for causal, tag in ((False, "noncausal"), (True, "causal")):
+        rows = sorted((r for r in sw["rows"] if r["causal"] == causal), key=lambda r: r["seqlen"])
+        out["fwd_" + tag] = [r["fwd_tflops"] for r in rows]
+        out["bwd_" + tag] = [r["bwd_tflops"] for r in rows]
+        out["fwd_bwd_" + tag] = [r["fwd_bwd_tflops"] for r in rows]
+    return out
+
+
+def write_extras(obj):
+    """Full tables (sweeps with kernel names, configs, parity, fused-backward probe) -> gpurun_out/bench_extras.json; returns the path or the reason."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "bench_extras.json")
+        with open(path, "w") as f:
+            json.dump(obj, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as e:
+        return f"not written: {e}"
+
+
 def fused_bwd_rows(be, dev, sync):
     """Extra key `bwd_fused`: the opt-in fused 5-contraction backward (FA_BWD_MODE=3, fa_bwd.hip fa_bwd_fused_kernel; profiles/r04_bwd_fused.txt) next
     to the default backward, timed alternately in this process: the headline shape and two shorter causal rows of the sweep.  Never fatal: a failure is
@@ -561,16 +585,33 @@ def main(argv=None):
             nbytes, detail = measure_traffic(sched["name"].split("::")[-1].split("<")[0])
             res["roofline"]["traffic"] = nbytes
             res["roofline"]["traffic_detail"] = detail
+        # Everything beyond the contract keys goes to a side file (round 4's 13.7 KB line was cut by the driver's tail); the line keeps a compact
+        # summary of it (numbers only) and the file's path.
+        extras = {}
         if world == 1 and not a.no_sweep:
-            res["sweep"] = sweep(be, dev, dev_sync)
-            res["sweep_d64"] = sweep(be, dev, dev_sync, 64)
-            res["configs"] = config_rows(be, dev, dev_sync)
-            res["features"] = feature_rows(be, dev, dev_sync, B, H, S, D)
-            res["bwd_fused"] = fused_bwd_probe()
+            extras["sweep"] = sweep(be, dev, dev_sync)
+            extras["sweep_d64"] = sweep(be, dev, dev_sync, 64)
+            extras["configs"] = config_rows(be, dev, dev_sync)
+            extras["features"] = feature_rows(be, dev, dev_sync, B, H, S, D)
+            extras["bwd_fused"] = fused_bwd_probe()
+            res["sweep_d128"] = compact_sweep(extras["sweep"])
+            res["sweep_d64"] = compact_sweep(extras["sweep_d64"])
+            res["configs"] = {r["config"].split(":")[0]: ([r.get("fwd_tflops"), r.get("bwd_tflops"), r.get("fwd_bwd_tflops")] if "error" not in r else "error")
+                              for r in extras["configs"]}
+            res["configs"]["columns"] = "fwd, bwd, fwd+bwd TFLOP/s on the visible pairs"
+            ca = extras["features"].get("causal_alibi")
+            if ca:
+                res["causal_alibi"] = [ca["fwd_tflops"], ca["bwd_tflops"], ca["fwd_bwd_tflops"]]
         if world == 1 and not a.no_parity:
-            res["parity"] = parity_report(be, dev, q, k, v, causal)
+            extras["parity"] = parity_report(be, dev, q, k, v, causal)
+            t = extras["parity"].get("tensors")
+            if t:
+                res["parity_max_abs_err"] = {nm: [round(t[nm][c]["max"], 6) for c in ("default", "strict", "pytorch_bf16")] for nm in t}
+                res["parity_max_abs_err"]["columns"] = "default, FA_STRICT, PyTorch bf16 -- against PyTorch fp32, all 128 units"
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(D, S, causal)
+        if extras:
+            res["extras_file"] = write_extras(dict(res, **extras))
         print(json.dumps(res), flush=True)
     if dist_on:
         dist.barrier()

@@ -379,14 +379,18 @@ int bwd_dq_schedule(const FaBwdParams* a) {
   return (a->d == 128 && plain && a->seqlen_k >= 2048 && a->seqlen_q >= 512) ? 64 : 4;
 }
 
-// dK/dV schedule (fa_launch.h Knobs::bwd_dkdv)
+// dK/dV schedule (fa_launch.h Knobs::bwd_dkdv): 64 = four waves x 64 keys (fa_bwd_dkdv_w64.hip; plain attention at head dim 64 / 128), 8 = eight waves x 32 keys
+// (fa_bwd.hip: every feature variant, head dim 256, trimmed head dims).  The choice does not depend on the sequence lengths, so a packed batch and its
+// sequences run one by one take the same kernel (tests: varlen == per-sequence, bit for bit).
 #ifndef FA_EXPERIMENTS
-#define FA_EXPERIMENTS 0   // experiments/build_experiments.py: the 64-keys-per-wave dK/dV kernel (FA_BWD_DKDV=64) and the dS-spill backward (FA_BWD_MODE=2),
-#endif                     // both measured and not faster (profiles/r02_bwd_schedules.txt); their sources live under experiments/, outside the product tree
+#define FA_EXPERIMENTS 0   // experiments/build_experiments.py: the dS-spill backward (FA_BWD_MODE=2), measured and not faster (profiles/r02_bwd_5_vs_7_contractions.txt)
+#endif
 int bwd_dkdv_schedule(const FaBwdParams* a) {
+  const bool plain = a->softcap <= 0.f && !a->alibi_slopes && a->p_dropout <= 0.f;
+  if (!plain || !head_dim_native(a->d) || head_dim_trimmed(head_dim_kernel(a->d)) || (a->d != 128 && a->d != 64)) return 8;
   const int knob = fa::knobs().bwd_dkdv;
-  if (FA_EXPERIMENTS && (knob == 8 || knob == 64)) return knob;
-  return 8;
+  if (knob == 8 || knob == 64) return knob;
+  return a->d == 128 ? 64 : 8;
 }
 
 int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
@@ -465,6 +469,15 @@ int64_t bwd_fused_sync_bytes(const FaBwdParams* a) {
   return fa::fz_sync_words((int64_t)a->b * a->h * ((a->seqlen_q + 255) / 256), fa::knobs().fz_line) * 4;
 }
 
+// the dK/dV launch of either schedule (-2 from the 64-keys-per-wave launcher = not covered after all: nothing was enqueued)
+int launch_dkdv_any(const FaBwdParams* a, const fa::BwdK& k, int bf, int dk_, hipStream_t s) {
+  int rc = -2, nw = 64;
+  if (!k.ds_ws && bwd_dkdv_schedule(a) == 64) rc = fa::launch_bwd_dkdv_w64(k, bf, a->d, s);
+  if (rc == -2) { nw = a->d > 128 ? 4 : 8; rc = fa::launch_bwd_dkdv(k, bf, dk_, s); }
+  fa::last_schedule().bwd_dkdv_nw = nw;
+  return rc;
+}
+
 int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   fa::BwdK k;
   if (int rc = fill_bwd(a, varlen, k)) return rc;
@@ -535,8 +548,7 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
     int rc = fa::launch_bwd_dq_w64(k, bf, a->d, s);
     if (rc == 0) {
       fa::last_schedule().bwd_dq_nw = 64;
-      rc = fa::launch_bwd_dkdv(k, bf, dk_, s);
-      fa::last_schedule().bwd_dkdv_nw = a->d > 128 ? 4 : 8;
+      rc = launch_dkdv_any(a, k, bf, dk_, s);
       fa::last_schedule().bwd_spill = 0; fa::last_schedule().bwd_list = (k.q_list != nullptr) + 2 * (k.k_list != nullptr);
       if (rc != 0) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
       return FA_OK;
@@ -546,14 +558,7 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   }
   int rc = fa::launch_bwd_delta(k, bf, dk_, s);
   if (rc == 0) {
-    int dkdv_nw = 64;
-#if FA_EXPERIMENTS
-    rc = bwd_dkdv_schedule(a) == 64 ? fa::launch_bwd_dkdv_w64(k, bf, a->d, s) : -2;
-#else
-    rc = -2;
-#endif
-    if (rc == -2) { dkdv_nw = a->d > 128 ? 4 : 8; rc = fa::launch_bwd_dkdv(k, bf, dk_, s); }
-    fa::last_schedule().bwd_dkdv_nw = dkdv_nw;
+    rc = launch_dkdv_any(a, k, bf, dk_, s);
   }
   if (rc == 0) rc = k.ds_ws ? fa::launch_bwd_dq_ds(k, bf, a->d, s) : fa::launch_bwd_dq(k, bf, dk_, s);
   if (rc == 0) { fa::last_schedule().bwd_spill = k.ds_ws != nullptr; fa::last_schedule().bwd_list = (k.q_list != nullptr) + 2 * (k.k_list != nullptr); }
