@@ -380,8 +380,9 @@ int bwd_dq_schedule(const FaBwdParams* a) {
 }
 
 // dK/dV schedule (fa_launch.h Knobs::bwd_dkdv): 64 = four waves x 64 keys (fa_bwd_dkdv_w64.hip; plain attention at head dim 64 / 128), 8 = eight waves x 32 keys
-// (fa_bwd.hip: every feature variant, head dim 256, trimmed head dims).  The choice does not depend on the sequence lengths, so a packed batch and its
-// sequences run one by one take the same kernel (tests: varlen == per-sequence, bit for bit).
+// (fa_bwd.hip: every feature variant, head dim 256, trimmed head dims).  Measured (profiles/r05_bwd_dkdv_w64.txt): at head dim 128 the 64-keys-per-wave kernel
+// wins from 2k query rows per key block (+1 % at S = 2048, +3 .. +6 % on the whole backward from S = 4096, GQA included) and loses below (its pipeline fill /
+// drain and 160 KB of LDS per workgroup cost more than they save on a short walk); at head dim 64 it ties or loses everywhere.
 #ifndef FA_EXPERIMENTS
 #define FA_EXPERIMENTS 0   // experiments/build_experiments.py: the dS-spill backward (FA_BWD_MODE=2), measured and not faster (profiles/r02_bwd_5_vs_7_contractions.txt)
 #endif
@@ -390,7 +391,8 @@ int bwd_dkdv_schedule(const FaBwdParams* a) {
   if (!plain || !head_dim_native(a->d) || head_dim_trimmed(head_dim_kernel(a->d)) || (a->d != 128 && a->d != 64)) return 8;
   const int knob = fa::knobs().bwd_dkdv;
   if (knob == 8 || knob == 64) return knob;
-  return a->d == 128 ? 64 : 8;
+  if (fa::knobs().dkdv_prescale) return 8;   // (FA_DKDV_PRESCALE=1 names a variant of the eight-wave kernel)
+  return (a->d == 128 && a->seqlen_q >= 2048) ? 64 : 8;
 }
 
 int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {

@@ -32,6 +32,9 @@
 #define FA_DKDV64_AHT 2     // phase B: transposed-fragment reads run this many fragments (two gaps each) ahead
 #endif
 
+#ifndef FA_DKDV64_WAIT2
+#define FA_DKDV64_WAIT2 0   // 1: one explicit LDS wait per k-step (phase A) / per two fragments (phase B) instead of hipcc's one per MFMA
+#endif
 #ifndef FA_DKDV64_ABL
 #define FA_DKDV64_ABL 0     // timing ablations, bit mask (results become wrong; tools/ablate_dkdv64.sh): 1 no softmax arithmetic, 2 phase A's LDS operands read only for the
 #endif                      // first k-step, 4 phase B's transposed operands read only for the first block, 8 no DMA wait / barrier per step, 16 no tile DMA after the prologue,
@@ -350,6 +353,11 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     static_for<4 * KS>([&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value, ks = g >> 2, kind = g & 3;
       if constexpr (g + AHJ < 4 * KS && !((FA_DKDV64_ABL & 2) && g + AHJ >= 4)) rd_a(ICw<g + AHJ>{}, qa, kva);
+#if FA_DKDV64_WAIT2
+      // one wait per k-step: its four fragments (and key block 1's LDS-resident K fragment, requested between them) have landed; the AHJ - 3 fragments
+      // requested behind them may stay in flight.  hipcc models the explicit wait and drops its own in front of the k-step's other three MFMAs.
+      if constexpr (kind == 0 && ks >= 1 && AHJ >= 3) __builtin_amdgcn_s_waitcnt(0xC07F | ((g + AHJ < 4 * KS ? AHJ - 3 : (4 * KS - 4 - g > 0 ? 4 * KS - 4 - g : 0)) << 8));
+#endif
       // k-step 0: key block 1's chain goes FIRST and takes key block 0's preloaded tuple as its C operand (one copy of -LSE/scale and -delta is loaded per step,
       // not two); block 0's chain then accumulates onto it in place.  The matrix pipe is in order: the second MFMA's write follows the first one's read.
       if constexpr (kind == 0) {
@@ -461,6 +469,13 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
         constexpr int x = decltype(xc)::value, F = x >> 1, kb = x & 1;
         constexpr int db = F >> 2, t = (F >> 1) & 1, src = F & 1;
         if constexpr (kb == 0 && F + AHT < NFB && !((FA_DKDV64_ABL & 4) && F + AHT >= 4)) rd_t(ICw<F + AHT>{}, t0p, t1p);
+#if FA_DKDV64_WAIT2
+        if constexpr (kb == 0 && (F & 1) == 0 && AHT >= 2) {   // fragments F and F + 1 have landed; the ones behind them (two transpose reads each) may stay in flight
+          constexpr int last = F + AHT < NFB ? F + AHT : NFB - 1;
+          constexpr int out = last - (F + 1) > 0 ? 2 * (last - (F + 1)) : 0;
+          __builtin_amdgcn_s_waitcnt(0xC07F | (out << 8));
+        }
+#endif
         if constexpr (src == 0) kv_mfma_tile<E, kb * DB + db>(ring[F % NT], pr[kb][t]);
         else kv_mfma_tile<E, 2 * DB + kb * DB + db>(ring[F % NT], dr[kb][t]);
         if constexpr (DO_SM && !(FA_DKDV64_ABL & 1)) {

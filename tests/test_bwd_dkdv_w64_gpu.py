@@ -1,0 +1,93 @@
+"""The 64-keys-per-wave dK/dV kernel (csrc/fa_bwd_dkdv_w64.hip; reference: the dK/dV half of compute_dq_dk_dv_1colblock, csrc/flash_attn/src/flash_bwd_kernel.h:457-733),
+the default at head dim 128 from 2k query rows: pinned with FA_BWD_DKDV=64 on every shape below and compared with
+  * an fp32 PyTorch reference (the reference suite's rule: error <= 2x the error of the established eight-wave kernel, floors 1e-2 bf16 / 2e-3 fp16),
+  * itself, run twice (bitwise: no atomics, fixed accumulation order),
+  * the same batch packed (varlen, key-block work list) against its sequences one by one (bitwise: the kernel's walk depends on the sequence alone).
+dQ does not come from this kernel; it is checked to be untouched by the knob (bitwise equal)."""
+import itertools
+
+import pytest
+import torch
+
+from tests.test_bwd_schedules_gpu import ref_grads, run_bwd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from flash_attn_amd import backend
+    return backend
+
+
+SHAPES = [  # B, Sq, Sk, H, Hk, causal, wl, wr
+    (2, 512, 512, 4, 4, True, -1, -1), (1, 1024, 1024, 4, 2, False, -1, -1), (2, 333, 777, 6, 2, True, -1, -1), (1, 2048, 2048, 8, 2, True, 256, 0),
+    (2, 200, 200, 2, 2, False, 64, 32), (1, 777, 333, 4, 4, True, -1, -1), (3, 65, 513, 2, 1, False, -1, -1), (1, 4096, 4096, 2, 2, True, -1, -1),
+    (1, 31, 31, 1, 1, True, -1, -1), (1, 1, 700, 2, 2, False, -1, -1), (1, 700, 1, 2, 1, True, -1, -1), (1, 2049, 2049, 2, 1, False, -1, 0),
+    (1, 640, 640, 1, 1, False, 300, -1), (1, 3000, 3000, 2, 2, True, 1024, 0),
+]
+
+
+@pytest.mark.parametrize("d", [128, 64])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "B%d_Sq%d_Sk%d_H%d_%d_c%d_w%d_%d" % s)
+def test_dkdv_w64_against_fp32_and_the_eight_wave_kernel(be, knobs, shape, dtype, d):
+    B, Sq, Sk, H, Hk, causal, wl, wr = shape
+    torch.manual_seed(0)
+    q = torch.randn(B, Sq, H, d, device="cuda", dtype=dtype)
+    k = torch.randn(B, Sk, Hk, d, device="cuda", dtype=dtype)
+    v, do = torch.randn_like(k), torch.randn_like(q)
+    knobs.set("FA_BWD_DKDV", 8)
+    g8 = run_bwd(be, q, k, v, do, causal, wl, wr)
+    assert g8[3]["bwd_dkdv_nw"] == 8
+    knobs.set("FA_BWD_DKDV", 64)
+    g64 = run_bwd(be, q, k, v, do, causal, wl, wr)
+    again = run_bwd(be, q, k, v, do, causal, wl, wr)
+    assert g64[3]["bwd_dkdv_nw"] == 64, g64[3]
+    assert all(torch.equal(a, b) for a, b in zip(g64[:3], again[:3])), "run-to-run"
+    assert torch.equal(g8[0], g64[0]), "dq is not this kernel's"
+    r = ref_grads(q, k, v, do, causal, wl, wr)
+    floor = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    for i in (1, 2):
+        assert torch.isfinite(g64[i].float()).all()
+        e8, e64 = float((g8[i].float() - r[i]).abs().max()), float((g64[i].float() - r[i]).abs().max())
+        assert e64 <= max(2 * e8, floor), (i, e64, e8)
+
+
+def test_default_picks_it_from_2k_query_rows_at_head_dim_128(be):
+    for (S, d, want) in ((4096, 128, 64), (2048, 128, 64), (1024, 128, 8), (4096, 64, 8)):
+        q = torch.randn(1, S, 2, d, device="cuda", dtype=torch.bfloat16)
+        k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
+        assert run_bwd(be, q, k, v, do, True)[3]["bwd_dkdv_nw"] == want, (S, d)
+    q = torch.randn(1, 4096, 2, 128, device="cuda", dtype=torch.bfloat16)
+    k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
+    assert run_bwd(be, q, k, v, do, True, softcap=20.0)[3]["bwd_dkdv_nw"] == 8   # feature variants stay on the eight-wave kernel
+
+
+@pytest.mark.parametrize("d", [128, 64])
+@pytest.mark.parametrize("causal", [False, True])
+def test_packed_batch_equals_its_sequences_bit_for_bit(be, knobs, d, causal):
+    knobs.set("FA_BWD_DKDV", 64)
+    knobs.set("FA_FWD_NW", "34")   # pin the forward schedule: out / LSE feed the backward
+    torch.manual_seed(3)
+    lens_q = [700, 33, 1500, 256, 64, 1, 900, 257, 0, 300]
+    lens_k = [700, 65, 1500, 300, 64, 77, 513, 257, 5, 1]
+    H, Hk = 4, 2
+    cu_q = torch.tensor([0] + list(itertools.accumulate(lens_q)), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0] + list(itertools.accumulate(lens_k)), dtype=torch.int32, device="cuda")
+    q = torch.randn(sum(lens_q), H, d, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(sum(lens_k), Hk, d, device="cuda", dtype=torch.bfloat16)
+    v, do = torch.randn_like(k), torch.randn_like(q)
+    sc = d ** -0.5
+    out, lse = be.varlen_fwd(q, k, v, None, cu_q, cu_k, None, None, None, None, max(lens_q), max(lens_k), 0.0, sc, False, causal, -1, -1, 0.0, False, None)[:2]
+    dq, dk, dv = be.varlen_bwd(do, q, k, v, out, lse, None, None, None, cu_q, cu_k, None, max(lens_q), max(lens_k), 0.0, sc, False, causal, -1, -1, 0.0, False,
+                               None, None)[:3]
+    assert be.last_schedule()["bwd_dkdv_nw"] == 64
+    for b in range(len(lens_q)):
+        a0, a1, b0, b1 = int(cu_q[b]), int(cu_q[b + 1]), int(cu_k[b]), int(cu_k[b + 1])
+        if a1 == a0:
+            assert torch.all(dk[b0:b1] == 0) and torch.all(dv[b0:b1] == 0)
+            continue
+        o1, l1 = be.fwd(q[None, a0:a1], k[None, b0:b1], v[None, b0:b1], None, None, 0.0, sc, causal, -1, -1, 0.0, False, None)[:2]
+        g = be.bwd(do[None, a0:a1], q[None, a0:a1], k[None, b0:b1], v[None, b0:b1], o1, l1, None, None, None, None, 0.0, sc, causal, -1, -1, 0.0, False, None, None)
+        assert torch.equal(dk[b0:b1], g[1][0]) and torch.equal(dv[b0:b1], g[2][0]), b

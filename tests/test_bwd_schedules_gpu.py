@@ -191,6 +191,7 @@ def test_fused_backward_matches_default_and_fp32(be, knobs, dtype, shape, d):
     v = torch.randn_like(k)
     do = torch.randn_like(q)
     knobs.set("FA_BWD_FUSE_DELTA", 0)   # softmax_d from the pre-pass on both sides: dK / dV come from the same arithmetic on the same inputs
+    knobs.set("FA_BWD_DKDV", 8)         # ... and from the same eight-wave dK/dV body (round 5: long sequences default to the 64-keys-per-wave kernel)
     a = run_bwd(be, q, k, v, do, causal)
     knobs.set("FA_BWD_MODE", 3)
     f = run_bwd(be, q, k, v, do, causal)
