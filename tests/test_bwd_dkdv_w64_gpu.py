@@ -68,7 +68,7 @@ def test_default_picks_it_from_2k_query_rows_at_head_dim_128(be):
 @pytest.mark.parametrize("causal", [False, True])
 def test_packed_batch_equals_its_sequences_bit_for_bit(be, knobs, d, causal):
     knobs.set("FA_BWD_DKDV", 64)
-    knobs.set("FA_FWD_NW", "34")   # pin the forward schedule: out / LSE feed the backward
+    knobs.set("FA_BWD_DQ_NW", 4)   # (softmax_d comes from the same pre-pass on both sides)
     torch.manual_seed(3)
     lens_q = [700, 33, 1500, 256, 64, 1, 900, 257, 0, 300]
     lens_k = [700, 65, 1500, 300, 64, 77, 513, 257, 5, 1]
@@ -88,6 +88,7 @@ def test_packed_batch_equals_its_sequences_bit_for_bit(be, knobs, d, causal):
         if a1 == a0:
             assert torch.all(dk[b0:b1] == 0) and torch.all(dv[b0:b1] == 0)
             continue
-        o1, l1 = be.fwd(q[None, a0:a1], k[None, b0:b1], v[None, b0:b1], None, None, 0.0, sc, causal, -1, -1, 0.0, False, None)[:2]
+        # (the packed forward's own rows: for very short sequences the fixed-length forward may take another schedule -- head packing -- and round differently)
+        o1, l1 = out[None, a0:a1].contiguous(), lse[None, :, a0:a1].contiguous()
         g = be.bwd(do[None, a0:a1], q[None, a0:a1], k[None, b0:b1], v[None, b0:b1], o1, l1, None, None, None, None, 0.0, sc, causal, -1, -1, 0.0, False, None, None)
         assert torch.equal(dk[b0:b1], g[1][0]) and torch.equal(dv[b0:b1], g[2][0]), b
