@@ -372,8 +372,11 @@ int bwd_dq_schedule(const FaBwdParams* a) {
   if (a->d == 64) {
     // round 4 (profiles/r04_bwd_schedules.txt): at head dim 64 the 64-rows-per-wave kernel wins from ~2k visible keys per query row ON AVERAGE -- non-causal
     // S >= 2048 (+5.5 .. +7.5 % on the whole backward), causal S >= 8192 (+5.6 .. +7.4 %); it ties at causal S = 4096 and loses below
+    // mean visible keys per query row: bottom-right aligned, row i sees keys up to i + (sk - sq) + window_right
     const bool right_bounded = a->is_causal || a->window_right >= 0;
-    const long avg_keys = right_bounded ? a->seqlen_k / 2 : a->seqlen_k;
+    const long wr = a->is_causal ? 0 : a->window_right;
+    long avg_keys = a->seqlen_k;
+    if (right_bounded) { avg_keys = (long)a->seqlen_k - a->seqlen_q / 2 + wr; if (avg_keys > a->seqlen_k) avg_keys = a->seqlen_k; if (avg_keys < 0) avg_keys = 0; }
     return (plain && a->window_left < 0 && a->seqlen_q >= 512 && avg_keys >= 2048) ? 64 : 4;
   }
   return (a->d == 128 && plain && a->seqlen_k >= 2048 && a->seqlen_q >= 512) ? 64 : 4;
@@ -684,6 +687,17 @@ int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {
   return (qe ? (qe + 1) * 8 : 0) + (ke ? (ke + 1) * 8 : 0) + bwd_ds_bytes(params);   // (work lists: varlen only; dS: fixed-length only)
 }
 int fa_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, false); }
+int fa_bwd_fused_status(const FaBwdParams* params, void* stream) {
+  if (!params || !params->workspace || fa::last_schedule().bwd_spill != 3) return FA_OK;   // (this thread's last backward did not take the fused path: the sync area was never initialised)
+  const int64_t fz = bwd_fused_ds_bytes(params);
+  if (fz <= 0 || params->workspace_bytes < fz + bwd_fused_sync_bytes(params)) return FA_OK;   // the call did not (could not) take the fused path
+  int32_t flag = 0;
+  if (hipMemcpyAsync(&flag, (const char*)params->workspace + fz + fa::FZ_ERR * 4, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return fail(FA_ERR_LAUNCH, "fused backward: could not read the launch's error flag: %s", hipGetErrorString(hipGetLastError()));
+  if (flag != 0) return fail(FA_ERR_LAUNCH, "fused backward (FA_BWD_MODE=3): a dQ hand-off timed out, a block of dq was not written -- discard this call's gradients");
+  return FA_OK;
+}
 int fa_varlen_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, true); }
 
 }  // extern "C"

@@ -188,7 +188,7 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; dk_boff = 0; dv_boff = 0; }
   if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
-  if (p.seqused_k) sk = min(p.seqused_k[b], p.sk);   // overrides the cu_seqlens_k length, as in the forward (block_info.h:17-36), clamped to max_seqlen_k
+  if (p.seqused_k) sk = min(p.seqused_k[b], sk);   // (include/fa_gfx950.h: in the backward seqused_k can only SHORTEN a sequence -- the key-block work list and its bound are sized from cu_seqlens_k)
   const int n0 = n_block * BNK;
   if (n0 >= sk) return;
   const int n1 = min(n0 + BNK, sk);
@@ -778,7 +778,8 @@ static __device__ __forceinline__ void fa_bwd_dq_from_ds(const BwdK& p, char FA_
 // value another XCD has long replaced, and with up to 256 workgroups finishing together the compare-exchange took 60-140 retries per item.)  A workgroup
 // whose decrement finds nothing gives it back; if the word is positive after giving back (a publication slipped in between), it tries again -- so of the
 // workgroups that fail around a publication the last one to give back always sees it, and nothing is left behind.  Every loop is bounded: a claimed slot
-// whose content does not appear (its publisher is between its two atomics) is polled with read-modify-writes; the error flag instead of a hang.
+// whose content does not appear (its publisher is between its two atomics) is polled with read-modify-writes; on a time-out the launch's error flag is set and the
+// binders raise after the call (fa_bwd_fused_status, include/fa_gfx950.h): the block of dq it stood for was not written.
 static __device__ __forceinline__ int fz_pop(int32_t* z, int32_t* ctrl, int32_t* slots, int (&st)[4]) {
   for (int spin = 0; spin < (1 << 12); ++spin) {
     if (__hip_atomic_fetch_add(ctrl + FZ_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
@@ -970,7 +971,7 @@ __global__ void __launch_bounds__(NW * 64, D > 128 ? 1 : 2) fa_bwd_dq_kernel(con
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; dq_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
   if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
-  if (p.seqused_k) sk = min(p.seqused_k[b], p.sk);   // overrides the cu_seqlens_k length, as in the forward (block_info.h:17-36), clamped to max_seqlen_k
+  if (p.seqused_k) sk = min(p.seqused_k[b], sk);   // (include/fa_gfx950.h: in the backward seqused_k can only SHORTEN a sequence -- the key-block work list and its bound are sized from cu_seqlens_k)
   const int m0 = m_block * BM;
   if (m0 >= sq) return;
 

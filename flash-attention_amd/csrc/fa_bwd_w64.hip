@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; q_row0 = c0; q_boff = 0; do_boff = 0; dq_boff = 0; }
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
   if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
-  if (p.seqused_k) sk = min(p.seqused_k[b], p.sk);   // overrides the cu_seqlens_k length, as in the forward (block_info.h:17-36), clamped to max_seqlen_k
+  if (p.seqused_k) sk = min(p.seqused_k[b], sk);   // (include/fa_gfx950.h: in the backward seqused_k can only SHORTEN a sequence -- the key-block work list and its bound are sized from cu_seqlens_k)
   const int m0 = m_block * BM;
   if (m0 >= sq) return;
 

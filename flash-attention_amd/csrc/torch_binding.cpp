@@ -312,6 +312,7 @@ void run_bwd(FaBwdParams& a, const Tensor& q, bool varlen) {
     a.workspace_bytes = ws;
   }
   fa_check(varlen ? fa_varlen_bwd(&a, cur_stream(q)) : fa_bwd(&a, cur_stream(q)));
+  if (ws > 0 && !varlen) fa_check(fa_bwd_fused_status(&a, cur_stream(q)));   // (FA_OK at once unless the opt-in fused backward ran: fa_gfx950.h)
 }
 
 void fill_bwd_ptrs(FaBwdParams& a, const BwdBufs& t, const Tensor& lse, Tensor& delta) {

@@ -88,7 +88,7 @@ EXPORTS = (
     "fa_abi_version", "fa_sizeof_fwd_params", "fa_sizeof_bwd_params", "fa_sizeof_kvappend_params", "fa_sizeof_rotary_params",
     "fa_last_error", "fa_rotary", "fa_knobs_reload", "fa_last_schedule", "fa_last_kernel_name", "fa_fwd_schedule_query", "fa_bwd_dq_schedule_query",
     "fa_fwd", "fa_varlen_fwd", "fa_fwd_kvcache", "fa_kvcache_append", "fa_set_rng_state", "fa_fwd_workspace_bytes",
-    "fa_bwd_workspace_bytes", "fa_bwd", "fa_varlen_bwd",
+    "fa_bwd_workspace_bytes", "fa_bwd", "fa_varlen_bwd", "fa_bwd_fused_status",
 )
 
 _LIB = None
@@ -144,6 +144,8 @@ def load():
     lib.fa_set_rng_state.restype = C.c_int
     lib.fa_fwd_workspace_bytes.argtypes = [C.POINTER(FaFwdParams)]
     lib.fa_fwd_workspace_bytes.restype = C.c_int64
+    lib.fa_bwd_fused_status.argtypes = [C.POINTER(FaBwdParams), C.c_void_p]
+    lib.fa_bwd_fused_status.restype = C.c_int
     lib.fa_bwd_workspace_bytes.argtypes = [C.POINTER(FaBwdParams)]
     lib.fa_bwd_workspace_bytes.restype = C.c_int64
     if lib.fa_abi_version() != FA_ABI_VERSION:

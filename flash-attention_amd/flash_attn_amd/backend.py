@@ -328,6 +328,8 @@ def _run_bwd(a, device, varlen):
     with torch.cuda.device(device):
         fn = lib.fa_varlen_bwd if varlen else lib.fa_bwd
         _cabi.check(fn(C.byref(a), C.c_void_p(_stream_ptr(device))))
+        if ws is not None and not varlen and last_schedule().get("bwd_spill") == 3:   # the opt-in fused backward: its hand-offs can time out (fa_gfx950.h)
+            _cabi.check(lib.fa_bwd_fused_status(C.byref(a), C.c_void_p(_stream_ptr(device))))
     return ws
 
 

@@ -146,7 +146,8 @@ def _padded_fwd_impl(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqle
 def _padded_fwd_fake(q, k, v, cu_seqlens_q, seqused_q, cu_seqlens_k, seqused_k, max_seqlen_q, max_seqlen_k, dropout_p, softmax_scale,
                      causal, window_size_left, window_size_right, softcap, alibi_slopes):
     total_q, H, _ = q.shape
-    return (torch.empty_like(q), torch.empty((H, total_q), dtype=torch.float32, device=q.device),
+    # (contiguous like the real op's freshly allocated output, whatever the strides of q: q may be a view of a packed qkv)
+    return (torch.empty(q.shape, dtype=q.dtype, device=q.device), torch.empty((H, total_q), dtype=torch.float32, device=q.device),
             torch.empty((2,), dtype=torch.int64, device=q.device))
 
 
@@ -324,7 +325,7 @@ class _PaddedAttnFn(torch.autograd.Function):
         Sq, Sk, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic, d_orig, q_shape, k_shape = ctx.cfg
         (dout_p,) = _pad_head_dim(dout) if dout.shape[-1] % 8 else (dout,)
         dof = dout_p.contiguous().reshape(-1, dout_p.shape[2], dout_p.shape[3])
-        dq, dk, dv = torch.empty_like(qf), torch.empty_like(kf), torch.empty_like(vf)   # (zero_tensors: the kernels' launcher clears them first)
+        dq, dk, dv = (torch.empty(t.shape, dtype=t.dtype, device=t.device) for t in (qf, kf, vf))   # contiguous whatever qf's strides (zero_tensors: the launcher clears them first)
         _flash_attn_padded_backward(dof, qf, kf, vf, out, lse, dq, dk, dv, cu_q, len_q, cu_k, len_k, Sq, Sk, dropout_p, softmax_scale, causal,
                                     window_size[0], window_size[1], softcap, alibi_slopes, deterministic, rng_state)
         return (dq.reshape(q_shape)[..., :d_orig], dk.reshape(k_shape)[..., :d_orig], dv.reshape(k_shape)[..., :d_orig]) + (None,) * 11
@@ -342,7 +343,10 @@ def flash_attn_padded_func(q, k, v, seqlens_q, seqlens_k=None, starts_q=None, st
     Sk = k.shape[1]
 
     if B == 0 or Sq == 0 or Sk == 0:   # nothing to attend: the padded output (and, through autograd, the gradients) are zeros
-        return (q * 0.0) + (k.sum() + v.sum()) * 0.0 if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v)) else torch.zeros_like(q)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v)):
+            # zeros attached to the graph of all three (zero gradients); built from EMPTY slices, so no NaN / Inf of the inputs can leak into them
+            return torch.zeros_like(q) + (q[:0].sum() + k[:0].sum() + v[:0].sum())
+        return torch.zeros_like(q)
 
     def _args(S, lens, starts):
         # clamped on the device, no host synchronisation: a run may not leave its entry (starts[b] + seqlens[b] <= S), or the kernels would read the

@@ -189,9 +189,11 @@ typedef struct FaBwdParams {
   int32_t reserved[3];
   const uint64_t* rng_state;    /* device {seed, offset} the forward used (p_dropout > 0) */
   const int32_t* seqused_q;     /* ABI v6, optional (B): as FaFwdParams::seqused_q; dq rows past it are not written */
-  const int32_t* seqused_k;     /* ABI v6, optional (B): keys of entry b in use -- the SAME rule as the forward's seqused_k: it replaces the
-                                   cu_seqlens_k length of the entry (clamped to seqlen_k = max_seqlen_k), so a forward / backward pair given the
-                                   same arrays attends to and differentiates the same keys; dk / dv rows past it are not written */
+  const int32_t* seqused_k;     /* ABI v6, optional (B): keys of entry b in use.  In the backward it can only SHORTEN an entry: the length is
+                                   min(seqused_k[b], the cu_seqlens_k length) (fixed-length: min(seqused_k[b], seqlen_k)) -- the key-block work
+                                   list is sized from cu_seqlens_k, so a longer value could not be honoured by every kernel (round 5; the forward's
+                                   seqused_k REPLACES the length, for KV caches).  A forward / backward pair of a padded batch (seqused <= the slot
+                                   length, what flash_attn_padded_func passes) sees the same keys; dk / dv rows past it are not written */
 } FaBwdParams;
 
 /* ABI version of the loaded library (== FA_ABI_VERSION of the header it was built from). */
@@ -246,6 +248,11 @@ int64_t fa_bwd_workspace_bytes(const FaBwdParams* params);
 int fa_bwd(const FaBwdParams* params, void* stream);
 /* Backward, packed variable-length batch. */
 int fa_varlen_bwd(const FaBwdParams* params, void* stream);
+/* Opt-in fused backward (FA_BWD_MODE=3) only: after fa_bwd with the SAME params, waits for `stream` and reads the launch's error flag from the workspace.
+   0 = the launch completed its hand-offs (or the call did not take the fused path), FA_ERR_LAUNCH = a dQ hand-off timed out: that 256-row block of dq was
+   not written, the gradients of this call must be discarded.  Both binders call it after every fused backward (the mode is experimental; the default
+   backward has no cross-workgroup hand-off and nothing to check). */
+int fa_bwd_fused_status(const FaBwdParams* params, void* stream);
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,7 @@ def test_no_scratch_in_the_hot_kernels():
     assert len(ks) >= 250, len(ks)
     fam = lambda s: {n: v for n, v in ks.items() if s in n}
     # the hand-scheduled kernels: never any scratch or vector spill (asm-owned accumulators: a spill there is a miscompile waiting to happen)
-    for s in ("fa_fwd_w64_kernel", "fa_bwd_dq_w64_kernel", "fa_fwd_il_kernel"):
+    for s in ("fa_fwd_w64_kernel", "fa_bwd_dq_w64_kernel", "fa_bwd_dkdv_w64_kernel", "fa_fwd_il_kernel"):
         assert fam(s), s
         for n, v in fam(s).items():
             assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (n, v)
@@ -65,6 +65,5 @@ def test_no_scratch_in_the_hot_kernels():
                 checked += 1
     assert checked >= 60, checked
     # and the total stays where round 3 left it
-    if True:
-        with_scratch = sorted(n for n, v in ks.items() if v["private_segment_fixed_size"] > 0)
-        assert len(with_scratch) <= 31, with_scratch   # (round 4: + the two D = 256 FEAT_EXACT dK/dV variants, 6 spills outside the tile loop like their FEAT_NONE twins)
+    with_scratch = sorted(n for n, v in ks.items() if v["private_segment_fixed_size"] > 0)
+    assert len(with_scratch) <= 31, with_scratch   # (round 4: + the two D = 256 FEAT_EXACT dK/dV variants, 6 spills outside the tile loop like their FEAT_NONE twins)
