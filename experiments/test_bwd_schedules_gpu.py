@@ -106,32 +106,4 @@ def test_ds_spill_needs_its_workspace_and_respects_the_cap(be, knobs):
     assert _cabi is not None and C is not None
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "B%d_Sq%d_Sk%d_H%d_%d_c%d_w%d_%d" % s)
-def test_dkdv_w64_kernel_matches_eight_wave_kernel_and_fp32(be, knobs, dtype, shape):
-    """fa_bwd_dkdv_w64_kernel (FA_BWD_DKDV=64, opt-in: four waves x 64 keys, software-pipelined, fa_bwd_dkdv64.hip) against the
-    default eight-wave dK/dV kernel: dq comes from the same dQ kernel (bit for bit); dk / dv have the same arithmetic per element
-    and the same accumulation order over the query tiles, so they agree bit for bit as well."""
-    B, Sq, Sk, H, Hk, causal, wl, wr = shape
-    torch.manual_seed(0)
-    q = torch.randn(B, Sq, H, 128, device="cuda", dtype=dtype)
-    k = torch.randn(B, Sk, Hk, 128, device="cuda", dtype=dtype)
-    v = torch.randn_like(k)
-    do = torch.randn_like(q)
-    knobs.set("FA_BWD_DKDV", 8)
-    a = run_bwd(be, q, k, v, do, causal, wl, wr)
-    knobs.set("FA_BWD_DKDV", 64)
-    w = run_bwd(be, q, k, v, do, causal, wl, wr)
-    if w[3]["bwd_dkdv_nw"] != 64:
-        pytest.skip("64-keys-per-wave dK/dV kernel not in this build (experiments/build_experiments.py, FA_GFX950_LIB)")
-    assert a[3]["bwd_dkdv_nw"] == 8 and w[3]["bwd_dkdv_nw"] == 64, (a[3], w[3])
-    assert torch.equal(a[0], w[0])
-    r = ref_grads(q, k, v, do, causal, wl, wr)
-    floor = 1e-2 if dtype == torch.bfloat16 else 2e-3
-    for i in (1, 2):
-        e8 = float((a[i].float() - r[i]).abs().max())
-        e64 = float((w[i].float() - r[i]).abs().max())
-        assert torch.isfinite(w[i].float()).all()
-        assert e64 <= max(2 * e8, floor), (i, e64, e8)
-
-
+# (the 64-keys-per-wave dK/dV kernel is a product kernel since round 5: tests/test_bwd_dkdv_w64_gpu.py)
