@@ -26,14 +26,14 @@
 #include "fa_w64_asm.h"
 
 #ifndef FA_DKDV64_AHJ
-#define FA_DKDV64_AHJ 5     // phase A: row-fragment reads run this many fragments (= MFMA gaps) ahead of their first MFMA
+#define FA_DKDV64_AHJ 6     // phase A: row-fragment reads run this many fragments (= MFMA gaps) ahead of their first MFMA
 #endif
 #ifndef FA_DKDV64_AHT
-#define FA_DKDV64_AHT 2     // phase B: transposed-fragment reads run this many fragments (two gaps each) ahead
+#define FA_DKDV64_AHT 3     // phase B: transposed-fragment reads run this many fragments (two gaps each) ahead
 #endif
 
 #ifndef FA_DKDV64_WAIT2
-#define FA_DKDV64_WAIT2 0   // 1: one explicit LDS wait per k-step (phase A) / per two fragments (phase B) instead of hipcc's one per MFMA
+#define FA_DKDV64_WAIT2 1   // 1: one explicit LDS wait per k-step (phase A) / per two fragments (phase B) instead of hipcc's one per MFMA
 #endif
 #ifndef FA_DKDV64_ABL
 #define FA_DKDV64_ABL 0     // timing ablations, bit mask (results become wrong; tools/ablate_dkdv64.sh): 1 no softmax arithmetic, 2 phase A's LDS operands read only for the
