@@ -1,6 +1,6 @@
-// EXPERIMENT (measured, not faster; not part of the default library): the dQ pass of the 5-contraction backward.  This text is included into
-// flash-attention_amd/csrc/fa_bwd_w64.hip (inside namespace fa, after the 64-rows-per-wave dQ kernel whose helpers it uses) when the library is built
-// with -DFA_EXPERIMENTS=1 by experiments/build_experiments.py; FA_BWD_MODE=2 selects it.  Records: profiles/r02_bwd_5_vs_7_contractions.txt,
+// EXPERIMENT (measured, not faster; not part of the default library): the dQ pass of the 5-contraction backward.  experiments/ds_spill.patch includes this
+// text into a copy of flash-attention_amd/csrc/fa_bwd_w64.hip (inside namespace fa, after the 64-rows-per-wave dQ kernel whose helpers it uses) and puts
+// the FA_BWD_MODE=2 dispatch back into a copy of fa_api.cpp (experiments/build_experiments.py).  Records: profiles/r02_bwd_5_vs_7_contractions.txt,
 // profiles/r03_bwd_5_contractions_mall.txt.
 // ------------------------------------------------------------------------------------------------------------------------
 // dQ from spilled dS (BwdK::ds_ws): dQ^T[d][query] = sum_key K^T[d][key] . dS^T[key][query] -- ONE contraction instead of the

@@ -52,7 +52,6 @@ const fa::Knobs* read_knobs() {
   k->bwd_dkdv = env_int("FA_BWD_DKDV", 0);
   k->bwd_ds_cap_mb = env_int("FA_BWD_DS_CAP_MB", 8192);
   k->fz_line = std::max(1, std::min(64, env_int("FA_FZ_LINE", 32)));
-  k->lds_pad = env_int("FA_IL_LDS_PAD", 0);
   k->w64_persist = env_int("FA_W64_PERSIST", 1);
   k->strict = env_int("FA_STRICT", 0);
   k->dkdv_prescale = env_int("FA_DKDV_PRESCALE", 0);
@@ -386,9 +385,6 @@ int bwd_dq_schedule(const FaBwdParams* a) {
 // (fa_bwd.hip: every feature variant, head dim 256, trimmed head dims).  Measured (profiles/r05_bwd_dkdv_w64.txt): at head dim 128 the 64-keys-per-wave kernel
 // wins from 2k query rows per key block (+1 % at S = 2048, +3 .. +6 % on the whole backward from S = 4096, GQA included) and loses below (its pipeline fill /
 // drain and 160 KB of LDS per workgroup cost more than they save on a short walk); at head dim 64 it ties or loses everywhere.
-#ifndef FA_EXPERIMENTS
-#define FA_EXPERIMENTS 0   // experiments/build_experiments.py: the dS-spill backward (FA_BWD_MODE=2), measured and not faster (profiles/r02_bwd_5_vs_7_contractions.txt)
-#endif
 int bwd_dkdv_schedule(const FaBwdParams* a) {
   const bool plain = a->softcap <= 0.f && !a->alibi_slopes && a->p_dropout <= 0.f;
   if (!plain || !head_dim_native(a->d) || head_dim_trimmed(head_dim_kernel(a->d)) || (a->d != 128 && a->d != 64)) return 8;
@@ -451,17 +447,8 @@ void bwd_list_entries(const FaBwdParams* a, int64_t& q_entries, int64_t& k_entri
   if (dk_dense * 4 > dk_bound * 5 && dk_dense >= 64) k_entries = dk_bound;
 }
 
-// dS spill (5-contraction backward, fa_kernel_params.h BwdK::ds_ws): bytes of the dS workspace, 0 = the dQ kernel recomputes.
-// Opt-in (FA_BWD_MODE=2): measured on MI355X it ties with the recomputing pair -- the spilled dS is B*H*Sq*Sk*2 bytes written
-// and read once (4.3 GB at config 3), which costs the HBM about what the two saved contractions cost the matrix pipe
-// (profiles/r02_bwd_5_vs_7_contractions.txt) -- and it needs O(S^2) scratch, so the default keeps the scratch-free 7.
-int64_t bwd_ds_bytes(const FaBwdParams* a) {
-  if (!FA_EXPERIMENTS || fa::knobs().bwd_mode != 2 || a->cu_seqlens_q || a->cu_seqlens_k || (a->d != 128 && a->d != 64)) return 0;
-  if (a->seqlen_q <= 0 || a->seqlen_k <= 0) return 0;
-  const int64_t bytes = (int64_t)a->b * a->h * ((a->seqlen_q + 31) / 32) * ((a->seqlen_k + 31) / 32) * 2048;
-  return bytes > ((int64_t)fa::knobs().bwd_ds_cap_mb << 20) ? 0 : bytes;
-}
-
+// (The two-launch dS-spill backward, FA_BWD_MODE=2, tied with the recomputing pair -- profiles/r02_bwd_5_vs_7_contractions.txt -- and needs O(S^2) scratch: it
+// is not part of this library; experiments/ds_spill.patch + experiments/build_experiments.py put it back for measurement.)
 // Fused backward (FA_BWD_MODE=3, fa_bwd.hip fa_bwd_fused_kernel): bytes of the dS workspace (256-B aligned) when the call qualifies, else 0; the sync
 // area (fa_kernel_params.h FZ_*) sits behind it.  Same conditions as launch_bwd_fused.
 int64_t bwd_fused_ds_bytes(const FaBwdParams* a) {
@@ -507,14 +494,6 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
     if (rc != -2) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (int rc2 = fill_bwd(a, varlen, k)) return rc2;   // does not apply after all: the default path, from a clean parameter block
   }
-  const int64_t ds_bytes = varlen ? 0 : bwd_ds_bytes(a);
-  if (ds_bytes > 0 && a->workspace && a->workspace_bytes >= ds_bytes) {
-    k.ds_ws = a->workspace;
-    k.ds_nq32 = (a->seqlen_q + 31) / 32;
-    k.ds_nk32 = (a->seqlen_k + 31) / 32;
-    k.nmb = (a->seqlen_q + 255) / 256;   // the dS.K pass works on 256-row blocks
-    fa::choose_units(a->b, a->h_k, a->h / a->h_k, k.nmb, k.q_units, k.q_unit_size, k.q_unit_hpx);
-  }
   if (varlen) {
     int64_t qe, ke;
     bwd_list_entries(a, qe, ke);
@@ -548,7 +527,7 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   // Round 4: where the 64-rows-per-wave dQ kernel runs (plain attention, head dim 64 / 128, long key loops) it computes softmax_d = rowsum(dO * O) of its own rows
   // in its prologue and goes FIRST; the dK/dV kernel behind it reads softmax_d from memory as before and the delta pre-pass is not launched
   // (FA_BWD_FUSE_DELTA=0: the three-launch order).  -2 from the launcher = the schedule does not apply after all: nothing was enqueued, fall through.
-  if (k.dq_nw == 64 && !k.ds_ws && fa::knobs().bwd_fuse_delta) {
+  if (k.dq_nw == 64 && fa::knobs().bwd_fuse_delta) {
     k.fuse_delta = 1;
     int rc = fa::launch_bwd_dq_w64(k, bf, a->d, s);
     if (rc == 0) {
@@ -565,8 +544,8 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   if (rc == 0) {
     rc = launch_dkdv_any(a, k, bf, dk_, s);
   }
-  if (rc == 0) rc = k.ds_ws ? fa::launch_bwd_dq_ds(k, bf, a->d, s) : fa::launch_bwd_dq(k, bf, dk_, s);
-  if (rc == 0) { fa::last_schedule().bwd_spill = k.ds_ws != nullptr; fa::last_schedule().bwd_list = (k.q_list != nullptr) + 2 * (k.k_list != nullptr); }
+  if (rc == 0) rc = fa::launch_bwd_dq(k, bf, dk_, s);
+  if (rc == 0) { fa::last_schedule().bwd_spill = 0; fa::last_schedule().bwd_list = (k.q_list != nullptr) + 2 * (k.k_list != nullptr); }
   if (rc == -2) return fail(FA_ERR_UNSUPPORTED, "no backward kernel for head dim %d", a->d);
   if (rc != 0) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   return FA_OK;
@@ -684,7 +663,7 @@ int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {
   int64_t qe, ke;
   bwd_list_entries(params, qe, ke);
   if (const int64_t fz = bwd_fused_ds_bytes(params); fz > 0) return fz + bwd_fused_sync_bytes(params);
-  return (qe ? (qe + 1) * 8 : 0) + (ke ? (ke + 1) * 8 : 0) + bwd_ds_bytes(params);   // (work lists: varlen only; dS: fixed-length only)
+  return (qe ? (qe + 1) * 8 : 0) + (ke ? (ke + 1) * 8 : 0);   // (work lists: varlen only)
 }
 int fa_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, false); }
 int fa_bwd_fused_status(const FaBwdParams* params, void* stream) {

@@ -27,15 +27,11 @@
 #include "fa_kernel_params.h"
 #include "fa_launch.h"
 
-#ifndef FA_BWD_WAIT2
-#define FA_BWD_WAIT2 1   // dK/dV kernel: one LDS wait per two MFMA ops, operand reads one slot further ahead
-#endif
-#ifndef FA_BWD_PF
-#define FA_BWD_PF (FA_BWD_WAIT2 ? 4 : 3)    // dK/dV kernel: row-major LDS operands are read this many MFMA slots minus one ahead
-#endif
-#ifndef FA_BWD_PFT
-#define FA_BWD_PFT (FA_BWD_WAIT2 ? 4 : 3)   // same for the transposed operands of the dV / dK products
-#endif
+// dK/dV kernel: LDS operands are read this many MFMA slots minus one ahead (row-major / transposed), one LDS wait per two MFMA ops.  The timing ablations,
+// the cycle statistics of the fused backward and the A/B switches measured in rounds 2-4 live in experiments/ablations/fa_bwd.patch (tools/ablate_dkdv.sh,
+// tools/ablate_fused.sh, tools/bwd_fused_check.py --stats).
+#define FA_BWD_PF 4
+#define FA_BWD_PFT 4
 // s_waitcnt lgkmcnt(n) with n known only after unrolling (the builtin wants a literal)
 #define FA_WAIT_LGKM_CASE(n) case n: __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8)); break;
 static __device__ __forceinline__ void wait_lgkm_le(int n) {
@@ -49,28 +45,9 @@ static __device__ __forceinline__ void wait_lgkm_le(int n) {
 // profiles/r02_bwd_schedules.txt): 4-wave workgroups of 128 keys at D <= 128 (FA_DKDV_SPLIT), the upper four waves one phase ahead of their SIMD
 // partners (FA_DKDV_ROT: 1494 | 2394 us against 1431 | 2278 in lock step), the dV / dK segment's first operands read before the vector phase
 // (FA_DKDV_CARRY: identical), static priority for the second-dispatched waves (FA_DKDV_PRIO: slower).
-#ifndef FA_EXPERIMENTS
-#define FA_EXPERIMENTS 0
-#endif
-#ifndef FA_FZ_STATS
-#define FA_FZ_STATS 0    // 1 = the fused backward adds up cycle counts of its parts in the sync area (tools/bwd_fused_check.py --stats)
-#endif
-#ifndef FA_FZ_ABL
-#define FA_FZ_ABL 0      // timing ablations of the fused backward (results become wrong; tools/ablate_fused.sh): 1 no dQ work, 2 plain dS stores, 4 no tickets, 8 no acquire, 16 no waiting at the end, 32 no dS DMA / 64 no K DMA after a dQ item's first two tiles, 128 one MFMA per dQ sub-tile
-#endif
 #ifndef FA_BWD_PART
 #define FA_BWD_PART 0    // build.py compiles this file three times side by side: 1 = delta + dK/dV, 2 = dQ, 3 = the fused backward; 0 = everything
 #endif
-#ifndef FA_DKDV_PRESCALE
-#define FA_DKDV_PRESCALE 1  // 0 = the plain dK/dV kernel subtracts LSE and delta on the vector ALU like the feature variants (A/B)
-#endif
-#ifndef FA_DKDV_WALK_DOWN
-#define FA_DKDV_WALK_DOWN 1  // 0 = query tiles always in ascending order (A/B)
-#endif
-#ifndef FA_DKDV_ABL
-#define FA_DKDV_ABL 0  // timing ablations of the dK/dV kernel (results become wrong; tools/ablate_dkdv.sh): 1 no exp2, 2 row-major LDS
-#endif                 // operands read once per sub-tile, 4 transposed operands read once, 8 no DMA wait / barrier per item,
-                       // 16 no S/dP MFMAs, 32 no dV/dK MFMAs, 64 no Q/dO DMA after the first item
 
 namespace fa {
 
@@ -150,8 +127,8 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
   // input dtype puts an error of |score| * 2^-9 (bf16) / 2^-12 (fp16) log2 units into the exponent of P that the forward's LSE does not share; the
   // reference's own acceptance tests see it (tests/test_flash_attn.py::test_flash_attn_causal with one visible key: P must be exactly 1 and dV exactly
   // dO, we returned dO * (1 + 2^-8); test_flash_attn_bwd_overflow in fp16: dV error 7x PyTorch's; profiles/r04_reference_suite.txt).
-  constexpr bool PRE = (FEAT == FEAT_NONE) && FA_DKDV_PRESCALE;                    // K pre-scaled, score chain starts from C = -LSE*log2e
-  constexpr bool PRE_D = ((FEAT & FEAT_ALL) == FEAT_NONE) && FA_DKDV_PRESCALE;     // dP chain starts from C = -delta (FEAT_NONE and FEAT_EXACT)
+  constexpr bool PRE = (FEAT == FEAT_NONE);                    // K pre-scaled, score chain starts from C = -LSE*log2e
+  constexpr bool PRE_D = ((FEAT & FEAT_ALL) == FEAT_NONE);     // dP chain starts from C = -delta (FEAT_NONE and FEAT_EXACT)
   // LDS: Q0 | Q1 | dO0 | dO1 | V block | aux0 aux1   (aux = BMQ x LSE*log2e followed by BMQ x delta).  The streamed tiles
   // sit below 64 KB so that (buffer, sub-block) offsets fit the 16-bit immediate of ds_read.
   constexpr int OFF_Q = 0, OFF_DO = 2 * QT_BYTES, OFF_V = 4 * QT_BYTES, OFF_AUX = OFF_V + VBLK_BYTES;
@@ -259,7 +236,7 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
   // DOWN from the last one, all key blocks of a (batch, head) -- co-resident on one XCD -- read the same Q/dO tile at the same
   // time and it is fetched into that L2 once; walking up, every key block starts at its own m_lo and the L2 would have to
   // hold the head's whole Q and dO (the round-1 counters: 51 % L2 hits, 2.8x the algorithmic HBM traffic at config 3).
-  const bool walk_down = FA_DKDV_WALK_DOWN && p.wr >= 0 && p.wl < 0;
+  const bool walk_down = p.wr >= 0 && p.wl < 0;
   auto item_m0 = [&](int it) {
     const int im = (it == it_cur ? c_im : n_im);
     return (m_lo + (walk_down ? nm - 1 - im : im)) * BMQ;
@@ -373,7 +350,6 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
     }
     auto rd = [&](int j) __attribute__((always_inline)) {
       const int ks = j >> 1;
-      if ((FA_DKDV_ABL & 2) && j >= 2) { ra[j % PF] = ra[(j & 1) % PF]; if (j & 1) rb[ks & 1] = rb[0]; return; }
       if ((j & 1) == 0) {
         ra[j % PF] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)((QB_OFF + sub) + (k0p ^ (ks << 5)));   // (byte offsets, not lds + ..: the segment base
                                                                                                               // is 0 by construction, and as a pointer add it costs a v_add per read)
@@ -387,7 +363,6 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
 #pragma unroll
     for (int j = 0; j < NOPS; ++j) {
       if (j + PF - 1 < NOPS) rd(j + PF - 1);
-#if FA_BWD_WAIT2
       // one LDS wait per TWO ops (as the 64-rows-per-wave kernels): before an even op, wait until the operands of the odd op behind it have
       // landed too -- everything requested later (ops j + 2 .. j + PF - 1: one read for an S op, two for a dP op) may stay in flight.
       // hipcc models the explicit wait and emits none in front of the odd op.
@@ -396,7 +371,6 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
         for (int g = j + 2; g <= j + PF - 1 && g < NOPS; ++g) out += (g & 1) ? 2 : 1;
         wait_lgkm_le(out);
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this op's MFMA
       const int ks = j >> 1;
       f32x16 c = (j & 1) ? dp : s;
@@ -408,7 +382,6 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
           for (int r = 0; r < 16; ++r) c[r] = 0.f;
         }
       }
-      if ((FA_DKDV_ABL & 16) && j >= 2) { if ((j & 1) == 0) s = c; else dp = c; continue; }
       if ((j & 1) == 0) s = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), kf[ks], c);
       else dp = T::mfma(bitcast_u32x4<V8>(ra[j % PF]), bitcast_u32x4<V8>(rb[ks & 1]), c);
     }
@@ -479,7 +452,7 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
       for (int j = 0; j < 4; ++j) {
         const int r = 4 * g + j;
         const float ex = PRE ? s[r] : __builtin_fmaf(s[r], cs, -l4[j]);   // PRE: the pipe already delivered S*c - LSE*log2e, and dP - delta
-        const float pv = (FA_DKDV_ABL & 1) ? ex : fast_exp2(ex);
+        const float pv = fast_exp2(ex);
         float pkeep = pv, dpe = dp[r];
         if constexpr (F_DROP) {
           if (drop) {  // Z = keep / (1 - p): dV uses P*Z (the 1/(1-p) is applied to dV at the end), dS = P*(dP*Z - delta)
@@ -496,16 +469,16 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
       }
     }
 
-    // (hook of experiments/fa_bwd_dq_ds.inc.hip, FA_BWD_MODE=2: ds_ws is NULL in the default library and the branch is never taken.  It is not compiled
-    // out: without it hipcc's register allocation of the softcap variant at D = 128 comes out two vector spills worse -- 12 bytes of scratch,
-    // tests/test_kernel_resources_cpu.py)
+    // (the fused backward's hand-over of dS, FA_BWD_MODE=3, and the dS-spill experiment's, experiments/ds_spill.patch; ds_ws is NULL otherwise and the branch is
+    // not taken.  It is part of every variant: without it hipcc's register allocation of the softcap variant at D = 128 comes out two vector spills worse --
+    // 12 bytes of scratch, tests/test_kernel_resources_cpu.py)
     if (p.ds_ws) {  // dS spill: this sub-tile's fragments, one 16-byte slot per lane (fa_device.h ds_slot), for the dQ contraction
       if (!key_valid) {  // keys past the end (their K rows are clamped copies over there): no contribution
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dsfrag[0][j] = (E)0.f; dsfrag[1][j] = (E)0.f; }
       }
       E* dst = (E*)p.ds_ws + (((((int64_t)b * p.h + item_head(it)) * p.ds_nq32 + (q0 >> 5)) * p.ds_nk32 + (wk0 >> 5)) << 10) + ds_slot(ki, hi) * 8;
-      if constexpr (FUSED && !(FA_FZ_ABL & 2)) {   // read by another workgroup of the SAME launch: written through (sc1), see fa_bwd_fused_kernel
+      if constexpr (FUSED) {   // read by another workgroup of the SAME launch: written through (sc1), see fa_bwd_fused_kernel
         st_global_16B_sc1(dst, __builtin_bit_cast(u32x4, dsfrag[0]));
         st_global_16B_sc1(dst + 512, __builtin_bit_cast(u32x4, dsfrag[1]));
       } else {
@@ -526,7 +499,6 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
     const int t0p = opaque(tr_base[0]), t1p = opaque(tr_base[1]);
     auto rd = [&](int i) __attribute__((always_inline)) {
       const int db = (i >> 1) % DB, t = i / (2 * DB);
-      if ((FA_DKDV_ABL & 4) && i >= 2) { tlo[i % PFT] = tlo[(i & 1) % PFT]; thi[i % PFT] = thi[(i & 1) % PFT]; return; }
       const int base = ((i & 1) ? QB_OFF : DOB_OFF) + sub + 16 * t * ROW_BYTES;
       tlo[i % PFT] = lds_read_tr16((const char FA_LDS*)(unsigned long)(unsigned)(base + (t0p ^ (db << 6))));
       thi[i % PFT] = lds_read_tr16((const char FA_LDS*)(unsigned long)(unsigned)(base + (t1p ^ (db << 6))));
@@ -537,16 +509,13 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
 #pragma unroll
     for (int i = 0; i < NOPS; ++i) {
       if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
-#if FA_BWD_WAIT2
       if ((i & 1) == 0 && i + 1 < NOPS) {   // (two transpose reads per op)
         int out = 0;
         for (int g = i + 2; g <= i + PFT - 1 && g < NOPS; ++g) out += 2;
         wait_lgkm_le(out);
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       const int db = (i >> 1) % DB, t = i / (2 * DB);
-      if ((FA_DKDV_ABL & 32) && i >= 2) continue;
       if ((i & 1) == 0) dv_acc[db] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), pfrag[t], dv_acc[db]);
       else dk_acc[db] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), dsfrag[t], dk_acc[db]);
     }
@@ -577,20 +546,19 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
     constexpr int cur = decltype(curc)::value;
     using CUR = std::integral_constant<int, cur>;
     const bool has_next = it + 1 < n_items;
-    if (has_next && !((FA_DKDV_ABL & 64) && it > 0)) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
+    if (has_next) load_item(it + 1, cur ^ 1);  // DMA lands in the other buffer while this item is computed
     const bool a0 = sub_active(it, 0), a1 = NQB > 1 && sub_active(it, 1);
     if (a0) { p1(CUR{}, Q0{}); p2(CUR{}, Q0{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q0{}, it); }); }
     if constexpr (NQB > 1) {
       if (a1) { p1(CUR{}, Q1{}); p2(CUR{}, Q1{}, [&]() __attribute__((always_inline)) { sm(CUR{}, Q1{}, it); }); }
     }
     if (has_next) store_item(cur ^ 1);
-    if (FA_DKDV_ABL & 8) return;
     lds_dma_wait_all();
     __syncthreads();
     if constexpr (FUSED) {
       // Every wave's dS stores of this item are acknowledged (the vmcnt(0) above, in every wave, then the barrier).  Thread 0 settles the ticket it
       // drew one item ago (its return value has long arrived: no wait) and draws one for the query block this item completed, if any.
-      if (tid == 0 && !(FA_FZ_ABL & 4)) {
+      if (tid == 0) {
         fz_settle();
         const int mt = item_m0(it) / BMQ;
         const bool block_done = walk_down ? ((mt % FZ_TPB) == 0 || mt == m_lo) : ((mt % FZ_TPB) == FZ_TPB - 1 || mt == m_lo + nm - 1);
@@ -693,18 +661,18 @@ static __device__ __forceinline__ void fa_bwd_dq_from_ds(const BwdK& p, char FA_
       const int row = idx * RPD + lane / CPR;
       const int c = (lane % CPR) ^ swz16<D>(row);
       const int key = min(n * BN + row, sk - 1);   // rows past the last key: clamped copies, their dS is zero
-      if (!((FA_FZ_ABL & 64) && n > n_min + 1)) lds_dma_16B(kp + (int64_t)key * p.k_rs + c * 8, lds + st * TILE_BYTES + idx * 1024);
+      lds_dma_16B(kp + (int64_t)key * p.k_rs + c * 8, lds + st * TILE_BYTES + idx * 1024);
     }
     if (wave_valid) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k32 = min(2 * n + (j >> 1), p.ds_nk32 - 1);
-        if (!((FA_FZ_ABL & 32) && n > n_min + 1)) lds_dma_16B(ds_row + ((int64_t)k32 << 10) + (j & 1) * 512, lds + OFF_DS + st * DS_BUF + wave * DS_WAVE + j * 1024);
+        lds_dma_16B(ds_row + ((int64_t)k32 << 10) + (j & 1) * 512, lds + OFF_DS + st * DS_BUF + wave * DS_WAVE + j * 1024);
       }
     }
   };
   auto wait_tile = [&](bool next_in_flight) __attribute__((always_inline)) {   // this wave's DMA of the current tile has landed
-    if (!next_in_flight || (FA_FZ_ABL & (32 | 64))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!next_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (wave_valid) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 4) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
   };
@@ -756,7 +724,6 @@ static __device__ __forceinline__ void fa_bwd_dq_from_ds(const BwdK& p, char FA_
 #pragma unroll
       for (int i = 0; i < NOPS; ++i) {
         if (i + PFT - 1 < NOPS) rd(i + PFT - 1);
-        if ((FA_FZ_ABL & 128) && i >= 1) continue;
         dq_acc[i % DB] = T::mfma(combine_tr<V8>(tlo[i % PFT], thi[i % PFT]), f[i / DB], dq_acc[i % DB]);
       }
     }
@@ -780,21 +747,19 @@ static __device__ __forceinline__ void fa_bwd_dq_from_ds(const BwdK& p, char FA_
 // workgroups that fail around a publication the last one to give back always sees it, and nothing is left behind.  Every loop is bounded: a claimed slot
 // whose content does not appear (its publisher is between its two atomics) is polled with read-modify-writes; on a time-out the launch's error flag is set and the
 // binders raise after the call (fa_bwd_fused_status, include/fa_gfx950.h): the block of dq it stood for was not written.
-static __device__ __forceinline__ int fz_pop(int32_t* z, int32_t* ctrl, int32_t* slots, int (&st)[4]) {
+static __device__ __forceinline__ int fz_pop(int32_t* z, int32_t* ctrl, int32_t* slots) {
   for (int spin = 0; spin < (1 << 12); ++spin) {
     if (__hip_atomic_fetch_add(ctrl + FZ_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
       const int hd = __hip_atomic_fetch_add(ctrl + FZ_HEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int tries = 0; tries < (1 << 18); ++tries) {
         const int v = __hip_atomic_fetch_add(slots + hd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v != 0) return v - 1;
-        if (FA_FZ_STATS) ++st[1];
         __builtin_amdgcn_s_sleep(4);
       }
       __hip_atomic_store(z + FZ_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return -1;
     }
     if (__hip_atomic_fetch_add(ctrl + FZ_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) return -1;   // still nothing after giving back
-    if (FA_FZ_STATS) ++st[0];
   }
   return -1;
 }
@@ -814,85 +779,48 @@ __global__ void __launch_bounds__(512, 2) fa_bwd_fused_kernel(const BwdK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char FA_LDS* lds = (char FA_LDS*)smem;
   constexpr int OFF_ITEM = fused_smem_bytes<D>();   // one word behind everything either part uses
-  int st[4] = {0, 0, 0, 0};                         // (FA_FZ_STATS) semaphore retries, publication polls, dQ items taken, key-block items taken
   const int qx = blockIdx.x & 7;
   int32_t* ctrl = p.fuse_sync + FZ_CTRL + qx * FZ_CTRL_STRIDE;
   int32_t* slots = p.fuse_sync + FZ_COUNTERS + (int64_t)p.fuse_items * p.fuse_line + (int64_t)qx * p.fuse_items;
   const int total_x = (p.fuse_total - qx + 7) >> 3;   // key-block items of this XCD
-#if FA_FZ_STATS
-  const unsigned long long w_begin = __builtin_amdgcn_s_memrealtime();
-  long long t_kv = 0, t_pop = 0, t_dq = 0;
-#endif
   for (;;) {
     __syncthreads();   // the part before is done with the LDS
     if (threadIdx.x == 0) *(int FA_LDS*)(lds + OFF_ITEM) = __hip_atomic_fetch_add(ctrl + FZ_NEXT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int kx = __builtin_amdgcn_readfirstlane(*(const int FA_LDS*)(lds + OFF_ITEM));
     const bool have_kv = kx < total_x;
-#if FA_FZ_STATS
-    const long long t0 = __builtin_readcyclecounter();
-#endif
     if (have_kv) {
-      if (FA_FZ_STATS) ++st[3];
       fa_bwd_dkdv_body<E, D, D, FEAT_EXACT, true>(p, qx + 8 * kx);
       if (threadIdx.x == 0) {   // this key block is over: everything it publishes is published (its atomics have returned)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(ctrl + FZ_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-#if FA_FZ_STATS
-    t_kv += __builtin_readcyclecounter() - t0;
-#endif
     for (;;) {   // dQ for whatever is ready
       __syncthreads();
-#if FA_FZ_STATS
-      const long long t1 = __builtin_readcyclecounter();
-#endif
       if (threadIdx.x == 0) {
-        int item = fz_pop(p.fuse_sync, ctrl, slots, st);
+        int item = fz_pop(p.fuse_sync, ctrl, slots);
         // no key block left to take: stay until the XCD's last key block is finished and the queue is empty (bounded, ~2 ms).  Nobody waits for a waiter --
         // publishers never depend on consumers -- and correctness never depends on the waiting: a publisher drains the queue itself.
-        if (item < 0 && !have_kv && !(FA_FZ_ABL & 16)) {
+        if (item < 0 && !have_kv) {
           for (int w = 0; w < 512; ++w) {
             const int done = __hip_atomic_fetch_add(ctrl + FZ_DONE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            item = fz_pop(p.fuse_sync, ctrl, slots, st);
+            item = fz_pop(p.fuse_sync, ctrl, slots);
             if (item >= 0 || done >= total_x) break;
             __builtin_amdgcn_s_sleep(96);
           }
         }
-        if (item >= 0 && !(FA_FZ_ABL & 8)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (item >= 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         *(int FA_LDS*)(lds + OFF_ITEM) = item;
       }
       __syncthreads();
       const int item = __builtin_amdgcn_readfirstlane(*(const int FA_LDS*)(lds + OFF_ITEM));
-#if FA_FZ_STATS
-      const long long t2 = __builtin_readcyclecounter();
-      t_pop += t2 - t1;
-#endif
       if (item < 0) break;
-      if (FA_FZ_STATS) ++st[2];
       const int bh = item / p.nmb;
-      if (FA_FZ_ABL & 1) continue;
       fa_bwd_dq_from_ds<E, D>(p, lds, bh / p.h, bh % p.h, item - bh * p.nmb);
-#if FA_FZ_STATS
-      t_dq += __builtin_readcyclecounter() - t2;
-#endif
     }
     if (!have_kv) break;
   }
-#if FA_FZ_STATS
-  if (threadIdx.x == 0) {
-    unsigned long long* sw = (unsigned long long*)(p.fuse_sync + FZ_STATS);
-    atomicAdd(sw + 0, (unsigned long long)t_kv);
-    atomicAdd(sw + 1, (unsigned long long)t_pop);
-    atomicAdd(sw + 2, (unsigned long long)t_dq);
-    atomicAdd(sw + 3, (unsigned long long)st[0]);
-    atomicAdd(sw + 4, (unsigned long long)st[1]);
-    atomicAdd(sw + 5, (unsigned long long)st[2]);
-    atomicAdd(sw + 6, 1ull);
-    atomicMax(sw + 7, (unsigned long long)t_pop);
-  }
-#endif
 }
 
 template <typename E, int D>

@@ -25,20 +25,10 @@
 #define FA_W64_CLOB FA_W64_ACC_CLOBBERS_256
 #include "fa_w64_asm.h"
 
-#ifndef FA_DKDV64_AHJ
+// LDS operand reads run ahead of their MFMAs with one explicit wait per k-step (phase A) / per two fragments (phase B).  The timing ablations and the
+// one-wait-per-MFMA variant live in experiments/ablations/fa_bwd_dkdv_w64.patch (tools/ablate_dkdv64.sh).
 #define FA_DKDV64_AHJ 6     // phase A: row-fragment reads run this many fragments (= MFMA gaps) ahead of their first MFMA
-#endif
-#ifndef FA_DKDV64_AHT
 #define FA_DKDV64_AHT 3     // phase B: transposed-fragment reads run this many fragments (two gaps each) ahead
-#endif
-
-#ifndef FA_DKDV64_WAIT2
-#define FA_DKDV64_WAIT2 1   // 1: one explicit LDS wait per k-step (phase A) / per two fragments (phase B) instead of hipcc's one per MFMA
-#endif
-#ifndef FA_DKDV64_ABL
-#define FA_DKDV64_ABL 0     // timing ablations, bit mask (results become wrong; tools/ablate_dkdv64.sh): 1 no softmax arithmetic, 2 phase A's LDS operands read only for the
-#endif                      // first k-step, 4 phase B's transposed operands read only for the first block, 8 no DMA wait / barrier per step, 16 no tile DMA after the prologue,
-                            // 32 no preload of the next step's operands, 128 every step takes the plain path (no activity / mask tests)
 
 namespace fa {
 namespace {
@@ -352,12 +342,10 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     __builtin_amdgcn_sched_barrier(0);
     static_for<4 * KS>([&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value, ks = g >> 2, kind = g & 3;
-      if constexpr (g + AHJ < 4 * KS && !((FA_DKDV64_ABL & 2) && g + AHJ >= 4)) rd_a(ICw<g + AHJ>{}, qa, kva);
-#if FA_DKDV64_WAIT2
+      if constexpr (g + AHJ < 4 * KS) rd_a(ICw<g + AHJ>{}, qa, kva);
       // one wait per k-step: its four fragments (and key block 1's LDS-resident K fragment, requested between them) have landed; the AHJ - 3 fragments
       // requested behind them may stay in flight.  hipcc models the explicit wait and drops its own in front of the k-step's other three MFMAs.
       if constexpr (kind == 0 && ks >= 1 && AHJ >= 3) __builtin_amdgcn_s_waitcnt(0xC07F | ((g + AHJ < 4 * KS ? AHJ - 3 : (4 * KS - 4 - g > 0 ? 4 * KS - 4 - g : 0)) << 8));
-#endif
       // k-step 0: key block 1's chain goes FIRST and takes key block 0's preloaded tuple as its C operand (one copy of -LSE/scale and -delta is loaded per step,
       // not two); block 0's chain then accumulates onto it in place.  The matrix pipe is in order: the second MFMA's write follows the first one's read.
       if constexpr (kind == 0) {
@@ -468,17 +456,15 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
       static_for<NG>([&](auto xc) __attribute__((always_inline)) {
         constexpr int x = decltype(xc)::value, F = x >> 1, kb = x & 1;
         constexpr int db = F >> 2, t = (F >> 1) & 1, src = F & 1;
-        if constexpr (kb == 0 && F + AHT < NFB && !((FA_DKDV64_ABL & 4) && F + AHT >= 4)) rd_t(ICw<F + AHT>{}, t0p, t1p);
-#if FA_DKDV64_WAIT2
+        if constexpr (kb == 0 && F + AHT < NFB) rd_t(ICw<F + AHT>{}, t0p, t1p);
         if constexpr (kb == 0 && (F & 1) == 0 && AHT >= 2) {   // fragments F and F + 1 have landed; the ones behind them (two transpose reads each) may stay in flight
           constexpr int last = F + AHT < NFB ? F + AHT : NFB - 1;
           constexpr int out = last - (F + 1) > 0 ? 2 * (last - (F + 1)) : 0;
           __builtin_amdgcn_s_waitcnt(0xC07F | (out << 8));
         }
-#endif
         if constexpr (src == 0) kv_mfma_tile<E, kb * DB + db>(ring[F % NT], pr[kb][t]);
         else kv_mfma_tile<E, 2 * DB + kb * DB + db>(ring[F % NT], dr[kb][t]);
-        if constexpr (DO_SM && !(FA_DKDV64_ABL & 1)) {
+        if constexpr (DO_SM) {
           static_for<EPG>([&](auto ic) __attribute__((always_inline)) {
             constexpr int e = x * EPG + decltype(ic)::value;
             sm1(ICw<e>{});
@@ -487,7 +473,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      if constexpr (DO_SM && !(FA_DKDV64_ABL & 1)) static_for<EPG>([&](auto ic) __attribute__((always_inline)) { sm2(ICw<32 - EPG + decltype(ic)::value>{}); });
+      if constexpr (DO_SM) static_for<EPG>([&](auto ic) __attribute__((always_inline)) { sm2(ICw<32 - EPG + decltype(ic)::value>{}); });
     } else if constexpr (DO_SM) {
       static_for<16>([&](auto hc) __attribute__((always_inline)) {   // pair by pair: few values alive at a time
         constexpr int e = 2 * decltype(hc)::value;
@@ -507,8 +493,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   bool act_prev = false;
   auto make_ctl = [&](int st) __attribute__((always_inline)) {   // for step st, from the counters as they stand (compute tile st, stream tile st + 2)
     Ctl c;
-    c.act = (FA_DKDV64_ABL & 128) ? (st < n_steps) : ((st < n_steps) && ((unsigned)(c_mt - a_lo) <= a_span));
-    c.msk = (FA_DKDV64_ABL & 128) ? false : !((unsigned)(c_mt - f_lo) <= f_span);
+    c.act = (st < n_steps) && ((unsigned)(c_mt - a_lo) <= a_span);
+    c.msk = !((unsigned)(c_mt - f_lo) <= f_span);
     c.slot_a = st & 3; c.slot2 = (st + 2) & 3;
     // (the fill's MFMAs multiply zeros by whatever the "previous tile's" slot holds: at step 0 that slot was never written -- NaN bit patterns times zero --,
     // so the fill reads the current tile's slot instead)
@@ -534,8 +520,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     if (__builtin_expect(c.act, 1)) {
       phase_a(c.slot_a, [&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
-        if constexpr (g == 1 && !(FA_DKDV64_ABL & 16)) stream_dma_q(c.z);
-        if constexpr (g == 3 && !(FA_DKDV64_ABL & 16)) stream_dma_d(c.z);
+        if constexpr (g == 1) stream_dma_q(c.z);
+        if constexpr (g == 3) stream_dma_d(c.z);
       });
     } else {
       stream_dma_q(c.z); stream_dma_d(c.z);
@@ -565,11 +551,11 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
       if (__builtin_expect(c.act && c.msk, 0)) phase_b(Y{}, Y{}, Y{}, c.slot_b, c.q0, pc, dc, pn, dn);
       else phase_b(Y{}, Y{}, N{}, c.slot_b, c.q0, pc, dc, pn, dn);
     }
-    if (!(FA_DKDV64_ABL & 32)) preload_a((st + 1) & 3);   // (tile st + 1 was published by the previous barrier.  Unconditional: a conditional definition keeps the 96 registers of
+    preload_a((st + 1) & 3);   // (tile st + 1 was published by the previous barrier.  Unconditional: a conditional definition keeps the 96 registers of
                                // S / dP / the fragment rings alive across phase B in hipcc's eyes; past the last tile it reads a stale slot nobody uses)
-    if (!(FA_DKDV64_ABL & 8)) lds_dma_wait_all();          // tile st + 2 has landed (requested in this step's first gaps)
+    lds_dma_wait_all();        // tile st + 2 has landed (requested in this step's first gaps)
     stream_store_aux(c.slot2);
-    if (!(FA_DKDV64_ABL & 8)) __syncthreads();
+    __syncthreads();
   };
 #pragma unroll 1
   for (int st = 0; st <= n_steps; ++st) step(st);

@@ -27,21 +27,9 @@
 #define FA_W64_CLOB FA_W64_ACC_CLOBBERS_256
 #include "fa_w64_asm.h"
 
-#ifndef FA_BW64_CDELTA
-#define FA_BW64_CDELTA 0
-#endif
-#ifndef FA_BW64_WAIT2
-#define FA_BW64_WAIT2 1
-#endif
-#ifndef FA_BW64_CARRY
-#define FA_BW64_CARRY 1   // as FA_W64_CARRY in fa_fwd_w64.hip: the first operand reads of an iteration's second step are issued in the last gaps of its first step
-#endif
-#ifndef FA_BW64_AH
-#define FA_BW64_AH 2   // (3 with the paired waits costs five spilled registers; the forward measured no difference between 1 and 4)
-#endif
-#ifndef FA_BW64_ABL
-#define FA_BW64_ABL 0  // timing ablations (results become wrong): 1 no exp2, 2 no LDS operand reads, 4 no K/V DMA after the
-#endif                 // first tiles, 8 no DMA wait / barrier per tile, 16 no packing
+// LDS operand reads run this many fragment slots (2 gaps each) ahead of their MFMAs, one explicit wait per two slots (3 costs five spilled registers; the forward
+// measured no difference between 1 and 4).  The timing ablations and the -delta-in-the-C-operand variant live in experiments/ablations/fa_bwd_w64.patch (tools/ablate_bw64.sh).
+#define FA_BW64_AH 2
 
 namespace fa {
 namespace {
@@ -339,19 +327,13 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
     for (int t = 0; t < 2; ++t) { fA[qb][t] = u32x4{0u, 0u, 0u, 0u}; fB[qb][t] = u32x4{0u, 0u, 0u, 0u}; }
   }
   // The score chains' C operand: -LSE*log2e broadcast (+inf LSE of a row past the end: -inf, P = 0).  (The dP chains could take -delta the same
-  // way -- FA_BW64_CDELTA -- but two more 32-register broadcasts do not fit: 352 bytes of scratch in the tile loop.)
+  // way -- built and measured as FA_BW64_CDELTA, experiments/ablations/fa_bwd_w64.patch -- but two more 32-register broadcasts do not fit: 352 bytes of scratch in the tile loop.)
   f32x16 nlse[QB];
-#if FA_BW64_CDELTA
-  f32x16 ndel[QB];
-#endif
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       nlse[qb][r] = -lse_l[qb];
-#if FA_BW64_CDELTA
-      ndel[qb][r] = -delta_l[qb];
-#endif
     }
   }
   bool have_cur = false, have_prev = false;
@@ -366,12 +348,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   };
   // dS_i of one element
   auto ds_elem = [&](float sv, float dpv, int qb) __attribute__((always_inline)) {
-    const float pv = (FA_BW64_ABL & 1) ? sv : fast_exp2(sv);   // sv = s*scale*log2e - LSE*log2e, dpv = dP - delta: both subtractions rode in the chains' C operands
-#if FA_BW64_CDELTA
-    return pv * dpv;
-#else
+    const float pv = fast_exp2(sv);   // sv = s*scale*log2e - LSE*log2e, dpv = dP - delta: both subtractions rode in the chains' C operands
     return pv * (dpv - delta_l[qb]);
-#endif
   };
   auto pack2 = [&](float x0, float x1) __attribute__((always_inline)) {
     using V2 = __attribute__((ext_vector_type(2))) E;
@@ -397,13 +375,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
         if constexpr (ks == 0) {
           mfma_v_first<E, BW_Q_BASE>(s_nxt[0], kf, nlse[0]);
           mfma_v_first<E, BW_Q_BASE + 4 * KS>(s_nxt[1], kf, nlse[1]);
-#if FA_BW64_CDELTA
-          mfma_v_first<E, BW_DO_BASE>(dp_nxt[0], vf, ndel[0]);
-          mfma_v_first<E, BW_DO_BASE + 4 * KS>(dp_nxt[1], vf, ndel[1]);
-#else
           mfma_v_first0<E, BW_DO_BASE>(dp_nxt[0], vf);
           mfma_v_first0<E, BW_DO_BASE + 4 * KS>(dp_nxt[1], vf);
-#endif
         } else {
           mfma_v_acc<E, BW_Q_BASE + 4 * ks>(s_nxt[0], kf);
           mfma_v_acc<E, BW_Q_BASE + 4 * (KS + ks)>(s_nxt[1], kf);
@@ -465,12 +438,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
     constexpr int AH = FA_BW64_AH, RNG = AH + 1;     // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
     constexpr int NF = 2 * KS + 2 * DB;     // fragment slots: KS K rows, KS V rows, 2*DB transposed K
     static_assert(RNG == FA_BW64_AH + 1, "the fragment ring is the caller's (carried from a first step to its second step)");
-    if (FA_BW64_ABL & 2) {
-#pragma unroll
-      for (int f = 0; f < RNG; ++f) fr[f] = f_prev[0][0];
-    }
     auto rd_frag = [&](int f) __attribute__((always_inline)) {
-      if (FA_BW64_ABL & 2) return;
       if (f < KS) {
         fr[f % RNG] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[f] + HOFF);
       } else if (f < 2 * KS) {
@@ -489,7 +457,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) { rel_hi[qb] = lim_hi[qb] - k0 - 4 * hi; rel_lo[qb] = lim_lo[qb] - k0 - 4 * hi; }
     }
-    if constexpr (!(FA_BW64_CARRY && half == 1)) {   // (second step: requested by the first step's last gaps)
+    if constexpr (half != 1) {   // (second step: requested by the first step's last gaps)
 #pragma unroll
       for (int f = 0; f < AH; ++f) rd_frag(f);
     }
@@ -498,30 +466,24 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       constexpr int x = decltype(xc)::value;
       constexpr int f = x / 2, qb = x & 1;
       if constexpr (qb == 0) rd_frag(f + AH);
-#if FA_BW64_WAIT2
       // one wait per TWO fragment slots (as fa_fwd_w64.hip): before the MFMAs of an even slot f, wait until slot f + 1 has landed too
       if constexpr (qb == 0 && (f & 1) == 0 && f + 1 < NF) {
         constexpr auto ops = [](int g) constexpr { return g < 2 * KS ? 1 : g < NF ? 2 : 0; };
         constexpr int out = [&]() constexpr { int n = 0; for (int g = f + 2; g <= f + AH; ++g) n += ops(g); return n; }();
         __builtin_amdgcn_s_waitcnt(0xC07F | (out << 8));
       }
-#endif
       if constexpr (x < QKG) {
         if constexpr (f == 0) mfma_v_first<E, BW_Q_BASE + 4 * (qb * KS)>(s_nxt[qb], fr[f % RNG], nlse[qb]);
         else mfma_v_acc<E, BW_Q_BASE + 4 * (qb * KS + f)>(s_nxt[qb], fr[f % RNG]);
       } else if constexpr (x < 2 * QKG) {
         constexpr int ks = f - KS;
-#if FA_BW64_CDELTA
-        if constexpr (ks == 0) mfma_v_first<E, BW_DO_BASE + 4 * (qb * KS)>(dp_nxt[qb], fr[f % RNG], ndel[qb]);
-#else
         if constexpr (ks == 0) mfma_v_first0<E, BW_DO_BASE + 4 * (qb * KS)>(dp_nxt[qb], fr[f % RNG]);
-#endif
         else mfma_v_acc<E, BW_DO_BASE + 4 * (qb * KS + ks)>(dp_nxt[qb], fr[f % RNG]);
       } else {
         constexpr int op = f - 2 * KS;
         mfma_q_acc<E, qb * DB + op % DB>(fr[f % RNG], f_prev[qb][op / DB]);
       }
-      if constexpr ((x & 1) && (x / 2) < DPW && !(FA_BW64_ABL & 4)) {
+      if constexpr ((x & 1) && (x / 2) < DPW) {
         constexpr int pc = x / 2;
         // (the tile's byte offset rides in the scalar-offset operand, as in fa_fwd_w64.hip: no per-piece address add)
         if constexpr (pc == 0)
@@ -539,17 +501,15 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
         }
         dsv[eq][r] = ds_elem(sv, dp_cur[eq][r], eq);
       }
-      if (!(FA_BW64_ABL & 16)) {
 #pragma unroll
-        for (int c = el_end(x - 1) / 2; c < el_end(x) / 2; ++c) {
-          const int cq = c >> 3, r = 2 * (c & 7);
-          unsigned pw = pack2(dsv[cq][r], dsv[cq][r + 1]);
-          asm volatile("" : "+v"(pw));   // pinned to this gap
-          f_cur[cq][r >> 3][(r & 7) >> 1] = pw;
-        }
+      for (int c = el_end(x - 1) / 2; c < el_end(x) / 2; ++c) {
+        const int cq = c >> 3, r = 2 * (c & 7);
+        unsigned pw = pack2(dsv[cq][r], dsv[cq][r + 1]);
+        asm volatile("" : "+v"(pw));   // pinned to this gap
+        f_cur[cq][r >> 3][(r & 7) >> 1] = pw;
       }
       // carry (fa_fwd_w64.hip): behind this step's last LDS wait the ring is free -- the first AH K-row fragments of the second step (half 1 of the same tile)
-      if constexpr (FA_BW64_CARRY && half == 0 && x >= NG - AH && !(FA_BW64_ABL & 2)) {
+      if constexpr (half == 0 && x >= NG - AH) {
         constexpr int fn = x - (NG - AH);
         fr[fn % RNG] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[fn] + 32 * ROW_BYTES);
       }
@@ -567,11 +527,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
     uf_hi = (a_hi - 1) >> 1;
     if (sk % BN != 0) uf_hi = min(uf_hi, sk / BN - n_min - 2);   // the steady-state DMA does not clamp rows: full tiles only
   }
-#ifdef FA_BW64_NOFAST
-  uf_lo = 1; uf_hi = 0;
-#endif
   auto iter_head = [&](int u) __attribute__((always_inline)) {
-    if ((FA_BW64_ABL & 4) && u > 1) return;
     if (u + 1 < n_tiles) {
       const int nslot = slot_k == RING - 1 ? 0 : slot_k + 1;
       dma_tile(ICw<0>{}, nslot, u + 1);
@@ -587,7 +543,6 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
 #pragma unroll
     for (int db = 0; db < DB; ++db) { ta0[db] += dt; ta1[db] += dt; }
     slot_k = slot_k == RING - 1 ? 0 : slot_k + 1;
-    if (FA_BW64_ABL & 8) return;
     lds_dma_wait_all();
     __syncthreads();
   };
@@ -649,15 +604,6 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
                                sq - row0, lane);
   });
 }
-
-#ifndef FA_EXPERIMENTS
-#define FA_EXPERIMENTS 0   // experiments/build_experiments.py: the measured-and-not-faster variants (dS-spill dQ kernel, 64-keys-per-wave dK/dV kernel) live under experiments/
-#endif
-#if FA_EXPERIMENTS
-#include "../../experiments/fa_bwd_dq_ds.inc.hip"
-#else
-int launch_bwd_dq_ds(const BwdK&, int, int, hipStream_t) { return -2; }   // not in the default build
-#endif
 
 template <typename E, int D, bool FUSE_DELTA>
 static int launch_bwd_dq_w64_f(const BwdK& p, hipStream_t stream) {

@@ -20,15 +20,8 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef FA_ABL
-#define FA_ABL 0  // timing ablations of the steady-state step (results become wrong): see tools/ablate_fwd.sh
-#endif
-#ifndef FA_IL_GENERIC_PIN
-#define FA_IL_GENERIC_PIN 1  // pin the operand prefetch of the generic (head / tail) steps above their MFMAs
-#endif
-#ifndef FA_IL_AHEAD
+// The timing ablations of the steady-state step and the occupancy experiment (extra dynamic LDS) live in experiments/ablations/fa_fwd_il.patch (tools/ablate_fwd.sh).
 #define FA_IL_AHEAD 4  // LDS operand reads issued this many MFMA slots ahead (LDS latency ~130-200 cycles, slot ~35)
-#endif
 
 #include "fa_device.h"
 #include "fa_kernel_params.h"
@@ -199,7 +192,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
       const int row = (wave * QDMA + i) * RPD + d_row;
       const int grow = min(m0 + row, sq - 1);
       const int c = d_pc ^ k_swz_il<D>(row);
-      lds_dma_16B(qp + (int64_t)(FA_ABL == 11 ? 0 : grow) * rs + c * 8, lds + QSTAGE + (wave * QDMA + i) * 1024);
+      lds_dma_16B(qp + (int64_t)grow * rs + c * 8, lds + QSTAGE + (wave * QDMA + i) * 1024);
     }
   }
   const int qbase = QSTAGE + (wave * 32 + qi) * ROW_BYTES + ((hi ^ k_swz_il<D>(qi)) << 4);
@@ -241,7 +234,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
         kfrag[nx % PF] = *(const u32x4 FA_LDS*)(kbuf + (kb_lane ^ (nx << 5)));
         if constexpr (QLDS) qfrag[nx % PF] = *(const u32x4 FA_LDS*)(lds + (qbase ^ (nx << 5)));
       }
-      if (FA_IL_GENERIC_PIN) __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this k-step's MFMA
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this k-step's MFMA
       f32x16 c = s;
       if (ks == 0) {
 #pragma unroll
@@ -268,7 +261,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
         vlo[nx % PFV] = lds_read_tr16(vbuf + (vb_lane ^ ((nx % DB) << 6)) + (16 * (nx / DB)) * ROW_BYTES);
         vhi[nx % PFV] = lds_read_tr16(vbuf + (vb_lane ^ ((nx % DB) << 6)) + (16 * (nx / DB) + 8) * ROW_BYTES);
       }
-      if (FA_IL_GENERIC_PIN) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
       o_acc[i % DB] = T::mfma(combine_tr<V8>(vlo[i % PFV], vhi[i % PFV]), pf[i / DB], o_acc[i % DB]);
     }
   };
@@ -337,13 +330,8 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     };
     // operand reads run AHEAD slots in front of their MFMA over the whole 16-slot sequence
     auto rd_slot = [&](int slot) __attribute__((always_inline)) {
-#if FA_ABL == 4
-      if (slot == 0) { rd_kq(0); } else if (slot == KS) { rd_v(0); } else if (slot < KS) { kfr[slot % RING] = kfr[0]; qfr[slot % RING] = qfr[0]; }
-      else if (slot < KS + NOP) { vlo[(slot - KS) % RING] = vlo[0]; vhi[(slot - KS) % RING] = vhi[0]; }
-#else
       if (slot < KS) rd_kq(slot);
       else if (slot < KS + NOP) rd_v(slot - KS);
-#endif
     };
     const float neg_mc = (m_run == -INFINITY) ? 0.f : -m_run * cs;
     float ps0 = 0.f, ps1 = 0.f;
@@ -358,21 +346,13 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
       }
-#if FA_ABL != 3
       s_nxt = T::mfma(bitcast_u32x4<V8>(kfr[g % RING]), QLDS ? bitcast_u32x4<V8>(qfr[g % RING]) : qreg[QLDS ? 0 : g], c);
-#else
-      asm volatile("" ::"v"(kfr[g % RING]), "v"(qfr[g % RING]));
-#endif
 #pragma unroll
       for (int e = 0; e < EPG; e += 2) {
         const int r = g * EPG + e;
-#if FA_ABL == 1
-        const float p0 = s_cur[r] * cs, p1 = s_cur[r + 1] * cs;
-#else
         // (v_pk_fma_f32 for the scale/subtract pair measured 5 % slower than two v_fma_f32)
         const float p0 = fast_exp2(__builtin_fmaf(s_cur[r], cs, neg_mc));
         const float p1 = fast_exp2(__builtin_fmaf(s_cur[r + 1], cs, neg_mc));
-#endif
         s_cur[r] = p0;
         s_cur[r + 1] = p1;
         ps0 += p0;
@@ -391,11 +371,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 #pragma unroll
     for (int g = 0; g < NOP; ++g) {
       rd_slot(KS + g + AHEAD);
-#if FA_ABL != 2
       o_acc[g % DB] = T::mfma(combine_tr<V8>(vlo[g % RING], vhi[g % RING]), pf_prev[g / DB], o_acc[g % DB]);
-#else
-      asm volatile("" ::"v"(vlo[g % RING]), "v"(vhi[g % RING]));
-#endif
       if constexpr (MASK) {  // mask.h:172-203 predicate on the freshly produced scores, spread over the first slots
         if (g >= 1 && g < 1 + 2) {
 #pragma unroll
@@ -409,7 +385,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) pf_cur[g][jj] = (E)s_cur[8 * g + jj];
       }
-      if (FA_ABL != 6 && g >= (MASK ? 3 : 2)) {  // row-max tree, spread over the remaining slots (2 values per max3)
+      if (g >= (MASK ? 3 : 2)) {  // row-max tree, spread over the remaining slots (2 values per max3)
         constexpr int G0 = MASK ? 3 : 2;
         constexpr int SLOTS = NOP - G0;
         constexpr int PER = (8 + SLOTS - 1) / SLOTS;  // max3 ops per slot
@@ -497,22 +473,13 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
     uf_hi = (a_hi - 1) >> 1;
   }
   auto iter_head = [&](int u) __attribute__((always_inline)) {
-#if FA_ABL == 5
-    if (u > 1) return;
-#endif
     const int par = u & 1;
     if (u + 1 < n_tiles) dma_tile(ICi<0>{}, par ^ 1, u + 1);
     if (u < n_tiles) dma_tile(ICi<1>{}, par, u);
   };
   auto iter_tail = [&]() __attribute__((always_inline)) {
-#if FA_ABL == 7
-    lds_dma_wait_all();
-#elif FA_ABL == 8
-    __syncthreads();
-#elif FA_ABL != 9
     lds_dma_wait_all();  // this wave's DMA pieces have landed ...
     __syncthreads();     // ... and everybody's are visible before the next iteration reads them
-#endif
   };
   if (n_tiles > 0) {
     int u = 0;
@@ -579,8 +546,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   // O tile through LDS (the K/V buffers are free after the last barrier; fa_device.h store_tile_via_lds).  Measured on
   // config 3: the direct epilogue cost ~60 us of the 660 us kernel (tools/overhead_fit.py).
   {
-    if (FA_ABL != 10)
-      store_tile_via_lds<E, D>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op + (int64_t)w_row0 * p.o_rs, p.o_rs, sq - w_row0, lane);
+    store_tile_via_lds<E, D>(lds + wave * 32 * (ROW_BYTES + 16), o_acc, inv, op + (int64_t)w_row0 * p.o_rs, p.o_rs, sq - w_row0, lane);
     if (row_valid && hi == 0) lsep[my_row] = dead ? INFINITY : (m_run * cs * kLn2 + __logf(l_tot));
   }
 }
@@ -593,14 +559,6 @@ static int launch_fwd_il_t(const FwdK& p, hipStream_t stream) {
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
   const long long total = p.work_list ? (long long)p.work_bound * p.h : units_grid(p.n_units, p.unit_size);
   if (total <= 0) return 0;
-#ifdef FA_IL_EXPERIMENTS  // occupancy experiments: extra (unused) dynamic LDS
-  if (knobs().lds_pad > 0) {
-    const int padded = smem + knobs().lds_pad;
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), padded, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-  }
-#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(NW * 64), smem, stream, p);
   if (hipGetLastError() != hipSuccess) return -1;
   LastSchedule& ls = last_schedule();

@@ -47,65 +47,14 @@
 #define FA_W64_CLOB FA_W64_ACC_CLOBBERS
 #include "fa_w64_asm.h"
 
-#ifndef FA_W64_ABL
-#define FA_W64_ABL 0  // timing ablations of the steady-state step, bit mask (results become wrong): tools/ablate_w64.sh
-#endif                // 1 no exp2, 2 no row-sum adds, 4 no packing, 8 no row-max tree, 16 LDS operand reads only once per step,
-                      // 32 no K/V DMA after the first tiles, 64 row-sum adds lag their exp2 by one gap, 128 no LDS operand reads at all,
-                      // 256 LSE output = shader clocks per MFMA of the wave's tile loop, 512 no DMA wait / barrier per tile,
-                      // 1024 no decision (row-max finish + branch), 2048 LSE output = this wave's clock stamps (lane i = stamp i: 0 prologue
-                      // barrier passed, 1 Q converted, 2 K_0 landed, 3 tile loop starts, 4+u iteration u done, 62 O stored), tools/w64_stamps.py; 16384 (with 2048): lanes 59-61 = round, workgroup, block start on the 100 MHz clock (tools/w64_timeline.py)
 
-// Gaps of a step that carry its LDS-DMA pieces (first gap, stride): where a piece is issued prices it between ~30 and ~180 clocks
-// (MI355X_MICROARCH.md "LDS-DMA piece issue cost"; profiles/r03_fwd_w64_dma_placement.txt)
-#ifndef FA_W64_MASKED_COPY
-#define FA_W64_MASKED_COPY 0
-#endif
-#ifndef FA_W64_LAGADD
-#define FA_W64_LAGADD 0   // (1: the row-sum adds lag their exp2 by one gap -- hipcc then places add and v_exp around the same MFMA again and pads it: no gain)
-#endif
-#ifndef FA_W64_WAIT2
-#define FA_W64_WAIT2 1
-#endif
-#ifndef FA_W64_AH
-#define FA_W64_AH (FA_W64_WAIT2 ? 3 : 2)   // LDS operand reads run this many fragment slots (2 gaps each) ahead of their MFMAs
-#endif
-#ifndef FA_W64_KDMA_G0
-#define FA_W64_KDMA_G0 1
-#define FA_W64_KDMA_GS 2
-#endif
-#ifndef FA_W64_VDMA_G0
+// Schedule constants of the hand-placed step (each one the winner of an A/B recorded under profiles/; the timing ablations and the losing variants are
+// applied as experiments/ablations/fa_fwd_w64.patch by tools/ablate_w64.sh -- the product source carries none of them):
+#define FA_W64_AH 3        // LDS operand reads run this many fragment slots (2 gaps each) ahead of their MFMAs, one explicit wait per two slots
+#define FA_W64_KDMA_G0 1   // gaps of a step that carry its LDS-DMA pieces (first gap, stride): where a piece is issued prices it between ~30 and ~180 clocks
+#define FA_W64_KDMA_GS 2   // (MI355X_MICROARCH.md "LDS-DMA piece issue cost"; profiles/r03_fwd_w64_dma_placement.txt)
 #define FA_W64_VDMA_G0 1
 #define FA_W64_VDMA_GS 2
-#endif
-#ifndef FA_W64_STAG
-#define FA_W64_STAG 0      // 1: slot s of a step belongs to wave s % 4 (piece s / 4), 2: to wave s / pieces-per-wave
-#endif
-#ifndef FA_W64_STAG_GS
-#define FA_W64_STAG_GS 1
-#endif
-#ifndef FA_W64_CARRY
-#define FA_W64_CARRY 1   // the first operand reads of an iteration's SECOND step (the other half of the same K tile: already in LDS) are issued in the last gaps of its first step
-#endif                   // instead of at the second step's head, where the first MFMA waits out their LDS round trip (A/B: profiles/r04_fwd_w64_carry.txt)
-#ifndef FA_W64_KV_POLN
-#define FA_W64_KV_POLN 0   // cache-policy bits of the K/V tile DMAs, bit mask: 1 sc0, 2 sc1, 4 nt (A/B in profiles/r04_fwd_w64_dma.txt)
-#endif
-#if FA_W64_KV_POLN == 0
-#define FA_W64_KV_POL ""
-#elif FA_W64_KV_POLN == 1
-#define FA_W64_KV_POL " sc0"
-#elif FA_W64_KV_POLN == 2
-#define FA_W64_KV_POL " sc1"
-#elif FA_W64_KV_POLN == 3
-#define FA_W64_KV_POL " sc0 sc1"
-#elif FA_W64_KV_POLN == 4
-#define FA_W64_KV_POL " nt"
-#elif FA_W64_KV_POLN == 5
-#define FA_W64_KV_POL " sc0 nt"
-#elif FA_W64_KV_POLN == 6
-#define FA_W64_KV_POL " sc1 nt"
-#else
-#define FA_W64_KV_POL " sc0 sc1 nt"
-#endif
 
 namespace fa {
 
@@ -272,16 +221,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   cur_id.b = 0; cur_id.h = 0; cur_id.m_block = 0;
   bool cur_ok = decode_id((int)blockIdx.x, 0, cur_id);
   for (int vb = blockIdx.x, round = 0; vb < n_virtual; vb += gridDim.x, ++round) {
-#if FA_W64_ABL & (256 | 2048)
-  const long long abl_tk = clock64();
-#endif
-#if FA_W64_ABL & 2048
-  int abl_st = 0, abl_n = 4;
-  const long long abl_rt = wall_clock64();   // constant 100 MHz: lane 63 of the stamps = the block's duration in 10 ns units
-#define FA_W64_STAMP(idx_) do { const int sv_ = (int)(clock64() - abl_tk); abl_st = (lane == (idx_)) ? sv_ : abl_st; } while (0)
-#else
-#define FA_W64_STAMP(idx_) ((void)0)
-#endif
   Blk blk = cur_id, nxt;
   const bool blk_ok = cur_ok && fill_blk(blk);
   nxt.b = 0; nxt.h = 0; nxt.m_block = 0;
@@ -353,16 +292,16 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
     if constexpr (DPW == 4) {
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                   "buffer_load_dwordx4 %1, %6, 0 offen" FA_W64_KV_POL " lds" "\n\t"
-                   "buffer_load_dwordx4 %2, %6, 0 offen offset:1024" FA_W64_KV_POL " lds" "\n\t"
-                   "buffer_load_dwordx4 %3, %6, 0 offen offset:2048" FA_W64_KV_POL " lds" "\n\t"
-                   "buffer_load_dwordx4 %4, %6, 0 offen offset:3072" FA_W64_KV_POL " lds" "\n\t"
+                   "buffer_load_dwordx4 %1, %6, 0 offen lds\n\t"
+                   "buffer_load_dwordx4 %2, %6, 0 offen offset:1024 lds\n\t"
+                   "buffer_load_dwordx4 %3, %6, 0 offen offset:2048 lds\n\t"
+                   "buffer_load_dwordx4 %4, %6, 0 offen offset:3072 lds\n\t"
                    "s_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "s"(dst), "s"(srd) : "memory");
     } else {
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                   "buffer_load_dwordx4 %1, %4, 0 offen" FA_W64_KV_POL " lds" "\n\t"
-                   "buffer_load_dwordx4 %2, %4, 0 offen offset:1024" FA_W64_KV_POL " lds" "\n\t"
+                   "buffer_load_dwordx4 %1, %4, 0 offen lds\n\t"
+                   "buffer_load_dwordx4 %2, %4, 0 offen offset:1024 lds\n\t"
                    "s_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(vo[0]), "v"(vo[DPW - 1]), "s"(dst), "s"(srd) : "memory");
     }
@@ -384,14 +323,10 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // vmcnt wait at the tile barriers made them visible), else loaded now.  K_0 rides under the Q conversion.
   // K_0 rides under the Q conversion; V buffer 1 -- which the first two steps of the pipeline multiply by P = 0 -- is zero-filled.
   __syncthreads();
-  FA_W64_STAMP(0);
   if (q_in_lds != vb) dma_q(q_srd_of(blk));
   // (round 4: only K_0 here.  Eight tile DMAs issued back to back cost ~160 clocks each -- the vector-memory queue fills --, 1300 clocks between the barrier
   // and the first LDS read of Q; the zero fill of V buffer 1 is issued between the two halves of the Q conversion instead, profiles/r04_fwd_w64_per_block_code.txt)
   if (n_tiles > 0) dma_tile(ICw<0>{}, 0, tile_of(0));
-#if FA_W64_ABL & 32768
-  FA_W64_STAMP(56);
-#endif
   if (q_in_lds != vb) {   // Q was not prefetched (first block of this workgroup): its pieces were requested first
     if (n_tiles > 0) { if constexpr (DPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }   // (all but K_0's pieces)
     else lds_dma_wait_all();
@@ -426,28 +361,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       load_q(qbc, ICw<0>{}); load_q(qbc, ICw<1>{}); load_q(qbc, ICw<2>{}); load_q(qbc, ICw<3>{});
       if constexpr (KS == 8) { load_q(qbc, ICw<4>{}); load_q(qbc, ICw<5>{}); load_q(qbc, ICw<6>{}); load_q(qbc, ICw<7>{}); }
     };
-#if FA_W64_ABL & 32768   // experiment: the conversion twice (idempotent), lane 58 = end of the first pass: cold vs warm instruction fetch of per-block code
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    FA_W64_STAMP(55);   // Q fragments read from LDS
-    int abl_nrep = 2;
-    asm volatile("" : "+s"(abl_nrep));
-#pragma unroll 1
-    for (int abl_rep = 0; abl_rep < abl_nrep; ++abl_rep) {
-      if (abl_rep == 1) FA_W64_STAMP(58);
-      load_q_all(ICw<0>{});
-      if (abl_rep == 0 && n_tiles > 0) dma_tile(ICw<1>{}, 1, -1);
-      load_q_all(ICw<1>{});
-    }
-#else
     load_q_all(ICw<0>{});
     if (n_tiles > 0) dma_tile(ICw<1>{}, 1, -1);   // V buffer 1 <- zeros (the pipeline's first two steps multiply it by P = 0)
     load_q_all(ICw<1>{});
-#endif
   }
-  FA_W64_STAMP(1);
   lds_dma_wait_all();   // K_0 (requested before the conversion)
   __syncthreads();
-  FA_W64_STAMP(2);
   // Next block's Q rows of this wave -> LDS under this block's tile loop, a few 1-KiB pieces per iteration (each iteration's
   // tile barrier waits for the pieces requested in it).  All of them at once, as in round 2, put 64 KB per CU -- 16 MB across
   // the chip, every workgroup at the same moment -- in front of the first tiles of the loop: 16k clocks to get the requests
@@ -655,17 +574,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     constexpr int NF = KS + 2 * DB;       // fragment slots per step: KS K fragments, then 2*DB V fragments
     static_assert(RING == FA_W64_AH + 1, "the K fragment ring is the caller's (carried from a first step to its second step)");
     s16x4 vlo[RING], vhi[RING];
-    if (FA_W64_ABL & 128) {
-#pragma unroll
-      for (int f = 0; f < RING; ++f) { kfr[f] = pf_prev[0][0]; vlo[f] = __builtin_bit_cast(s16x4, u32x2{pf_prev[0][1][0], pf_prev[0][1][1]}); vhi[f] = vlo[f]; }
-    }
     auto rd_frag = [&](int f) __attribute__((always_inline)) {
-      if (FA_W64_ABL & 128) return;
-      if ((FA_W64_ABL & 16) && f != 0 && f != KS) {
-        if (f < KS) kfr[f % RING] = kfr[0];
-        else if (f < NF) { vlo[f % RING] = vlo[KS % RING]; vhi[f % RING] = vhi[KS % RING]; }
-        return;
-      }
       if (f < KS) {
         kfr[f % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[f] + KOFF);
       } else if (f < NF) {
@@ -683,7 +592,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     constexpr int UPG = PVG >= 16 ? 1 : 2;        // max3 units per gap
     auto tree_g0 = [](int mq) constexpr { return 1 + mq; };   // the chain of block mq retired at gap QKG - 2 + mq
     auto hm_gap = [&](int mq) constexpr { return tree_g0(mq) + 8 / UPG; };           // cross-half combine right after the tree
-    if constexpr (!(FA_W64_CARRY && half == 1)) {   // (second step: its first AH fragments were requested by the first step, see the end of the gap loop)
+    if constexpr (half != 1) {   // (second step: its first AH fragments were requested by the first step, see the end of the gap loop)
 #pragma unroll
       for (int f = 0; f < AH; ++f) rd_frag(f);
     }
@@ -692,7 +601,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       constexpr int x = decltype(xc)::value;
       constexpr int f = x / 2, qb = x & 1;
       if constexpr (qb == 0) rd_frag(f + AH);
-#if FA_W64_WAIT2
       // One wait per TWO fragment slots: before the MFMAs of an even slot f, wait until slot f + 1 has landed too (everything requested
       // after it may still be in flight: slots f + 2 .. f + AH, one LDS instruction per K fragment, two per transposed V fragment).  hipcc
       // models an explicit s_waitcnt and drops its own wait in front of slot f + 1 -- sixteen fewer instructions per iteration.
@@ -701,7 +609,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
         constexpr int out = [&]() constexpr { int n = 0; for (int g = f + 2; g <= f + AH; ++g) n += ops(g); return n; }();
         __builtin_amdgcn_s_waitcnt(0xC07F | (out << 8));
       }
-#endif
       if constexpr (x < QKG) {
         if constexpr (f == 0) mfma_s_first<E, qb * KS>(s_nxt[qb], kfr[f % RING], negm[qb]);
         else mfma_s_acc<E, qb * KS + f>(s_nxt[qb], kfr[f % RING]);
@@ -712,33 +619,13 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       }
       // this step's DMA pieces (K_{u+1} in the first step of an iteration, V_u in the second): gaps G0, G0 + GS, ..
       constexpr int G0 = half == 0 ? FA_W64_KDMA_G0 : FA_W64_VDMA_G0, GS = half == 0 ? FA_W64_KDMA_GS : FA_W64_VDMA_GS;
-#if FA_W64_STAG
-      // wave-staggered slots: at most one wave of the workgroup issues a piece in any gap (the four waves run in lock step behind the tile
-      // barrier, so same-gap pieces queue behind each other at the CU's one vector-memory path)
-      constexpr int SG = FA_W64_STAG_GS;   // gaps between slots
-      if constexpr (x % SG == 0 && x / SG < NW * DPW && !(FA_W64_ABL & 32)) {
-        constexpr int sl = x / SG;
-        constexpr int own = FA_W64_STAG == 1 ? sl % NW : sl / DPW, pc = FA_W64_STAG == 1 ? sl / NW : sl % DPW;
-        int wv = wave;
-        asm volatile("" : "+s"(wv));   // (compared here, as a scalar: hoisted, the sixteen compares become lane masks and cost two VALU per slot)
-        if (wv == own) {
-          if constexpr (pc == 0)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen" FA_W64_KV_POL " lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
-          else
-            asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2" FA_W64_KV_POL " lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
-        }
-      }
-      if constexpr (false) {
-        constexpr int pc = 0;
-#else
-      if constexpr (x >= G0 && (x - G0) % GS == 0 && (x - G0) / GS < DPW && !(FA_W64_ABL & 32)) {
+      if constexpr (x >= G0 && (x - G0) % GS == 0 && (x - G0) / GS < DPW) {
         constexpr int pc = (x - G0) / GS;
-#endif
         // (the tile's byte offset rides in the scalar-offset operand; the range check accounts for it: tools/ubench/lds_dma_oob.hip)
         if constexpr (pc == 0)
-          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen" FA_W64_KV_POL " lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(dma_off[pc]), "s"(dma_dst), "s"(dma_srd), "s"(dma_toff) : "memory");
         else
-          asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2" FA_W64_KV_POL " lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
+          asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2 lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
       }
       if constexpr (ALIBI) {   // the C broadcasts move on to the next step's keys (the other half of the tile: +32 keys; the next tile down: -96): 32 in-place adds
         constexpr auto ab_end = [](int g) constexpr { return g < 4 ? 0 : (((g - 3) * 32 + (NG - 5)) / (NG - 4) > 32 ? 32 : ((g - 3) * 32 + (NG - 5)) / (NG - 4)); };
@@ -754,26 +641,15 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #pragma unroll
       for (int e = el_end(x); e < el_end(x + 1); ++e) {
         const int eq = e >> 4, r = e & 15;
-        pe[eq][r] = (FA_W64_ABL & 1) ? s_cur[eq][r] : fast_exp2(s_cur[eq][r]);
-        if (!(FA_W64_ABL & 2) && !FA_W64_LAGADD) l_run[eq][r & 1] += pe[eq][r];
-#if FA_W64_STAG
-        asm volatile("" : "+v"(pe[eq][r]), "+v"(l_run[eq][r & 1]));   // (the slot branches end basic blocks: keep the gap's VALU in its gap)
-#endif
-      }
-      // (experiment: the row-sum adds lag their exp2 by one gap -- an add right behind the v_exp that feeds it costs a wait state, which hipcc
-      // pads with an s_nop even across the asm MFMA)
-      if (FA_W64_LAGADD && !(FA_W64_ABL & 2) && x > 0) {
-#pragma unroll
-        for (int e = el_end(x - 1); e < el_end(x); ++e) {
-          l_run[e >> 4][e & 1] += pe[e >> 4][e & 15];
-        }
+        pe[eq][r] = fast_exp2(s_cur[eq][r]);
+        l_run[eq][r & 1] += pe[eq][r];
       }
       if constexpr (x >= QKG) {
         constexpr int y = x - QKG;  // gap inside the PV half
         // packing of P_i: PVG gaps, 16 conversions (one packed register each)
         constexpr int CPG = 16 / PVG > 0 ? 16 / PVG : 1;
 #pragma unroll
-        for (int c = y * CPG; c < (y + 1) * CPG && c < 16 && !(FA_W64_ABL & 4); ++c) {
+        for (int c = y * CPG; c < (y + 1) * CPG && c < 16; ++c) {
           const int j = c >> 2, m = c & 3, cq = j >> 1, t = j & 1;
           using V2 = __attribute__((ext_vector_type(2))) E;
           V2 pr;
@@ -787,10 +663,10 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #pragma unroll
         for (int mq = 0; mq < QB; ++mq) {
           const int g0 = tree_g0(mq);
-          if (y >= g0 && y < g0 + 8 / UPG && !(FA_W64_ABL & 8)) {
+          if (y >= g0 && y < g0 + 8 / UPG) {
 #pragma unroll
             for (int u = (y - g0) * UPG; u < (y - g0 + 1) * UPG; ++u)  // 16 values in 8 ops: max3(s0,s1,s2), 6 x max3(t,.,.), max(t,s15)
-              if (u == 7 && UPG == 1 && !(FA_W64_ABL & 1024)) {   // the tree's last maximum and the copy for the cross-half swap in one statement (no pad between them)
+              if (u == 7 && UPG == 1) {   // the tree's last maximum and the copy for the cross-half swap in one statement (no pad between them)
                 float t_in = tmax[mq], t_out, t_cp;
                 asm volatile("v_max_f32 %0, %2, %3\n\tv_mov_b32 %1, %0" : "=&v"(t_out), "=v"(t_cp) : "v"(t_in), "v"(s_nxt[mq][15]));
                 tmax[mq] = t_out; tcopy[mq] = t_cp;
@@ -800,29 +676,23 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
           }
           // cross-half combine in two statements a gap apart: the copy, then swap + max (v_permlane32_swap wants two wait states
           // after the write of its operand: the gap's other instructions provide them, no s_nop)
-          if (y == hm_gap(mq) - 1 && UPG != 1 && !(FA_W64_ABL & (8 | 1024))) asm volatile("v_mov_b32 %0, %1" : "=v"(tcopy[mq]) : "v"(tmax[mq]));
-          if (y == hm_gap(mq) && !(FA_W64_ABL & (8 | 1024)))
+          if (y == hm_gap(mq) - 1 && UPG != 1) asm volatile("v_mov_b32 %0, %1" : "=v"(tcopy[mq]) : "v"(tmax[mq]));
+          if (y == hm_gap(mq))
             asm volatile("v_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(tmax[mq]), "+v"(tcopy[mq]));
         }
       }
       // carry: behind this step's last LDS wait (gap NG - 4: slot NF - 2, everything landed) the K ring is free -- request the first AH fragments of the SECOND
       // step's score chain (half 1 of the same K tile), one per gap; that step's waits count them exactly as if it had issued them itself
-      if constexpr (FA_W64_CARRY && half == 0 && x >= NG - AH && !(FA_W64_ABL & 128)) {
+      if constexpr (half == 0 && x >= NG - AH) {
         constexpr int fn = x - (NG - AH);
         kfr[fn % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[fn] + par * TILE_BYTES + 32 * ROW_BYTES);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    if (FA_W64_LAGADD && !(FA_W64_ABL & 2)) {   // the last gap's elements
 #pragma unroll
-      for (int e = el_end(NG - 1); e < el_end(NG); ++e) l_run[e >> 4][e & 1] += pe[e >> 4][e & 15];
-    }
-    if (!(FA_W64_ABL & 1024)) {
-#pragma unroll
-      for (int mq = 0; mq < QB; ++mq)
-        if (hm_gap(mq) >= PVG && !(FA_W64_ABL & 8)) tmax[mq] = vhalf_max(tmax[mq]);   // (no gap left for it)
-      decide_and_rescale(tmax, s_nxt);
-    }
+    for (int mq = 0; mq < QB; ++mq)
+      if (hm_gap(mq) >= PVG) tmax[mq] = vhalf_max(tmax[mq]);   // (no gap left for it)
+    decide_and_rescale(tmax, s_nxt);
   };
 
   // Iteration u (0 .. n_tiles) = two steps: 2u-1 and 2u score K_u (K buffer u & 1) and multiply by V_{u-1} (V buffer (u - 1) & 1);
@@ -859,21 +729,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   }
   u_first = __builtin_amdgcn_readfirstlane(u_first); u_last = __builtin_amdgcn_readfirstlane(u_last);   // (wave-uniform by construction; said so)
   const unsigned wave_dst = (unsigned)(wave * DPW * 1024);
-#if FA_W64_ABL & 256
-  const long long abl_t0 = clock64();
-#endif
-  FA_W64_STAMP(3);
   auto iter_end = [&]() __attribute__((always_inline)) {
-    if (!(FA_W64_ABL & 512)) {
-      lds_dma_wait_all();
-      __syncthreads();
-    }
-#if FA_W64_ABL & 2048
-    if (abl_n < 62) { FA_W64_STAMP(abl_n); ++abl_n; }
-#endif
+    lds_dma_wait_all();
+    __syncthreads();
   };
   // Active iterations outside [m_lo, m_hi] hold a step that straddles a mask boundary
-  const int m_lo = __builtin_amdgcn_readfirstlane((FA_W64_ABL & 4096) ? 0 : p_lo), m_hi = __builtin_amdgcn_readfirstlane((FA_W64_ABL & 4096) ? 0x3fffffff : p_hi);
+  const int m_lo = __builtin_amdgcn_readfirstlane(p_lo), m_hi = __builtin_amdgcn_readfirstlane(p_hi);
   const unsigned step_k = (unsigned)(BN * 2) * (unsigned)p.k_rs, step_v = (unsigned)(BN * 2) * (unsigned)p.v_rs;
   const int nmin_s = __builtin_amdgcn_readfirstlane(n_min), nts_s = __builtin_amdgcn_readfirstlane(n_tiles);
   auto step_pair = [&](auto parc, int u) __attribute__((always_inline)) {
@@ -896,32 +757,16 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     asm volatile("" : "+s"(tk_), "+s"(tv_), "+s"(dst_k), "+s"(dst_v), "+s"(im32));
     // (each test on a freshly laundered scalar: as one hoisted boolean hipcc keeps a lane mask and spends five instructions per test)
     auto masked = [&]() __attribute__((always_inline)) { int c = im32; asm volatile("" : "+s"(c)); return c != 0; };
-#if FA_W64_MASKED_COPY
-    // (experiment, off: one test per iteration, the masked iteration as a cold COPY of the two steps with the mask rewrites around them.  As with
-    // every step-variant attempt before it the copies' tuples meet the hot ones at the join: 75 vector spills, 160 bytes of scratch, v_accvgpr
-    // traffic in the copies and eight more pad s_nop in the hot steps.)
-    if (__builtin_expect(masked(), 0)) {
-      set_mask(2 * u);
-      fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k, kring);
-      set_mask(2 * u + 1);
-      fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v, kring);
-      clear_mask(2 * u + 2);
-    } else {
-      fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k, kring);
-      fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v, kring);
-    }
-#else
     if (__builtin_expect(masked(), 0)) set_mask(2 * u);
     fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k, kring);
     if (__builtin_expect(masked(), 0)) set_mask(2 * u + 1);
     fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v, kring);
     if (__builtin_expect(masked(), 0)) clear_mask(2 * u + 2);
-#endif
     iter_end();
   };
   auto idle_iter = [&](int u) __attribute__((always_inline)) {
     q_trickle();
-    if (!(FA_W64_ABL & 32) || u <= 1) { dma_tile(ICw<0>{}, (u & 1) ^ 1, tile_of(u + 1)); dma_tile(ICw<1>{}, u & 1, tile_of(u)); }
+    dma_tile(ICw<0>{}, (u & 1) ^ 1, tile_of(u + 1)); dma_tile(ICw<1>{}, u & 1, tile_of(u));
     iter_end();
   };
   if (n_tiles > 0) {
@@ -946,10 +791,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     for (; u <= n_tiles; ++u) idle_iter(u);
   }
 
-#if FA_W64_ABL & 256
-  const long long abl_t1 = clock64();
-  const float abl_ticks = (float)(abl_t1 - abl_t0) / (float)(n_tiles > 0 ? n_tiles * 16 * DB : 1);
-#endif
   if (wave_valid) {
   mfma_drain_acc();
   u32x4 o_srd;
@@ -963,13 +804,6 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   }
   // O tile through LDS (the K/V buffers are free after the last tile barrier; the Q region may already hold the next block's
   // rows and is not touched): whole-row stores
-#if FA_W64_ABL & 32768   // experiment: the epilogue twice (idempotent), lane 57 = end of the first pass
-  int abl_erep = 2;
-  asm volatile("" : "+s"(abl_erep));
-#pragma unroll 1
-  for (int abl_e = 0; abl_e < abl_erep; ++abl_e) {
-  if (abl_e == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FA_W64_STAMP(57); }
-#endif
   static_for<QB>([&](auto qbc) __attribute__((always_inline)) {
     constexpr int qb = decltype(qbc)::value;
     f32x16 o_v[DB];
@@ -1011,31 +845,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging rows are rewritten by the next query block
       }
       const int my_row = row0 + qi;
-#if FA_W64_ABL & 256   // rows = 0 mod 4: clocks per MFMA of the tile loop; 1: prologue clocks; 2: tile-loop clocks; 3: epilogue clocks so far
-      if (my_row < sq && hi == 0) {
-        const int sel = my_row & 3;
-        lsep[my_row] = sel == 0 ? abl_ticks : sel == 1 ? (float)(abl_t0 - abl_tk) : sel == 2 ? (float)(abl_t1 - abl_t0) : (float)(clock64() - abl_t1);
-      }
-#elif FA_W64_ABL & 2048
-      if (qb == QB - 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        FA_W64_STAMP(62);
-        abl_st = (lane == 63) ? (int)(wall_clock64() - abl_rt) : abl_st;
-#if FA_W64_ABL & 16384   // timeline (tools/w64_timeline.py): these lanes are iteration stamps of blocks with more than 54 iterations otherwise
-        abl_st = (lane == 61) ? (int)(abl_rt & 0x3fffff) : abl_st;   // block start on the chip-wide 100 MHz clock (low 22 bits: exact in an fp32)
-        abl_st = (lane == 60) ? (int)blockIdx.x : abl_st;            // workgroup (persistent launch: the CU slot)
-        abl_st = (lane == 59) ? round : abl_st;
-#endif
-        if (w_row0 + lane < sq) lsep[w_row0 + lane] = (float)abl_st;
-      }
-#else
       if (my_row < sq && hi == 0) lsep[my_row] = dead ? INFINITY : (m_run[qb] * kLn2 + __logf(l_tot));
-#endif
     }
   });
-#if FA_W64_ABL & 32768
-  }
-#endif
   }  // wave_valid
   }  // persistent block loop
 }

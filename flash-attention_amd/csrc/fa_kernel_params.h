@@ -59,8 +59,8 @@ struct FwdK {
   float rp_keep;             // 1 / (1 - p_dropout)
 };
 
-// Fused backward (BwdK::fuse_sync, fa_bwd.hip fa_bwd_fused_kernel): int32 words of the sync area.  An error flag, 16 words of statistics (FA_FZ_STATS
-// builds), then eight control blocks -- one per XCD x, whose key-block items are those numbered x + 8k: the ready queue's tail, head and count of published
+// Fused backward (BwdK::fuse_sync, fa_bwd.hip fa_bwd_fused_kernel): int32 words of the sync area.  An error flag, 16 words reserved for the cycle statistics of
+// experiments/ablations/fa_bwd.patch, then eight control blocks -- one per XCD x, whose key-block items are those numbered x + 8k: the ready queue's tail, head and count of published
 // and unclaimed dQ items, the count of key-block items finished, the next key-block item to hand out, a 128-byte line each -- then one arrival counter per
 // dQ item (batch, head, 256-query block), BwdK::fuse_line words apart (32 = a line each), then the eight queues (item + 1; 0 = not published yet),
 // fuse_items words each.  Zeroed before every launch.

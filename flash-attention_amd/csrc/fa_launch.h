@@ -14,13 +14,12 @@ struct Knobs {
   int varlen_list;     // FA_VARLEN_LIST: 0 = always the dense varlen grid
   int il_sched;        // FA_IL_SCHED: 0 = compiler-ordered pipelined step, else hand-placed slots
   int bwd_dq_nw;       // FA_BWD_DQ_NW: 0 = heuristic; recomputing dQ kernel of 4 or 8 waves x 32 rows, 64 = 4 waves x 64 rows (fa_bwd_w64.hip)
-  int bwd_dkdv;        // FA_BWD_DKDV: 0 = heuristic; 8 = eight waves x 32 keys (fa_bwd.hip), 64 = four waves x 64 keys, software-pipelined (fa_bwd_dkdv64.hip)
-  int bwd_mode;        // FA_BWD_MODE: 0 / 1 = the dQ kernel recomputes S, dP, dS (7 contractions, no O(S^2) scratch); 2 (experiments/ build only) = the dK/dV
-                       // kernel spills dS and a second kernel computes dQ = dS.K; 3 = the same 5 contractions in ONE persistent launch (fa_bwd.hip
-                       // fa_bwd_fused_kernel): plain attention, head dim 64 / 128, fixed-length batches, no left window, whose dS workspace fits FA_BWD_DS_CAP_MB
+  int bwd_dkdv;        // FA_BWD_DKDV: 0 = heuristic; 8 = eight waves x 32 keys (fa_bwd.hip), 64 = four waves x 64 keys, software-pipelined (fa_bwd_dkdv_w64.hip)
+  int bwd_mode;        // FA_BWD_MODE: 0 / 1 = the dQ kernel recomputes S, dP, dS (7 contractions, no O(S^2) scratch); 3 = the dK/dV part hands dS over and dQ = dS.K
+                       // (5 contractions) in ONE persistent launch (fa_bwd.hip fa_bwd_fused_kernel): plain attention, head dim 64 / 128, fixed-length batches, no
+                       // left window, whose dS workspace fits FA_BWD_DS_CAP_MB.  (2 = the two-launch dS spill: experiments/ds_spill.patch only)
   int fz_line;         // FA_FZ_LINE: fused backward, int32 words between two arrival counters of the sync area (default 32 = one 128-byte line each)
-  int bwd_ds_cap_mb;   // FA_BWD_DS_CAP_MB: largest dS workspace FA_BWD_MODE=2 / 3 ask for (default 8192)
-  int lds_pad;         // FA_IL_LDS_PAD (occupancy experiments, FA_IL_EXPERIMENTS builds only)
+  int bwd_ds_cap_mb;   // FA_BWD_DS_CAP_MB: largest dS workspace FA_BWD_MODE=3 asks for (default 8192)
   int w64_persist;     // FA_W64_PERSIST: 0 = one workgroup per block (no persistent walk) in the 64-rows-per-wave forward
   int pack_gqa;        // FA_PACK_GQA: 0 = never pack the query heads of a KV group into the rows of a block on the KV-cache path (A/B, tests)
   int dkdv_prescale;   // FA_DKDV_PRESCALE=1: the plain dK/dV kernel pre-scales K by softmax_scale*log2e (rounded to the input dtype; ~3 % faster, fa_bwd.hip: PRE);
@@ -41,7 +40,7 @@ struct LastSchedule {
   int d, bf16;
   int bwd_dq_nw, bwd_list, bwd_spill;
   int fwd_pack;     // query heads packed into the rows (FwdK::pack_g)
-  int bwd_dkdv_nw;  // dK/dV schedule: 8 = eight waves x 32 keys (4 at head dim 256), 64 = four waves x 64 keys (fa_bwd_dkdv64.hip)
+  int bwd_dkdv_nw;  // dK/dV schedule: 8 = eight waves x 32 keys (4 at head dim 256), 64 = four waves x 64 keys (fa_bwd_dkdv_w64.hip)
   char name[96];
 };
 LastSchedule& last_schedule();
@@ -132,8 +131,7 @@ int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_fused(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);   // fa_bwd.hip (FA_BWD_PART=3): dK/dV + dQ = dS.K in one launch; -2 = does not apply
 int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_dq_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
-int launch_bwd_dkdv_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);   // fa_bwd_dkdv64.hip: 64 keys per wave, software-pipelined; -2 = not covered
-int launch_bwd_dq_ds(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);    // fa_bwd_w64.hip: dQ = dS.K from the spilled dS   // fa_bwd_w64.hip; -2 = shape / feature not covered
+int launch_bwd_dkdv_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);   // fa_bwd_dkdv_w64.hip: 64 keys per wave, software-pipelined; -2 = not covered
 int bwd_block_m(int dq_nw);   // query rows per dQ workgroup of schedule dq_nw (BwdK::dq_nw)
 int bwd_block_n(int d);   // key rows per dK/dV workgroup (256; 128 for head dim 256)
 

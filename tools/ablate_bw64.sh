@@ -4,13 +4,13 @@
 # (results of the ablated builds are wrong by construction).
 set -e
 cd "$(dirname "$0")/.."
-PKG=flash-attention_amd
+. tools/ablate_common.sh
 MASKS="${MASKS:-0 1 2 4 8 16 31}"
 if [ "$1" != "run" ]; then
-  mkdir -p gpurun_abl
+  SRC=$(abl_source fa_bwd_w64.hip)
   for m in $MASKS; do
-    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -DFA_BW64_ABL=$m $EXTRA -c $PKG/csrc/fa_bwd_w64.hip -o gpurun_abl/bw64_$m.o &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_bwabl_$m.so $PKG/csrc/fa_fwd_bf16.o $PKG/csrc/fa_fwd_f16.o $PKG/csrc/fa_fwd_il.o $PKG/csrc/fa_fwd_w64_bf16.o $PKG/csrc/fa_fwd_w64_f16.o $PKG/csrc/fa_bwd_dkdv.o $PKG/csrc/fa_bwd_dq.o gpurun_abl/bw64_$m.o $PKG/csrc/fa_api.o && rm gpurun_abl/bw64_$m.o ) &
+    ( $HIPCC -fno-slp-vectorize -DFA_BW64_ABL=$m $EXTRA -c $SRC -o gpurun_abl/bw64_$m.o &&
+      abl_link gpurun_abl/libfa_bwabl_$m.so fa_bwd_w64.o gpurun_abl/bw64_$m.o && rm gpurun_abl/bw64_$m.o ) &
   done
   wait
   ls -la gpurun_abl

@@ -3,15 +3,14 @@
 # `tools/ablate_dkdv64.sh run` on the GPU box reports the kernel's duration under rocprofv3 for each (builds with -DFA_DKDV64_ABL compute wrong results).
 set -e
 cd "$(dirname "$0")/.."
-PKG=flash-attention_amd
+. tools/ablate_common.sh
 VARIANTS="${VARIANTS:-base:}"
-OBJS="fa_fwd_bf16.o fa_fwd_f16.o fa_fwd_il.o fa_fwd_w64_bf16.o fa_fwd_w64_f16.o fa_bwd_dkdv.o fa_bwd_dq.o fa_bwd_fused.o fa_bwd_w64.o fa_api.o"
 if [ "$1" != "run" ]; then
-  mkdir -p gpurun_abl
+  SRC=$(abl_source fa_bwd_dkdv_w64.hip)
   for v in $VARIANTS; do
     name=${v%%:*}; flags=$(echo "${v#*:}" | tr ',' ' ')
-    ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c $PKG/csrc/fa_bwd_dkdv_w64.hip -o gpurun_abl/dk64_$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Spill|Scratch" | sort | uniq -c | tr '\n' ' '; echo " <- $name";
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_dk64_$name.so $(for o in $OBJS; do echo $PKG/csrc/$o; done) gpurun_abl/dk64_$name.o && rm gpurun_abl/dk64_$name.o ) &
+    ( $HIPCC -fno-slp-vectorize $flags -c $SRC -o gpurun_abl/dk64_$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Spill|ScratchSize" | sort | uniq -c | sed "s/^/$name: /" ;
+      abl_link gpurun_abl/libfa_dk64_$name.so fa_bwd_dkdv_w64.o gpurun_abl/dk64_$name.o && rm gpurun_abl/dk64_$name.o ) &
   done
   wait
   ls gpurun_abl

@@ -6,21 +6,20 @@
 #   VARIANTS="name:flags;..."    arbitrary -D variants, e.g. "k28:-DFA_W64_KDMA_G0=28 -DFA_W64_KDMA_GS=1"
 set -e
 cd "$(dirname "$0")/.."
-PKG=flash-attention_amd
+. tools/ablate_common.sh
 MASKS="${MASKS-0 1 2 4 8 16 32 64 3 15 31 63}"
 LIST=""
 for m in $MASKS; do LIST="$LIST;abl_$m:-DFA_W64_ABL=$m"; done
 LIST="$LIST;$VARIANTS"
-OTHERS="$PKG/csrc/fa_fwd_bf16.o $PKG/csrc/fa_fwd_f16.o $PKG/csrc/fa_fwd_il.o $PKG/csrc/fa_bwd_dkdv.o $PKG/csrc/fa_bwd_dq.o $PKG/csrc/fa_bwd_w64.o $PKG/csrc/fa_api.o"
 
 IFS=';'
 if [ "$1" != "run" ]; then
-  mkdir -p gpurun_abl
+  SRC=$(abl_source fa_fwd_w64.hip)
   for v in $LIST; do
     [ -z "$v" ] && continue
     name="${v%%:*}"; flags="${v#*:}"
-    ( IFS=' '; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c $PKG/csrc/fa_fwd_w64.hip -o gpurun_abl/w64_$name.o &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_abl/libfa_$name.so gpurun_abl/w64_$name.o $OTHERS && rm gpurun_abl/w64_$name.o ) &
+    ( IFS=' '; $HIPCC -fno-slp-vectorize -DFA_W64_PART=1 $flags -c $SRC -o gpurun_abl/w64_$name.o &&
+      abl_link gpurun_abl/libfa_$name.so fa_fwd_w64_bf16.o gpurun_abl/w64_$name.o && rm gpurun_abl/w64_$name.o ) &
   done
   wait
   ls -la gpurun_abl

@@ -76,7 +76,7 @@ def timings():
         print(line, flush=True)
 
 def stats():
-    """Library built with -DFA_FZ_STATS=1 (tools/ablate_fused.sh): where the fused launch spends its workgroups' cycles."""
+    """Library built with EXTRA=-DFA_FZ_STATS=1 tools/ablate_fused.sh (experiments/ablations/fa_bwd.patch): where the fused launch spends its workgroups' cycles."""
     last = {}
     orig = be._run_bwd
     def keep(a, device, varlen):

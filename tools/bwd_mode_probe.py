@@ -1,5 +1,5 @@
 """Does the dS-spill (5-contraction) backward win when its dS fits the 256 MB Infinity Cache?  FA_BWD_MODE=0 (7 contractions) vs 2 at growing dS footprints
-(library built with -DFA_EXPERIMENTS=1, FA_GFX950_LIB).  dS touched under a causal mask = B*H*S*S bytes (bf16, half of the square)."""
+(experiments/build_experiments.py's library, FA_GFX950_LIB).  dS touched under a causal mask = B*H*S*S bytes (bf16, half of the square)."""
 import os, sys, statistics
 sys.path.insert(0, "flash-attention_amd")
 import torch
