@@ -361,13 +361,19 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
 // dQ schedule (fa_launch.h Knobs::bwd_dq_nw).  Measured on MI355X (profiles/r02_bwd_schedules.txt): the 64-rows-per-wave
 // kernel wins from ~2k keys at head dim 128 (config 3: dQ 955 vs 997 us, S = 16k non-causal 1383 vs 1584 us) and loses on
 // short sequences, where its 256-row blocks leave CUs idle.
+// What the 64-per-wave backward kernels cover besides plain attention: ALiBi under a causal right bound (the bias is linear in the key there)
+bool bwd_w64_features_ok(const FaBwdParams* a) {
+  if (a->softcap > 0.f || a->p_dropout > 0.f) return false;
+  return !a->alibi_slopes || a->is_causal || a->window_right == 0;
+}
+
 int bwd_dq_schedule(const FaBwdParams* a) {
   // trimmed head dims (32 / 96 / 192), head dims between the built sizes and head dim 256 only have the 4-wave, 128-row dQ kernel
   // (fa_bwd.hip: launch_dq_f): the block size fill_bwd / bwd_list_entries derive from the schedule has to be that kernel's, whatever the knob says
   if (head_dim_trimmed(head_dim_kernel(a->d)) || !head_dim_native(a->d) || a->d > 128) return 4;
   const int knob = fa::knobs().bwd_dq_nw;
   if (knob == 4 || knob == 8 || knob == 64) return knob;
-  const bool plain = a->softcap <= 0.f && !a->alibi_slopes && a->p_dropout <= 0.f;
+  const bool plain = bwd_w64_features_ok(a);
   if (a->d == 64) {
     // round 4 (profiles/r04_bwd_schedules.txt): at head dim 64 the 64-rows-per-wave kernel wins from ~2k visible keys per query row ON AVERAGE -- non-causal
     // S >= 2048 (+5.5 .. +7.5 % on the whole backward), causal S >= 8192 (+5.6 .. +7.4 %); it ties at causal S = 4096 and loses below
@@ -381,12 +387,12 @@ int bwd_dq_schedule(const FaBwdParams* a) {
   return (a->d == 128 && plain && a->seqlen_k >= 2048 && a->seqlen_q >= 512) ? 64 : 4;
 }
 
-// dK/dV schedule (fa_launch.h Knobs::bwd_dkdv): 64 = four waves x 64 keys (fa_bwd_dkdv_w64.hip; plain attention at head dim 64 / 128), 8 = eight waves x 32 keys
+// dK/dV schedule (fa_launch.h Knobs::bwd_dkdv): 64 = four waves x 64 keys (fa_bwd_dkdv_w64.hip; plain attention or causal ALiBi at head dim 64 / 128), 8 = eight waves x 32 keys
 // (fa_bwd.hip: every feature variant, head dim 256, trimmed head dims).  Measured (profiles/r05_bwd_dkdv_w64.txt): at head dim 128 the 64-keys-per-wave kernel
 // wins from 2k query rows per key block (+1 % at S = 2048, +3 .. +6 % on the whole backward from S = 4096, GQA included) and loses below (its pipeline fill /
 // drain and 160 KB of LDS per workgroup cost more than they save on a short walk); at head dim 64 it ties or loses everywhere.
 int bwd_dkdv_schedule(const FaBwdParams* a) {
-  const bool plain = a->softcap <= 0.f && !a->alibi_slopes && a->p_dropout <= 0.f;
+  const bool plain = bwd_w64_features_ok(a);
   if (!plain || !head_dim_native(a->d) || head_dim_trimmed(head_dim_kernel(a->d)) || (a->d != 128 && a->d != 64)) return 8;
   const int knob = fa::knobs().bwd_dkdv;
   if (knob == 8 || knob == 64) return knob;

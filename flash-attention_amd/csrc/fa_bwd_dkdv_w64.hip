@@ -63,7 +63,11 @@ template <typename E, int T> FA_DEVINL void kv_mfma_tile(u32x4 a, u32x4 b) {
 
 }  // namespace
 
-template <typename E, int D>
+// ALIBI (under a causal right bound, where the bias -slope * |key - row - shift| is linear in the key): the exponent of P gets slope*log2e * (key - row - shift).
+// With q0 = the tile's first row: the row's part, -slope * (row - q0), rides with -LSE in the score chains' C operand (stream_aux), the key's part,
+// slope*log2e * (key - q0 - shift) -- one value per lane, key block and tile, from an integer difference --, is the addend of the fused multiply-add that
+// applies scale*log2e (a plain multiply without ALiBi): no instruction per element.  The slopes of the group's query heads wait in a small LDS table.
+template <typename E, int D, bool ALIBI>
 __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
@@ -79,6 +83,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   // lane-linear LDS region and are read back one k-step ahead (KL fragments, 1 KiB each per wave)
   constexpr int KL = D == 128 ? KS - 1 : 0;
   constexpr int OFF_KX = OFF_AUX + NSLOT * AUX_SLOT;
+  constexpr int OFF_TAB = OFF_KX + NW * KL * 1024;   // (ALIBI) slope*log2e of the group's query heads, hk_ratio + 1 words
   constexpr int RPD = 1024 / ROW_BYTES;       // tile rows per 1-KiB DMA piece
   constexpr int NP = QT / 1024, PW = NP / NW; // pieces per operand / per wave
   static_assert(D == 128 || D == 64, "head dims of this schedule: 64, 128");
@@ -158,6 +163,10 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
       *(u32x4 FA_LDS*)(lds + OFF_V + tile_off<D>(row, ch)) = x;
     }
   }
+  if constexpr (ALIBI) {
+    for (int i = tid; i <= p.hk_ratio; i += 256)   // (one word past the last head: the drain step's preload reads it and nobody uses it)
+      *(float FA_LDS*)(lds + OFF_TAB + 4 * i) = p.alibi[(int64_t)b * p.alibi_bs + min(hk * p.hk_ratio + i, p.h - 1)] * 1.4426950408889634f;
+  }
 
   // ---- tile stream: Q / dO tiles by LDS-DMA through buffer descriptors of the head's rows (rows past the sequence end are outside the range and arrive as
   // zeros), swizzle on the source chunk (the LDS image is lane-linear); -LSE*log2e and -delta of the tile's rows through a register of wave 0.
@@ -186,8 +195,11 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   int t2 = 0, s_h = 0, s_mt = mt_first, s_left = __builtin_amdgcn_readfirstlane(nm);
   u32x4 q_srd = {0u, 0u, 0u, 0x00020000u}, do_srd = q_srd;
   const float* aux_h = p.lse;   // per lane: lanes 0-31 the head's LSE rows, lanes 32-63 its delta rows
+  float s_slope = 0.f;          // (ALIBI) slope of the stream's head
+  const float kif = (float)ki;
   auto stream_head = [&]() __attribute__((always_inline)) {
     const int h = hk * p.hk_ratio + s_h;
+    if constexpr (ALIBI) s_slope = p.alibi[(int64_t)b * p.alibi_bs + h];
     q_srd = make_srd((const E*)p.q + q_boff + q_row0 * p.q_rs + (int64_t)h * p.q_hs, p.q_rs);
     do_srd = make_srd((const E*)p.dout + do_boff + q_row0 * p.do_rs + (int64_t)h * p.do_hs, p.do_rs);
     const int64_t base = p.cu_q ? ((int64_t)h * p.total_q + q_row0) : (((int64_t)b * p.h + h) * p.sq);
@@ -232,8 +244,9 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   auto stream_aux = [&](const Strm& z) __attribute__((always_inline)) {
     const int r = z.m0 + ki;
     const int lim = z.real ? sq : 0;
-    const float x = aux_h[max(min(r, sq - 1), 0)];
+    float x = aux_h[max(min(r, sq - 1), 0)];
     const bool ok = r < lim;
+    if constexpr (ALIBI) x = hi ? x : __builtin_fmaf(s_slope, kif, x);   // LSE + slope * (row - q0)
     aux_reg = hi ? (ok ? -x : 0.f) : (ok ? -x * rscale : -INFINITY);
   };
   auto stream_advance = [&]() __attribute__((always_inline)) {
@@ -306,6 +319,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   static_assert(NT <= NR, "phase B's ring lives in phase A's");
   u32x4 ring[NR];
   u32x4 kx[2];   // key block 1's K fragment of the k-step in flight and of the next one (KL > 0)
+  float slope_v = 0.f;   // (ALIBI) slope*log2e of the head of the tile in flight (uniform; loaded with the chains' C operands)
 
   // phase A fragment stream: j = 4*ks + kind, kind 0 = Q row fragment (S chains), 1 = dO row fragment (dP chains), 2 / 3 = V fragment of key block 0 / 1
   auto rd_a = [&](auto jc, int qa, int kva) __attribute__((always_inline)) {
@@ -319,7 +333,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   // S - LSE/scale and the exponent of P is ONE multiply by scale*log2e away: (S - LSE/scale) * scale * log2e = S*scale*log2e - LSE*log2e, the scale applied
   // in fp32), -delta for dP, the same sixteen rows for both key blocks -- and the first AHJ fragments.  Requested at the end of the step before (the tile
   // was published one barrier earlier).
-  auto preload_a = [&](int slot) __attribute__((always_inline)) {
+  auto preload_a = [&](int slot, int hq) __attribute__((always_inline)) {
+    if constexpr (ALIBI) slope_v = *(const float FA_LDS*)(unsigned long)(unsigned)opaque(OFF_TAB + 4 * hq);
     {
       const int auxp = opaque(aux_lane) + slot * AUX_SLOT;
 #pragma unroll
@@ -429,10 +444,16 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     float c_l = cs;
     asm volatile("" : "+s"(c_l));   // (a copy of its own per instantiation: hipcc otherwise hoists all 32 multiplies by scale*log2e -- common to the masked and the
                                     // plain instantiation -- in front of the branch between them: 32 registers)
+    float lb[KB] = {0.f, 0.f};   // (ALIBI) slope*log2e * (key - q0 - shift) of this lane's key in block kb
+    if constexpr (ALIBI && DO_SM) {
+      const float f0 = (float)(wk0 + ki - shift - q0);
+      lb[0] = slope_v * f0;
+      lb[1] = slope_v * (f0 + 32.f);
+    }
     float pv[32], dv[32];   // P and dS of the tile's elements (each lives for a gap or two)
     auto sm1 = [&](auto ec) __attribute__((always_inline)) {
       constexpr int e = decltype(ec)::value, kb = e >> 4, r = e & 15;
-      float xv = s[kb][r] * c_l;
+      float xv = ALIBI ? __builtin_fmaf(s[kb][r], c_l, lb[kb]) : s[kb][r] * c_l;
       if constexpr (MASK) {
         unsigned t;
         asm volatile("v_bfe_i32 %1, %2, %c3, 1\n\tv_bfi_b32 %0, %1, %0, %4" : "+v"(xv), "=&v"(t) : "v"(vis[kb]), "i"(acc_row(r, 0)), "v"(ninf));
@@ -488,8 +509,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   // ---- the step loop ----------------------------------------------------------------------------------------------------------------
   // Control block of a step: everything scalar it needs, made DURING the step before it (inside phase A's gaps, where the scalar ALU idles): the first version
   // made it at the step's head -- ~90 instructions and a dozen branches per 64 MFMAs with nothing to hide behind (profiles/r05_bwd_dkdv_w64.txt).
-  struct Ctl { bool act, msk; int slot_a, slot_b, slot2, q0; Strm z; };
-  int c_mt = mt_first, c_left = __builtin_amdgcn_readfirstlane(nm);   // tile st of the walk
+  struct Ctl { bool act, msk; int slot_a, slot_b, slot2, q0, hq; Strm z; };
+  int c_mt = mt_first, c_left = __builtin_amdgcn_readfirstlane(nm), c_h = 0;   // tile st of the walk: tile index, tiles left in its head, head of the group
   bool act_prev = false;
   auto make_ctl = [&](int st) __attribute__((always_inline)) {   // for step st, from the counters as they stand (compute tile st, stream tile st + 2)
     Ctl c;
@@ -500,6 +521,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     // so the fill reads the current tile's slot instead)
     c.slot_b = act_prev ? ((st - 1) & 3) : c.slot_a;
     c.q0 = c_mt * TQ;
+    c.hq = c_h;
     c.z = stream_prep(c.slot2);
     return c;
   };
@@ -509,10 +531,11 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     const bool wrap = c_left == 1;
     c_mt = wrap ? mt_first : c_mt + mt_dir;
     c_left = wrap ? nm : c_left - 1;
+    if constexpr (ALIBI) c_h = wrap ? c_h + 1 : c_h;
     stream_advance();
     nxt = make_ctl(st + 1);
   };
-  preload_a(0);
+  preload_a(0, 0);
   auto step = [&](int st) __attribute__((always_inline)) {
     const Ctl c = nxt;
     stream_aux(c.z);
@@ -551,7 +574,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
       if (__builtin_expect(c.act && c.msk, 0)) phase_b(Y{}, Y{}, Y{}, c.slot_b, c.q0, pc, dc, pn, dn);
       else phase_b(Y{}, Y{}, N{}, c.slot_b, c.q0, pc, dc, pn, dn);
     }
-    preload_a((st + 1) & 3);   // (tile st + 1 was published by the previous barrier.  Unconditional: a conditional definition keeps the 96 registers of
+    preload_a((st + 1) & 3, nxt.hq);   // (tile st + 1 was published by the previous barrier.  Unconditional: a conditional definition keeps the 96 registers of
                                // S / dP / the fragment rings alive across phase B in hipcc's eyes; past the last tile it reads a stale slot nobody uses)
     lds_dma_wait_all();        // tile st + 2 has landed (requested in this step's first gaps)
     stream_store_aux(c.slot2);
@@ -579,22 +602,29 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   });
 }
 
-template <typename E, int D>
-static int launch_dkdv_w64_t(const BwdK& p, hipStream_t stream) {
-  constexpr int smem = 4 * 2 * 32 * D * 2 + 256 * D * 2 + 4 * 2 * 32 * 4 + (D == 128 ? 4 * (D / 16 - 1) * 1024 : 0);   // tile ring | V block | aux ring | K overflow
-  auto kern = fa_bwd_dkdv_w64_kernel<E, D>;
+template <typename E, int D, bool ALIBI>
+static int launch_dkdv_w64_f(const BwdK& p, hipStream_t stream) {
+  constexpr int base = 4 * 2 * 32 * D * 2 + 256 * D * 2 + 4 * 2 * 32 * 4 + (D == 128 ? 4 * (D / 16 - 1) * 1024 : 0);   // tile ring | V block | aux ring | K overflow
+  const int smem = base + (ALIBI ? (4 * (p.hk_ratio + 1) + 15) / 16 * 16 : 0);                                          // | (ALIBI) slope table
+  if (smem > 160 * 1024) return -2;
+  auto kern = fa_bwd_dkdv_w64_kernel<E, D, ALIBI>;
   static std::atomic<unsigned long long> attr_mask{0};
-  if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, 160 * 1024, true) != 0) return -1;
   const long long total = p.k_list ? (long long)p.k_bound * p.h_k : units_grid(p.k_units, p.k_unit_size);
   if (total <= 0) return 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), smem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+template <typename E, int D>
+static int launch_dkdv_w64_t(const BwdK& p, hipStream_t stream) {
+  return p.alibi ? launch_dkdv_w64_f<E, D, true>(p, stream) : launch_dkdv_w64_f<E, D, false>(p, stream);
+}
 
-// 4 waves x 64 keys per workgroup (the same 256-key blocks as fa_bwd_dkdv_kernel: grid and work list unchanged).  Plain attention, head dim 64 / 128;
-// -2 = not covered, the caller runs fa_bwd_dkdv_kernel.
+// 4 waves x 64 keys per workgroup (the same 256-key blocks as fa_bwd_dkdv_kernel: grid and work list unchanged).  Plain attention or ALiBi under a causal right
+// bound, head dim 64 / 128; -2 = not covered, the caller runs fa_bwd_dkdv_kernel.
 int launch_bwd_dkdv_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
-  if (p.softcap > 0.f || p.alibi != nullptr || p.rng != nullptr || p.ds_ws != nullptr || p.d_chunks > 0) return -2;
+  if (p.softcap > 0.f || p.rng != nullptr || p.ds_ws != nullptr || p.d_chunks > 0) return -2;
+  if (p.alibi != nullptr && p.wr != 0) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal
   if (d != 128 && d != 64) return -2;
   // buffer addressing of the streamed tiles: 32-bit byte offsets from the head's first row
   const uint64_t span = ((uint64_t)(p.sq > 0 ? p.sq : 1) + 64) * (uint64_t)(p.q_rs > p.do_rs ? p.q_rs : p.do_rs) * 2u;

@@ -70,13 +70,18 @@ template <typename E, int T> FA_DEVINL void mfma_q_acc(u32x4 a, u32x4 b) {
 
 }  // namespace
 
-template <typename E, int D, bool FUSE_DELTA>
+// ALIBI (under a causal right bound, where the bias -slope * |key - row - shift| is linear in the key): the exponent of P gets slope*log2e * (key - row - shift).
+// Element r of a step scores key k0 + 4*hi + acc_row(r, 0): slope*log2e * acc_row(r, 0) rides in the score chains' C operand next to -LSE*log2e (per block),
+// slope*log2e * (k0 + 4*hi - row - shift) -- one value per lane, query block and step, from an integer difference -- is added to every score of the step
+// in front of its exp2: one more vector instruction per element (32 per 48 MFMAs).
+template <typename E, int D, bool FUSE_DELTA, bool ALIBI>
 __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   constexpr int NW = 4, QB = 2, BM = NW * 64, BN = 64, CPR = D / 8;
   constexpr int ROW_BYTES = D * 2, TILE_BYTES = BN * ROW_BYTES;
   constexpr int KS = D / 16, DB = D / 32;
+  constexpr int AHK = FA_BW64_AH;   // (the ALiBi variant needs the four registers of a ring entry at D = 128: with them it spills one)
   constexpr int RING = 3;                         // K tiles u-1 (transposed), u (rows), u+1 (arriving); V shares the slot index
   constexpr int V_RING = RING * TILE_BYTES;       // V ring behind the K ring
   constexpr int DO_OFF = BM * ROW_BYTES;          // prologue staging: Q rows at 0, dO rows behind (both under the rings)
@@ -137,6 +142,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   const int w_full_hi = (p.wr >= 0) ? min(sk - 1, w_row0 + shift + p.wr) : sk - 1;
   const int w_full_lo = (p.wl >= 0) ? (w_row1 + shift - p.wl) : 0;
   const float cs = p.scale_log2;
+  float slope2 = 0.f;   // ALiBi slope of this head in log2 units
+  if constexpr (ALIBI) slope2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.alibi[(int64_t)b * p.alibi_bs + h] * kLog2eW)));   // (uniform; said so: one scalar register)
   int lim_hi[QB], lim_lo[QB];
   float lse_l[QB], delta_l[QB];
 #pragma unroll
@@ -333,7 +340,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      nlse[qb][r] = -lse_l[qb];
+      nlse[qb][r] = ALIBI ? __builtin_fmaf(slope2, (float)acc_row(r, 0), -lse_l[qb]) : -lse_l[qb];
     }
   }
   bool have_cur = false, have_prev = false;
@@ -347,10 +354,20 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
     return __builtin_bit_cast(u32x4, combine_tr<V8>(lo, hi4));
   };
   // dS_i of one element
-  auto ds_elem = [&](float sv, float dpv, int qb) __attribute__((always_inline)) {
-    const float pv = fast_exp2(sv);   // sv = s*scale*log2e - LSE*log2e, dpv = dP - delta: both subtractions rode in the chains' C operands
+  auto ds_elem = [&](float sv, float dpv, int qb, float sb) __attribute__((always_inline)) {
+    if constexpr (ALIBI) sv += sb;
+    const float pv = fast_exp2(sv);   // sv = s*scale*log2e - LSE*log2e (the subtraction rode in the chain's C operand)
     return pv * (dpv - delta_l[qb]);
   };
+  // (ALIBI) the step's per-lane part of the bias, slope*log2e * (first key of the step + 4*hi - row - shift), from the same integer the masked steps compare
+  // against: rel_hi = (row + shift) - k0 - 4*hi is the lane's right bound under the causal mask this variant requires (a row past the end, where the bound is
+  // clamped, has LSE = +inf and P = 0 whatever the bias) -- no register of its own across the tile loop
+  auto bias_of = [&](int rel_hi) __attribute__((always_inline)) { return -slope2 * (float)rel_hi; };
+  // (ALIBI) ... and the left bound relative to the step follows from the right one (window_right = 0: lim_lo = lim_hi - window_left): two registers fewer across the loop
+  const int lo_gap = __builtin_amdgcn_readfirstlane(p.wl >= 0 ? p.wl : (1 << 30));
+  auto rel_lo_of = [&](int qb, int rel_hi, int k04) __attribute__((always_inline)) { return ALIBI ? rel_hi - lo_gap : lim_lo[qb] - k04; };
+  // (ALIBI) ... and query block 1's right bound is block 0's + 32 (where that is past the last key the row is past the end: P = 0 through its LSE): one more
+  auto lim_hi_of = [&](int qb) __attribute__((always_inline)) { return ALIBI ? lim_hi[0] + 32 * qb : lim_hi[qb]; };
   auto pack2 = [&](float x0, float x1) __attribute__((always_inline)) {
     using V2 = __attribute__((ext_vector_type(2))) E;
     V2 pr;
@@ -392,14 +409,15 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       const int k0 = key_base + 32 * i;
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        const int rel_hi = lim_hi[qb] - k0 - 4 * hi, rel_lo = lim_lo[qb] - k0 - 4 * hi;
+        const int rel_hi = lim_hi_of(qb) - k0 - 4 * hi, rel_lo = rel_lo_of(qb, rel_hi, k0 + 4 * hi);
+        const float sbq = bias_of(rel_hi);
         float dsv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int off = acc_row(r, 0);
           float sv = s_cur[qb][r];
           if (mask) sv = ((off <= rel_hi) && (off >= rel_lo)) ? sv : -INFINITY;
-          dsv[r] = ds_elem(sv, dp_cur[qb][r], qb);
+          dsv[r] = ds_elem(sv, dp_cur[qb][r], qb, sbq);
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) f_cur[qb][c >> 2][c & 3] = pack2(dsv[2 * c], dsv[2 * c + 1]);
@@ -430,14 +448,13 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   //   pieces in the odd gaps 1, 3, ...  The score chains end 16 MFMAs before the next step reads them.
   auto fast_step = [&](auto halfc, auto maskc, int i_cur, f32x16 (&s_cur)[QB], f32x16 (&dp_cur)[QB], f32x16 (&s_nxt)[QB],
                        f32x16 (&dp_nxt)[QB], const u32x4 (&f_prev)[QB][2], u32x4 (&f_cur)[QB][2], const u32x4& dma_srd,
-                       const unsigned (&dma_off)[DPW], unsigned dma_toff, unsigned dma_dst, u32x4 (&fr)[FA_BW64_AH + 1]) __attribute__((always_inline)) {
+                       const unsigned (&dma_off)[DPW], unsigned dma_toff, unsigned dma_dst, u32x4 (&fr)[AHK + 1]) __attribute__((always_inline)) {
     constexpr int half = decltype(halfc)::value;
     constexpr bool MASK = decltype(maskc)::value != 0;
     constexpr int HOFF = half * 32 * ROW_BYTES;
     constexpr int QKG = 2 * KS, DQG = 4 * DB, NG = 2 * QKG + DQG;
-    constexpr int AH = FA_BW64_AH, RNG = AH + 1;     // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
+    constexpr int AH = AHK, RNG = AH + 1;     // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
     constexpr int NF = 2 * KS + 2 * DB;     // fragment slots: KS K rows, KS V rows, 2*DB transposed K
-    static_assert(RNG == FA_BW64_AH + 1, "the fragment ring is the caller's (carried from a first step to its second step)");
     auto rd_frag = [&](int f) __attribute__((always_inline)) {
       if (f < KS) {
         fr[f % RNG] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[f] + HOFF);
@@ -451,11 +468,12 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
     // elements of dS_i done before gap x (e = 16*qb + r), all 32 before the last gap; pairs are packed one gap later
     auto el_end = [](int x) constexpr { return x <= 0 ? 0 : ((32 * x + NG - 2) / (NG - 1) > 32 ? 32 : (32 * x + NG - 2) / (NG - 1)); };
     float dsv[QB][16];
+    float sbv = 0.f;   // (ALIBI) the bias of the query block whose elements are being processed: made when its first element comes up
     int rel_hi[QB] = {0, 0}, rel_lo[QB] = {0, 0};
+    const int k0c = key_base + 32 * i_cur;
     if constexpr (MASK) {
-      const int k0 = key_base + 32 * i_cur;
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) { rel_hi[qb] = lim_hi[qb] - k0 - 4 * hi; rel_lo[qb] = lim_lo[qb] - k0 - 4 * hi; }
+      for (int qb = 0; qb < QB; ++qb) { rel_hi[qb] = lim_hi_of(qb) - k0c - 4 * hi; rel_lo[qb] = rel_lo_of(qb, rel_hi[qb], k0c + 4 * hi); }
     }
     if constexpr (half != 1) {   // (second step: requested by the first step's last gaps)
 #pragma unroll
@@ -495,11 +513,12 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       for (int e = el_end(x); e < el_end(x + 1); ++e) {
         const int eq = e >> 4, r = e & 15;
         float sv = s_cur[eq][r];
+        if constexpr (ALIBI) { if (r == 0) sbv = bias_of(MASK ? rel_hi[eq] : lim_hi_of(eq) - k0c - 4 * hi); }
         if constexpr (MASK) {
           const int off = acc_row(r, 0);
           sv = ((off <= rel_hi[eq]) && (off >= rel_lo[eq])) ? sv : -INFINITY;
         }
-        dsv[eq][r] = ds_elem(sv, dp_cur[eq][r], eq);
+        dsv[eq][r] = ds_elem(sv, dp_cur[eq][r], eq, sbv);
       }
 #pragma unroll
       for (int c = el_end(x - 1) / 2; c < el_end(x) / 2; ++c) {
@@ -562,7 +581,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       const unsigned toff_k = (unsigned)(n_min + uu + 1) * (unsigned)(BN * 2) * (unsigned)p.k_rs;
       const unsigned toff_v = (unsigned)(n_min + uu + 1) * (unsigned)(BN * 2) * (unsigned)p.v_rs;
       // (a tile past the last one lands in the slot nobody reads again; rows past the descriptor's range are never a fault)
-      u32x4 fring[FA_BW64_AH + 1];   // operand ring of the two steps (the second step's first fragments are requested by the first)
+      u32x4 fring[AHK + 1];   // operand ring of the two steps (the second step's first fragments are requested by the first)
       fast_step(ICw<0>{}, maskc, 2 * uu - 1, sA, dpA, sB, dpB, fA, fB, k_srd, koff_l, toff_k,
                 __builtin_amdgcn_readfirstlane((unsigned)(nslot * TILE_BYTES) + wave_dst), fring);
       fast_step(ICw<1>{}, maskc, 2 * uu, sB, dpB, sA, dpA, fB, fA, v_srd, voff_l, toff_v,
@@ -599,17 +618,19 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       acc_read_tuple<16 * (qb * DB + db)>(o_v[db]);
     });
     const int row0 = w_row0 + 32 * qb;
+    // (the lane index made again from the hardware counter: as `lane` it is one more register alive across the tile loop -- the ALiBi variant at D = 128 spilled it)
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (row0 < sq)
       store_tile_via_lds<E, D>(lds + (wave * 64 + qb * 32) * (ROW_BYTES + 16), o_v, p.scale, dqtile + (int64_t)(32 * qb) * p.dq_rs, p.dq_rs,
-                               sq - row0, lane);
+                               sq - row0, lane_e);
   });
 }
 
-template <typename E, int D, bool FUSE_DELTA>
+template <typename E, int D, bool FUSE_DELTA, bool ALIBI>
 static int launch_bwd_dq_w64_f(const BwdK& p, hipStream_t stream) {
   constexpr int TILE = 64 * D * 2, RINGS = 2 * 3 * TILE, STAGE_IN = 2 * 256 * D * 2, STAGE_OUT = 256 * (D * 2 + 16);
   constexpr int smem = (RINGS > STAGE_IN ? (RINGS > STAGE_OUT ? RINGS : STAGE_OUT) : (STAGE_IN > STAGE_OUT ? STAGE_IN : STAGE_OUT));
-  auto kern = fa_bwd_dq_w64_kernel<E, D, FUSE_DELTA>;
+  auto kern = fa_bwd_dq_w64_kernel<E, D, FUSE_DELTA, ALIBI>;
   static std::atomic<unsigned long long> attr_mask{0};
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
   const long long total = p.q_list ? (long long)p.q_bound * p.h : units_grid(p.q_units, p.q_unit_size);
@@ -620,13 +641,15 @@ static int launch_bwd_dq_w64_f(const BwdK& p, hipStream_t stream) {
 
 template <typename E, int D>
 static int launch_bwd_dq_w64_t(const BwdK& p, hipStream_t stream) {
-  return p.fuse_delta ? launch_bwd_dq_w64_f<E, D, true>(p, stream) : launch_bwd_dq_w64_f<E, D, false>(p, stream);
+  if (p.alibi) return p.fuse_delta ? launch_bwd_dq_w64_f<E, D, true, true>(p, stream) : launch_bwd_dq_w64_f<E, D, false, true>(p, stream);
+  return p.fuse_delta ? launch_bwd_dq_w64_f<E, D, true, false>(p, stream) : launch_bwd_dq_w64_f<E, D, false, false>(p, stream);
 }
 
-// 4 waves x 64 query rows per workgroup (the caller sized nmb / the work list for 256-row blocks).  Plain attention only;
+// 4 waves x 64 query rows per workgroup (the caller sized nmb / the work list for 256-row blocks).  Plain attention, or ALiBi under a causal right bound;
 // -2 = not covered, the caller falls back to fa_bwd_dq_kernel<.., 8, ..> on the same blocks.
 int launch_bwd_dq_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
-  if (p.softcap > 0.f || p.alibi != nullptr || p.rng != nullptr) return -2;
+  if (p.softcap > 0.f || p.rng != nullptr) return -2;
+  if (p.alibi != nullptr && p.wr != 0) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal
   const uint64_t span = ((uint64_t)(p.sk > 0 ? p.sk : 1) + 128) * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u;
   if (span >= (1ull << 32)) return -2;   // buffer addressing: 32-bit byte offsets from the (batch, kv-head) base
   if (d == 128) return dtype_bf16 ? launch_bwd_dq_w64_t<__bf16, 128>(p, stream) : launch_bwd_dq_w64_t<_Float16, 128>(p, stream);

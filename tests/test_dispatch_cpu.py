@@ -118,6 +118,8 @@ def test_backward_dq_schedule(lib, monkeypatch):
     assert dq(bp(2, 8192, 32, 64, is_causal=1)) == 64
     assert dq(bp(16, 1024, 32, 64)) == 4
     assert dq(bp(4, 4096, 32, 128, softcap=20.0)) == 4
+    assert dq(bp(4, 4096, 32, 128, alibi_slopes=1, is_causal=1)) == 64    # round 5: ALiBi under a causal bound runs on the 64-rows-per-wave kernel too
+    assert dq(bp(4, 4096, 32, 128, alibi_slopes=1)) == 4                  # ... not without it (|key - row| is not linear in the key)
     monkeypatch.setenv("FA_BWD_DQ_NW", "64"); lib.fa_knobs_reload()
     assert dq(bp(4, 4096, 32, 96)) == 4                                 # trimmed head dims only have the 4-wave kernel, whatever the knob says
     assert dq(bp(4, 512, 8, 128)) == 64
