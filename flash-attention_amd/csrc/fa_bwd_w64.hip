@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   constexpr int NW = 4, QB = 2, BM = NW * 64, BN = 64, CPR = D / 8;
   constexpr int ROW_BYTES = D * 2, TILE_BYTES = BN * ROW_BYTES;
   constexpr int KS = D / 16, DB = D / 32;
-  constexpr int AHK = FA_BW64_AH;   // (the ALiBi variant needs the four registers of a ring entry at D = 128: with them it spills one)
+  constexpr int AHK = FA_BW64_AH;
   constexpr int RING = 3;                         // K tiles u-1 (transposed), u (rows), u+1 (arriving); V shares the slot index
   constexpr int V_RING = RING * TILE_BYTES;       // V ring behind the K ring
   constexpr int DO_OFF = BM * ROW_BYTES;          // prologue staging: Q rows at 0, dO rows behind (both under the rings)
