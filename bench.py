@@ -233,8 +233,8 @@ def fused_bwd_probe(timeout=120):
 
 
 def feature_rows(be, dev, sync, B, H, S, D):
-    """Extra key `features`: the headline config with causal ALiBi (standard slopes 2^(-8(h+1)/H)) -- forward on the 64-rows-per-wave kernel's
-    ALiBi variant, backward on the ALiBi variants of the dK/dV and dQ kernels -- next to the plain numbers of the main line.  Never fatal:
+    """Extra key `features`: the headline config with causal ALiBi (standard slopes 2^(-8(h+1)/H)) -- forward and backward on the ALiBi variants of the
+    64-per-wave kernels -- and with softcap, next to the plain numbers of the main line.  Never fatal:
     any failure is reported in the key instead of taking the contract line down."""
     try:
         q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
@@ -249,8 +249,18 @@ def feature_rows(be, dev, sync, B, H, S, D):
         h = lambda: be.bwd(g, q, k, v, o, l, None, None, None, al, 0.0, sc, True, -1, -1, 0.0, False, None, None)
         _, mb = time_kernel(h, 8, 2, sync)
         fl = fwd_flops(B, H, S, D, True)
-        return {"causal_alibi": {"fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
-                                 "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name}}
+        out = {"causal_alibi": {"fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
+                                "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name}}
+        # ... and with softcap 30 (round 5: forward on the 64-rows-per-wave kernel's softcap variant; the backward on the feature kernels of fa_bwd.hip)
+        f = lambda: be.fwd(q, k, v, None, None, 0.0, sc, True, -1, -1, 30.0, False, None)
+        _, ms = time_kernel(f, 20, 5, sync)
+        name = be.last_schedule()["name"]
+        o, l = f()[:2]
+        h = lambda: be.bwd(g, q, k, v, o, l, None, None, None, None, 0.0, sc, True, -1, -1, 30.0, False, None, None)
+        _, mb = time_kernel(h, 8, 2, sync)
+        out["causal_softcap"] = {"fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
+                                 "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name}
+        return out
     except Exception as e:   # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
 
@@ -602,6 +612,9 @@ def main(argv=None):
             ca = extras["features"].get("causal_alibi")
             if ca:
                 res["causal_alibi"] = [ca["fwd_tflops"], ca["bwd_tflops"], ca["fwd_bwd_tflops"]]
+            cs = extras["features"].get("causal_softcap")
+            if cs:
+                res["causal_softcap"] = [cs["fwd_tflops"], cs["bwd_tflops"], cs["fwd_bwd_tflops"]]
         if world == 1 and not a.no_parity:
             extras["parity"] = parity_report(be, dev, q, k, v, causal)
             t = extras["parity"].get("tensors")

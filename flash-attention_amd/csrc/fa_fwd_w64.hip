@@ -95,11 +95,20 @@ template <typename E, int T> FA_DEVINL void mfma_o_acc(u32x4 a, u32x4 b) {
 // scores grow by slope*32 per step, the running maximum moves at every step and the 540-instruction rescale runs every step (measured: 527
 // TFLOP/s at config 3 against 614 for the lock-step kernel, profiles/r03_fwd_schedules.txt); downwards the maximum is found in the first tiles.
 // set_mask / clear_mask rewrite the broadcast exactly and the rescale moves it, so the incremental adds' rounding does not accumulate past them.
+//
+// FEAT_CAP = softcap (round 5; reference: flash_fwd_kernel.h:357-368 + utils.h:395-409, scores -> softcap * tanh(scores / softcap)).  The map is not linear, so the
+// maximum cannot be subtracted by the matrix pipe: Q carries scale/softcap * 2*log2e, the chains start from C = 0 (-inf where masked, as ever) and deliver
+// y = 2*log2e * z, z = score*scale/softcap; with c = softcap*log2e the probability is 2^(c*tanh(z) - m) = 2^(off - 2c/(2^y + 1)), off = c - m one value per row.
+// Seven vector instructions per score instead of two (exp2, add, rcp, two fused multiply-adds -- one of them only carries a masked score's -inf through tanh's
+// saturation: -inf * 2^-100 --, exp2, row sum), staged over three gaps so that no instruction waits for the one before it; the row-max tree runs on y itself (tanh is
+// monotone) and the decision maps the row maximum once per row and step.  Elements are spread 20 : 12 over the two halves of the step instead of 24 : 8 (the
+// score half has the K reads and the DMA, the other half the packing and the tree).
 template <typename E, int D, int FEAT = 0>
 __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   constexpr bool ALIBI = FEAT == FEAT_ALIBI;
+  constexpr bool SOFTCAP = FEAT == FEAT_CAP;
   constexpr bool DESC = ALIBI;   // iteration u scores key tile n_tiles - 1 - u instead of tile u
-  static_assert(FEAT == 0 || FEAT == FEAT_ALIBI, "feature variants of this schedule: none, causal ALiBi");
+  static_assert(FEAT == 0 || FEAT == FEAT_ALIBI || FEAT == FEAT_CAP, "feature variants of this schedule: none, causal ALiBi, softcap");
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   constexpr int NW = 4, QB = 2, BM = NW * 64, BN = 64, CPR = D / 8;
@@ -334,7 +343,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // this wave's B-operand fragments of Q, pre-multiplied by softmax_scale*log2(e) and rounded once to the input dtype, into
   // accumulator registers for the whole block
   {
-    const float cq = p.scale_log2;
+    const float cq = SOFTCAP ? p.scale * 2.885390081777927f / p.softcap : p.scale_log2;   // (softcap: the chains deliver 2*log2e * score*scale/softcap)
     // (all reads of a query block first: read -> convert -> write one fragment at a time exposes the LDS latency sixteen times)
     u32x4 qraw[QB][KS];
 #pragma unroll
@@ -415,6 +424,14 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   }
   float m_run[QB], l_run[QB][2], o_lag[QB];
   float thr_l[QB];          // per-lane decision threshold: -inf until the row has seen a key (any finite score moves m), then rescale_thr
+  // (SOFTCAP) c = softcap*log2e (the capped scores live in [-c, c] log2 units), -2c, and per row off = c - m_base
+  float capc = 0.f, cap_m2c = 0.f, capoff[QB] = {0.f, 0.f};
+  if constexpr (SOFTCAP) {
+    capc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.softcap * 1.4426950408889634f)));
+    cap_m2c = -2.f * capc;
+    capoff[0] = capc; capoff[1] = capc;
+  }
+  constexpr float kCapTiny = 7.888609052210118e-31f;   // 2^-100: y * tiny vanishes for every finite y and keeps a masked score's -inf
   unsigned long long lag_mask = 0ull;   // wave-uniform, all ones or zero: some o_lag != 1 is waiting to be applied to O
   f32x16 negm[QB];     // the C operand of every score chain's first MFMA: -m broadcast (0 while m = -inf), plus the ALiBi bias of the step's keys
   // ALiBi: element r of a step has the bias slope2 * (step_key + 4*hi + acc_row(r, 0) - row - shift).  The key distance is formed in INTEGERS first
@@ -461,8 +478,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     // in place, element by element through tied asm operands: a recomputed tuple would live in NEW registers and cost the
     // common path a 16-register copy at the join
     const float neg = -m_safe;
+    if constexpr (SOFTCAP) capoff[qb] = capc - m_safe;   // (the pending scores are raw: nothing to re-base, the C broadcast stays 0 / -inf)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < (SOFTCAP ? 0 : 16); ++r) {
       float sv = s_nxt[r], nv = negm[qb][r];
       if constexpr (ALIBI) asm volatile("v_sub_f32 %0, %0, %2\n\tv_sub_f32 %1, %1, %2" : "+v"(sv), "+v"(nv) : "v"(delta), "v"(neg));   // (the bias stays; -inf stays -inf)
       else asm volatile("v_sub_f32 %0, %0, %2\n\tv_mov_b32 %1, %3" : "+v"(sv), "+v"(nv) : "v"(delta), "v"(neg));
@@ -508,7 +526,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     asm volatile("" : "+v"(ninf));
     static_for<QB>([&](auto mqc) __attribute__((always_inline)) {
       constexpr int mq = decltype(mqc)::value;
-      float nb = (m_run[mq] == -INFINITY) ? 0.f : -m_run[mq];
+      float nb = (SOFTCAP || m_run[mq] == -INFINITY) ? 0.f : -m_run[mq];
       // element r of this lane scores key k0m + 4*hi + acc_row(r, 0): the lane's visibility bitmap over those offsets, then two instructions per
       // element (sign-extended bit -> select mask -> bit-field insert)
       const int rel_hi = min(lim_hi[mq] - k0m - 4 * hi, 31), rel_lo = max(lim_lo[mq] - k0m - 4 * hi, 0);
@@ -541,7 +559,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   auto clear_mask = [&](int i_next) __attribute__((always_inline)) {   // i_next: the step whose keys the broadcast serves next (ALiBi)
     static_for<QB>([&](auto mqc) __attribute__((always_inline)) {
       constexpr int mq = decltype(mqc)::value;
-      float nb = (m_run[mq] == -INFINITY) ? 0.f : -m_run[mq];
+      float nb = (SOFTCAP || m_run[mq] == -INFINITY) ? 0.f : -m_run[mq];
       if constexpr (ALIBI) nb += slope2 * (float)(arel[mq] + step_key(i_next));
       asm volatile("" : "+v"(nb));
 #pragma unroll
@@ -585,8 +603,19 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       }
     };
     // element e of P_i (e = 16*qb + r): done-by-gap schedule
-    auto el_end = [](int x) constexpr { return x <= QKG ? (24 * x) / QKG : (24 + ((x - QKG) * 16) / PVG > 32 ? 32 : 24 + ((x - QKG) * 16) / PVG); };
+    // (SOFTCAP: no element takes this path -- its staged form follows its own schedule, cap_a below)
+    auto el_end = [](int x) constexpr { return SOFTCAP ? 32 : x <= QKG ? (24 * x) / QKG : (24 + ((x - QKG) * 16) / PVG > 32 ? 32 : 24 + ((x - QKG) * 16) / PVG); };
     float pe[QB][16];   // P_i as scalars (writing them back into the score tuples makes hipcc copy whole 16-register tuples)
+    // (SOFTCAP) stage A of element e is issued in the gaps before x for e < cap_a(x): 20 elements under the score chains, 12 under the first PVG - 2 gaps of the
+    // PV half; stages B and C follow one and two gaps later (the last element's stage C sits in the step's last gap)
+    auto cap_a = [](int x) constexpr {
+      if (x <= 0) return 0;
+      if (x <= QKG) return (20 * x) / QKG;
+      const int n = 20 + ((x - QKG) * 12 + (PVG - 3)) / (PVG - 2);
+      return n > 32 ? 32 : n;
+    };
+    static_assert(!SOFTCAP || cap_a(NG - 2) == 32, "every element's last stage inside the step");
+    float cap_a1[32], cap_d[32], cap_arg[32], cap_g[QB] = {0.f, 0.f}, cap_gt[QB] = {-INFINITY, -INFINITY};   // values in flight between the stages (a gap or two each)
     float tmax[QB] = {-INFINITY, -INFINITY}, tcopy[QB] = {0.f, 0.f};
     // gap (inside the PV half) schedule of the row-max work of query block mq
     constexpr int UPG = PVG >= 16 ? 1 : 2;        // max3 units per gap
@@ -637,6 +666,23 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
           negm[e >> 4][e & 15] = nv;
         }
       }
+      if constexpr (SOFTCAP) {
+        // three stages, oldest elements first: C = exp2 + row sum, B = rcp + the exponent, A = the mask carrier, exp2 and +1
+#pragma unroll
+        for (int e = cap_a(x - 2); e < cap_a(x - 1); ++e) {
+          const int eq = e >> 4, r = e & 15;
+          pe[eq][r] = fast_exp2(cap_arg[e]);
+          l_run[eq][r & 1] += pe[eq][r];
+        }
+#pragma unroll
+        for (int e = cap_a(x - 1); e < cap_a(x); ++e) cap_arg[e] = __builtin_fmaf(__builtin_amdgcn_rcpf(cap_d[e]), cap_m2c, cap_a1[e]);
+#pragma unroll
+        for (int e = cap_a(x); e < cap_a(x + 1); ++e) {
+          const float yv = s_cur[e >> 4][e & 15];
+          cap_a1[e] = __builtin_fmaf(yv, kCapTiny, capoff[e >> 4]);
+          cap_d[e] = fast_exp2(yv) + 1.f;
+        }
+      }
       // exp2 + row sums (two running sums per query block, carried across steps)
 #pragma unroll
       for (int e = el_end(x); e < el_end(x + 1); ++e) {
@@ -679,6 +725,13 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
           if (y == hm_gap(mq) - 1 && UPG != 1) asm volatile("v_mov_b32 %0, %1" : "=v"(tcopy[mq]) : "v"(tmax[mq]));
           if (y == hm_gap(mq))
             asm volatile("v_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(tmax[mq]), "+v"(tcopy[mq]));
+          if constexpr (SOFTCAP) {   // the decision's operand: the row maximum through the cap, relative to the row's base -- c*tanh(z_max) - m_base, -inf kept
+            constexpr int last = PVG - 1;
+            const int g1 = hm_gap(mq) + 1 < last ? hm_gap(mq) + 1 : last, g2 = hm_gap(mq) + 2 < last ? hm_gap(mq) + 2 : last, g3 = hm_gap(mq) + 3 < last ? hm_gap(mq) + 3 : last;
+            if (y == g1) cap_g[mq] = fast_exp2(tmax[mq]) + 1.f;
+            if (y == g2) cap_g[mq] = __builtin_fmaf(__builtin_amdgcn_rcpf(cap_g[mq]), cap_m2c, capoff[mq]);
+            if (y == g3) cap_gt[mq] = __builtin_fmaf(tmax[mq], kCapTiny, cap_g[mq]);
+          }
         }
       }
       // carry: behind this step's last LDS wait (gap NG - 4: slot NF - 2, everything landed) the K ring is free -- request the first AH fragments of the SECOND
@@ -692,6 +745,8 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #pragma unroll
     for (int mq = 0; mq < QB; ++mq)
       if (hm_gap(mq) >= PVG) tmax[mq] = vhalf_max(tmax[mq]);   // (no gap left for it)
+    static_assert(!SOFTCAP || QB + 8 / UPG < PVG - 1, "softcap: the capped maximum is made inside the gaps");
+    if constexpr (SOFTCAP) { tmax[0] = cap_gt[0]; tmax[1] = cap_gt[1]; }   // (the decision's operand: the capped maximum relative to the row's base)
     decide_and_rescale(tmax, s_nxt);
   };
 
@@ -878,7 +933,7 @@ static int launch_fwd_w64_t(const FwdK& p, hipStream_t stream) {
   LastSchedule& ls = last_schedule();
   ls.fwd_kernel = 3; ls.fwd_nw = 4; ls.fwd_feat = FEAT; ls.fwd_splits = 1; ls.fwd_list = p.work_list != nullptr; ls.d = D;
   ls.bf16 = std::is_same<E, __bf16>::value;
-  if (FEAT) snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d,alibi>", ls.bf16 ? "bf16" : "f16", D);
+  if (FEAT) snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d,%s>", ls.bf16 ? "bf16" : "f16", D, FEAT == FEAT_CAP ? "softcap" : "alibi");
   else snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d>", ls.bf16 ? "bf16" : "f16", D);
   return 0;
 }
@@ -892,6 +947,11 @@ int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream);
 int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream);
 #if FA_W64_PART != 1
 int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream) {
+  if (p.softcap > 0.f) {
+    if (d == 128) return launch_fwd_w64_t<_Float16, 128, FEAT_CAP>(p, stream);
+    if (d == 64) return launch_fwd_w64_t<_Float16, 64, FEAT_CAP>(p, stream);
+    return -2;
+  }
   if (p.alibi) {
     if (d == 128) return launch_fwd_w64_t<_Float16, 128, FEAT_ALIBI>(p, stream);
     if (d == 64) return launch_fwd_w64_t<_Float16, 64, FEAT_ALIBI>(p, stream);
@@ -904,6 +964,11 @@ int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream) {
 #endif
 #if FA_W64_PART != 2
 int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream) {
+  if (p.softcap > 0.f) {
+    if (d == 128) return launch_fwd_w64_t<__bf16, 128, FEAT_CAP>(p, stream);
+    if (d == 64) return launch_fwd_w64_t<__bf16, 64, FEAT_CAP>(p, stream);
+    return -2;
+  }
   if (p.alibi) {
     if (d == 128) return launch_fwd_w64_t<__bf16, 128, FEAT_ALIBI>(p, stream);
     if (d == 64) return launch_fwd_w64_t<__bf16, 64, FEAT_ALIBI>(p, stream);
@@ -913,9 +978,10 @@ int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream) {
   if (d == 64) return launch_fwd_w64_t<__bf16, 64>(p, stream);
   return -2;
 }
-// 4 waves x 64 query rows per workgroup.  Plain attention, or ALiBi under a causal right bound (no softcap / dropout / split keys / paged KV).
+// 4 waves x 64 query rows per workgroup.  Plain attention, softcap, or ALiBi under a causal right bound (no dropout / split keys / paged KV, not softcap AND ALiBi).
 int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
-  if (p.softcap > 0.f || p.rng != nullptr || p.n_splits > 1 || p.block_table != nullptr) return -2;
+  if (p.rng != nullptr || p.n_splits > 1 || p.block_table != nullptr) return -2;
+  if (p.softcap > 0.f && p.alibi != nullptr) return -2;
   if (p.alibi != nullptr && p.wr != 0) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal
   // buffer addressing: 32-bit byte offsets from the (batch, kv-head) base
   const uint64_t span = ((uint64_t)(p.sk > 0 ? p.sk : 1) + 128) * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u;

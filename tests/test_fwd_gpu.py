@@ -329,3 +329,80 @@ def test_w64_causal_alibi_varlen(be, knobs):
         errs.append((float((out[a:b_].float().cpu() - ref).abs().max()), float((out8[a:b_].float().cpu() - ref).abs().max()),
                      float((lse[:, a:b_].cpu() - lse_ref).abs().max()), float((lse8[:, a:b_].cpu() - lse_ref).abs().max())))
     assert all(e64 < max(2 * e8, 1.2e-2) and l64 < max(2 * l8, 8e-3) for e64, e8, l64, l8 in errs), errs
+
+
+@pytest.mark.parametrize("mask", [(False, -1, -1), (True, -1, -1), (False, 300, 0), (False, 100, 200)], ids=["full", "causal", "local_causal", "local"])
+@pytest.mark.parametrize("softcap,dtype,scale_in", [(15.0, torch.bfloat16, 1.0), (50.0, torch.bfloat16, 1.0), (30.0, torch.float16, 1.0), (30.0, torch.bfloat16, 6.0)])
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D", [(2, 1024, 1024, 4, 4, 128), (1, 1500, 1700, 6, 2, 128), (1, 1700, 700, 2, 2, 128), (2, 2048, 2048, 4, 2, 64), (1, 333, 2100, 2, 1, 64)])
+def test_w64_softcap(be, knobs, B, Sq, Sk, H, Hk, D, softcap, dtype, scale_in, mask):
+    """Softcap on the 64-rows-per-wave forward (fa_fwd_w64_kernel<.., softcap>, round 5; reference: flash_fwd_kernel.h:357-368 + utils.h:395-409).  The chains start
+    from C = 0 and deliver 2*log2e * score*scale/softcap, the cap is applied per score on the vector ALU (three staged gaps), masked scores keep their -inf through
+    tanh's saturation, the row maximum goes through the cap once per row and step.  Against the fp64 oracle and against the lock-step kernel that served softcap
+    before.  scale_in = 6 is a stress case (capped scores of +-20 log2 units, the running maximum moves through the whole row, the cap saturates): there the once-rounded
+    Q of this schedule shows -- 0.031-0.037 against 0.016 for the lock-step kernel's fp32 scaling, LSE 0.02-0.03, tools/softcap_fwd_diag.py -- and the bound is 3x
+    instead of the reference's 2x (FA_STRICT=1 selects the exact kernels).  Sq > Sk under a causal mask: rows that see no key (LSE = +inf, zeros)."""
+    from oracle import attention_oracle as orc
+    causal, wl, wr = mask
+    torch.manual_seed(B * Sq + D + int(softcap))
+    q = torch.randn(B, Sq, H, D, device="cuda", dtype=dtype) * scale_in
+    k = torch.randn(B, Sk, Hk, D, device="cuda", dtype=dtype)
+    v = torch.randn_like(k)
+    run = lambda: be.fwd(q, k, v, None, None, 0.0, D ** -0.5, causal, wl, wr, softcap, False, None)[:2]
+    knobs.set("FA_FWD_NW", "64")
+    out, lse = run()
+    s = be.last_schedule()
+    assert s["fwd_kernel"] == 3 and "softcap" in s["name"], s
+    out_b, lse_b = run()
+    assert torch.equal(out, out_b) and torch.equal(lse, lse_b), "run-to-run"
+    knobs.set("FA_FWD_NW", "8")
+    out8, lse8 = run()
+    assert be.last_schedule()["fwd_kernel"] == 1
+    knobs.unset("FA_FWD_NW")
+    ref, lse_ref = orc.attention_fwd(q, k, v, D ** -0.5, causal, (wl, wr), softcap, None)
+    ref, lse_ref = torch.from_numpy(ref).float(), torch.from_numpy(lse_ref).float()
+    assert torch.isfinite(out.float()).all()
+    e64, e8 = float((out.float().cpu() - ref).abs().max()), float((out8.float().cpu() - ref).abs().max())
+    fin = torch.isfinite(lse_ref)
+    el = float((lse.cpu() - lse_ref)[fin].abs().max()) if fin.any() else 0.0
+    # (the scores reach the cap through a Q that was scaled and rounded once, as on the plain kernel: the LSE bound of tests/test_baseline_configs_gpu.py lse_tolerance)
+    assert e64 < max((2 if scale_in == 1.0 else 3) * e8, 1.2e-2 if dtype == torch.bfloat16 else 4e-3), (e64, e8)
+    assert el < (8e-3 if dtype == torch.bfloat16 else 2e-3) * max(1.0, scale_in), el
+    assert torch.equal(torch.isinf(lse.cpu()), ~fin)
+
+
+def test_w64_softcap_varlen_and_default_dispatch(be, knobs):
+    """The softcap variant through the packed entry point (work list or dense grid) against the sequences one by one, and the default's choice: softcap takes the
+    64-rows-per-wave kernel where plain attention does; softcap together with ALiBi or dropout stays on the lock-step kernel."""
+    import itertools
+    torch.manual_seed(9)
+    lens_q = [700, 33, 1500, 256, 1, 900, 0, 300]
+    lens_k = [700, 65, 1500, 300, 77, 513, 5, 2048]
+    H, Hk, D, cap = 4, 2, 128, 20.0
+    cu_q = torch.tensor([0] + list(itertools.accumulate(lens_q)), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0] + list(itertools.accumulate(lens_k)), dtype=torch.int32, device="cuda")
+    q = torch.randn(sum(lens_q), H, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(sum(lens_k), Hk, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    knobs.set("FA_FWD_NW", "64")
+    out, lse = be.varlen_fwd(q, k, v, None, cu_q, cu_k, None, None, None, None, max(lens_q), max(lens_k), 0.0, D ** -0.5, False, True, -1, -1, cap, False, None)[:2]
+    s = be.last_schedule()
+    assert s["fwd_kernel"] == 3 and "softcap" in s["name"], s
+    for b in range(len(lens_q)):
+        a0, a1, b0, b1 = int(cu_q[b]), int(cu_q[b + 1]), int(cu_k[b]), int(cu_k[b + 1])
+        if a1 == a0:
+            continue
+        o1, l1 = be.fwd(q[None, a0:a1], k[None, b0:b1], v[None, b0:b1], None, None, 0.0, D ** -0.5, True, -1, -1, cap, False, None)[:2]
+        if be.last_schedule()["fwd_kernel"] == 3:   # the same kernel on the same rows: bit for bit
+            assert torch.equal(out[a0:a1], o1[0]) and torch.equal(lse[:, a0:a1], l1[0]), b
+        else:                                        # (a very short sequence on its own may take another schedule: head packing, the 4-wave kernel)
+            assert float((out[a0:a1].float() - o1[0].float()).abs().max()) < 2e-2 and float((lse[:, a0:a1] - l1[0]).abs().max()) < 8e-3, b
+    knobs.unset("FA_FWD_NW")
+    q4 = torch.randn(2, 4096, 8, 128, device="cuda", dtype=torch.bfloat16)
+    k4, v4 = torch.randn_like(q4), torch.randn_like(q4)
+    be.fwd(q4, k4, v4, None, None, 0.0, 128 ** -0.5, True, -1, -1, 30.0, False, None)
+    s = be.last_schedule()
+    assert s["fwd_kernel"] == 3 and "softcap" in s["name"], s
+    be.fwd(q4, k4, v4, None, torch.full((8,), 0.1, device="cuda"), 0.0, 128 ** -0.5, True, -1, -1, 30.0, False, None)
+    assert be.last_schedule()["fwd_kernel"] == 1
+    be.fwd(q4, k4, v4, None, None, 0.1, 128 ** -0.5, True, -1, -1, 30.0, False, None)
+    assert be.last_schedule()["fwd_kernel"] == 1
