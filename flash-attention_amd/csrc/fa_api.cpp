@@ -157,7 +157,8 @@ int64_t splitkv_bytes(const FaFwdParams* a, int n_splits) {
 bool w64_span_ok(const FaFwdParams* a) {
   const uint64_t rs = (uint64_t)std::max<int64_t>(a->k_row_stride, a->v_row_stride);
   const uint64_t qo = (uint64_t)std::max<int64_t>(a->q_row_stride, a->o_row_stride);
-  return ((uint64_t)(a->seqlen_k > 0 ? a->seqlen_k : 1) + 128) * rs * 2u < (1ull << 32) && 256ull * qo * 2u < (1ull << 32);
+  const uint64_t keys = a->block_table ? 64 : (a->seqlen_k > 0 ? a->seqlen_k : 1);   // (a paged cache is addressed tile by tile)
+  return (keys + 128) * rs * 2u < (1ull << 32) && 256ull * qo * 2u < (1ull << 32);
 }
 int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
   // Schedule (measured on MI355X, tools/ab_bench.py, profiles/r03_fwd_schedules.txt; FA_FWD_NW overrides):
@@ -228,7 +229,8 @@ int check_common(int b, int h, int h_k, int d, int dtype, float softcap, bool fo
 // What the heuristic's pick becomes once the features have had their say (shared by do_fwd and fa_fwd_schedule_query):
 //   64 = the 64-rows-per-wave kernel: plain attention, ALiBi under a right bound on the diagonal (its FEAT_ALIBI variant: the bias rides in the
 //        score chains' C operand, key tiles walked downwards), or softcap (FEAT_CAP, round 5: seven vector instructions per score, staged over three
-//        gaps); anything else that asked for it runs the 8-wave lock-step kernel on the same 256-row blocks;
+//        gaps), and plain attention over a paged cache (round 5: a buffer descriptor per 64-key tile); anything else that asked for it runs the 8-wave
+//        lock-step kernel on the same 256-row blocks;
 //   34 / 38 = the software-pipelined kernel with 4 / 8 waves: plain attention only, else the lock-step kernel with the same wave count.
 int resolve_fwd_features(const FaFwdParams* a, int nw, int wr, int n_splits, int pack, bool bounded, bool& w64, bool& il) {
   const bool base0 = !(a->p_dropout > 0.f) && n_splits == 1 && pack == 1 && !bounded;
@@ -236,7 +238,9 @@ int resolve_fwd_features(const FaFwdParams* a, int nw, int wr, int n_splits, int
   const bool plain = base && !a->alibi_slopes;
   const bool w64_alibi = base && a->alibi_slopes && wr == 0;
   const bool w64_cap = base0 && a->softcap > 0.f && !a->alibi_slopes;
-  w64 = nw == 64 && (plain || w64_alibi || w64_cap) && !a->block_table;
+  // (a paged cache: the plain variant only, and not together with a batch index or left padding -- the API rejects those combinations anyway)
+  const bool paged_ok = !a->block_table || (plain && !a->cache_batch_idx && !a->leftpad_k && a->page_block_size % 64 == 0);
+  w64 = nw == 64 && (plain || w64_alibi || w64_cap) && paged_ok;
   if (nw == 64 && !w64) nw = 8;
   il = (nw == 34 || nw == 38) && plain;
   if ((nw == 34 || nw == 38) && !il) nw -= 30;

@@ -103,9 +103,16 @@ template <typename E, int T> FA_DEVINL void mfma_o_acc(u32x4 a, u32x4 b) {
 // saturation: -inf * 2^-100 --, exp2, row sum), staged over three gaps so that no instruction waits for the one before it; the row-max tree runs on y itself (tanh is
 // monotone) and the decision maps the row maximum once per row and step.  Elements are spread 20 : 12 over the two halves of the step instead of 24 : 8 (the
 // score half has the K reads and the DMA, the other half the packing and the tree).
-template <typename E, int D, int FEAT = 0>
+//
+// PAGED = keys and values live in a paged cache (FwdK::block_table; reference: the block_table path of compute_attn_1rowblock_splitkv, flash_fwd_kernel.h:505-1078,
+// and of mha_varlen_fwd, flash_api.cpp:538-788).  A page holds a multiple of 256 keys, so a 64-key tile never straddles two: every tile gets its own buffer
+// descriptor -- base = pool + table[b][page] * page_stride + the tile's rows inside the page, range = the tile's rows that exist -- made from scalars at the
+// head of its iteration (~30 scalar instructions per iteration); the table entry of the tile after next is requested one iteration ahead.  Pools of any size
+// (the 32-bit offsets only span a tile).  Plain attention only.
+template <typename E, int D, int FEAT = 0, bool PAGED = false>
 __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   constexpr bool ALIBI = FEAT == FEAT_ALIBI;
+  static_assert(!PAGED || FEAT == 0, "the paged variant serves plain attention");
   constexpr bool SOFTCAP = FEAT == FEAT_CAP;
   constexpr bool DESC = ALIBI;   // iteration u scores key tile n_tiles - 1 - u instead of tile u
   static_assert(FEAT == 0 || FEAT == FEAT_ALIBI || FEAT == FEAT_CAP, "feature variants of this schedule: none, causal ALiBi, softcap");
@@ -178,6 +185,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       k.sk = max(0, k.sk - lp);
       k.k_row0 += lp;
     }
+    if constexpr (PAGED) { k.k_boff = 0; k.v_boff = 0; k.k_row0 = 0; }   // the page table supplies the rows, cu_seqlens_k / seqused_k only the lengths
     return k.m_block * BM < k.sq;
   };
   // this wave's 64 rows of a block's Q -> its rows of the LDS Q region (coalesced DMA, K-style swizzle on the source chunk)
@@ -296,6 +304,35 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   // records zero-fills a whole tile without touching memory -- tiles past the last one, and the V tile the pipeline's first two
   // steps multiply by P = 0, are "loaded" that way.
   const u32x4 null_srd = {k_srd[0], k_srd[1], 0u, k_srd[3]};
+  // (PAGED) table entry of a page (clamped into the sequence's pages: a tile past the end reads nothing, its descriptor has no records), and the descriptor of
+  // absolute tile n: tile tin of page entry blk
+  const int pg_tpp = __builtin_amdgcn_readfirstlane(PAGED ? p.page_size / BN : 1);   // tiles per page
+  const int pg_last = __builtin_amdgcn_readfirstlane(sk > 0 ? (sk - 1) / max(p.page_size, 1) : 0);   // the sequence's last page
+  const int* __restrict__ pg_table = p.block_table + (PAGED ? (int64_t)__builtin_amdgcn_readfirstlane(b) * p.block_table_bs : 0);
+  auto page_entry = [&](int page) __attribute__((always_inline)) {
+    const int pc = min(max(page, 0), pg_last);
+    return __builtin_amdgcn_readfirstlane(pg_table[pc]);
+  };
+  // (all scalar: a page's bytes and a tile's bytes fit 32 bits -- checked by the launcher --, so the address is one 32 x 32 -> 64 multiply, one 32-bit multiply and
+  // two 64-bit adds; at one wave per SIMD every instruction of the iteration's head is exposed)
+  const unsigned pg_bytes_k = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p.k_bs * 2)), pg_bytes_v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(p.v_bs * 2));
+  const unsigned tl_bytes_k = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(BN * p.k_rs * 2)), tl_bytes_v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(BN * p.v_rs * 2));
+  // (readfirstlane returns a SIGNED int: through unsigned before it is widened, or a low half with bit 31 set sign-extends over the high half)
+  auto uniform64 = [](const void* ptr) __attribute__((always_inline)) {
+    const unsigned long long a = (unsigned long long)ptr;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+  };
+  const unsigned long long pg_base_k = uniform64(kp), pg_base_v = uniform64(vp);
+  auto tile_srd = [&](auto isvc, int blk, int tin, int n) __attribute__((always_inline)) {
+    constexpr bool ISV = decltype(isvc)::value != 0;
+    const unsigned rs = (unsigned)(ISV ? p.v_rs : p.k_rs);
+    const int rows = (n >= 0) ? min(BN, sk - n * BN) : 0;
+    const unsigned long long a = (ISV ? pg_base_v : pg_base_k) + (unsigned long long)(unsigned)blk * (unsigned long long)(ISV ? pg_bytes_v : pg_bytes_k) + (unsigned long long)((unsigned)tin * (ISV ? tl_bytes_v : tl_bytes_k));
+    const unsigned nrec = rows > 0 ? ((unsigned)(rows - 1) * rs + (unsigned)D) * 2u : 0u;
+    u32x4 sd = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, nrec, 0x00020000u};
+    return sd;
+  };
   auto dma_pieces = [&](const u32x4& srd, const unsigned (&vo)[DPW], unsigned lds_dst) __attribute__((always_inline)) {
     unsigned keep;
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
@@ -320,6 +357,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     const bool real = t >= 0 && t < n_tiles;
     const int64_t rs = ISV ? p.v_rs : p.k_rs;
     const unsigned lds_dst = (unsigned)((ISV ? 2 + buf : buf) * TILE_BYTES + wave * DPW * 1024);
+    if constexpr (PAGED) {   // (prologue and idle iterations: everything made on the spot)
+      const int n = n_min + t, page = max(n, 0) / pg_tpp;
+      const u32x4 sd = real ? tile_srd(isvc, page_entry(page), max(n, 0) - page * pg_tpp, n) : null_srd;
+      dma_pieces(sd, ISV ? voff_l : koff_l, lds_dst);
+      return;
+    }
     const unsigned toff = real ? (unsigned)(n_min + t) * (unsigned)(BN * 2) * (unsigned)rs : 0u;
     unsigned vo[DPW];
 #pragma unroll
@@ -792,6 +835,17 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   const int m_lo = __builtin_amdgcn_readfirstlane(p_lo), m_hi = __builtin_amdgcn_readfirstlane(p_hi);
   const unsigned step_k = (unsigned)(BN * 2) * (unsigned)p.k_rs, step_v = (unsigned)(BN * 2) * (unsigned)p.v_rs;
   const int nmin_s = __builtin_amdgcn_readfirstlane(n_min), nts_s = __builtin_amdgcn_readfirstlane(n_tiles);
+  // (PAGED) table entries and in-page tile indices of the tiles the next iteration requests: K tile u + 1 and V tile u (the K tile of the iteration before);
+  // pg_nxt = the tile after those, whose entry is requested one iteration ahead
+  int pg_blk_k = 0, pg_tin_k = 0, pg_blk_v = 0, pg_tin_v = 0, pg_page_n = 0, pg_tin_n = 0;
+  auto pg_enter = [&](int u) __attribute__((always_inline)) {   // before the first active iteration u
+    if constexpr (PAGED) {
+      const int nv = n_min + u, nk = nv + 1, nn = nv + 2;
+      pg_tin_v = nv % pg_tpp; pg_blk_v = page_entry(nv / pg_tpp);
+      pg_tin_k = nk % pg_tpp; pg_blk_k = page_entry(nk / pg_tpp);
+      pg_page_n = nn / pg_tpp; pg_tin_n = nn - pg_page_n * pg_tpp;
+    }
+  };
   auto step_pair = [&](auto parc, int u) __attribute__((always_inline)) {
     constexpr int par = decltype(parc)::value;
     // K_{u+1} rides in the first step, V_u in the second.  A tile past the block's last one is requested like any other: past the last key
@@ -809,13 +863,29 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     int im32 = ((us - m_lo) | (m_hi - us)) >> 31;   // -1 outside [m_lo, m_hi] (arithmetic, not a compare + select: that one goes through a lane mask)
     dst_k = __builtin_amdgcn_readfirstlane(dst_k); dst_v = __builtin_amdgcn_readfirstlane(dst_v);
     im32 = __builtin_amdgcn_readfirstlane(im32);
+    u32x4 srd_k = k_srd, srd_v = v_srd;
+    if constexpr (PAGED) {
+      // (the carried values are wave-uniform; said so -- assigned under the "active" branch they would live in vector registers and drag the arithmetic there)
+      const int bk = __builtin_amdgcn_readfirstlane(pg_blk_k), tk = __builtin_amdgcn_readfirstlane(pg_tin_k);
+      const int bv = __builtin_amdgcn_readfirstlane(pg_blk_v), tv = __builtin_amdgcn_readfirstlane(pg_tin_v);
+      const int pn = __builtin_amdgcn_readfirstlane(pg_page_n), tn = __builtin_amdgcn_readfirstlane(pg_tin_n);
+      srd_k = tile_srd(ICw<0>{}, bk, tk, nmin_s + us + 1);
+      srd_v = tile_srd(ICw<1>{}, bv, tv, nmin_s + us);
+      tk_ = 0u; tv_ = 0u;
+      // next iteration: its V tile is this one's K tile; its K tile is pg_nxt, whose entry has a whole iteration to arrive
+      pg_blk_v = bk; pg_tin_v = tk;
+      pg_blk_k = page_entry(pn); pg_tin_k = tn;
+      const bool wrap = tn + 1 == pg_tpp;
+      pg_tin_n = wrap ? 0 : tn + 1;
+      pg_page_n = wrap ? pn + 1 : pn;
+    }
     asm volatile("" : "+s"(tk_), "+s"(tv_), "+s"(dst_k), "+s"(dst_v), "+s"(im32));
     // (each test on a freshly laundered scalar: as one hoisted boolean hipcc keeps a lane mask and spends five instructions per test)
     auto masked = [&]() __attribute__((always_inline)) { int c = im32; asm volatile("" : "+s"(c)); return c != 0; };
     if (__builtin_expect(masked(), 0)) set_mask(2 * u);
-    fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, k_srd, koff_l, tk_, dst_k, kring);
+    fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, srd_k, koff_l, tk_, dst_k, kring);
     if (__builtin_expect(masked(), 0)) set_mask(2 * u + 1);
-    fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, v_srd, voff_l, tv_, dst_v, kring);
+    fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, srd_v, voff_l, tv_, dst_v, kring);
     if (__builtin_expect(masked(), 0)) clear_mask(2 * u + 2);
     iter_end();
   };
@@ -833,6 +903,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
 #pragma unroll 1
     for (; u < ua; ++u) idle_iter(u);
     if (active) {
+      pg_enter(u);
       if constexpr (ALIBI) { if (u > 0) clear_mask(2 * u); }   // (the broadcasts were initialised for step 0)
 #pragma unroll 1
       for (;;) {
@@ -907,11 +978,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   }  // persistent block loop
 }
 
-template <typename E, int D, int FEAT = 0>
+template <typename E, int D, int FEAT = 0, bool PAGED = false>
 static int launch_fwd_w64_t(const FwdK& p, hipStream_t stream) {
   constexpr int STAGE = 256 * (D * 2 + 16);
   constexpr int smem = ((4 * 64 * D * 2 > STAGE ? 4 * 64 * D * 2 : STAGE + 1023) / 1024 * 1024) + 256 * D * 2;  // K/V buffers | O staging, then the Q block
-  auto kern = fa_fwd_w64_kernel<E, D, FEAT>;
+  auto kern = fa_fwd_w64_kernel<E, D, FEAT, PAGED>;
   static std::atomic<unsigned long long> attr_mask{0};  // the kernel addresses LDS by byte offset: the dynamic segment must start at 0
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
   const long long total = p.work_list ? (long long)p.work_bound * p.h : units_grid(p.n_units, p.unit_size);
@@ -934,6 +1005,7 @@ static int launch_fwd_w64_t(const FwdK& p, hipStream_t stream) {
   ls.fwd_kernel = 3; ls.fwd_nw = 4; ls.fwd_feat = FEAT; ls.fwd_splits = 1; ls.fwd_list = p.work_list != nullptr; ls.d = D;
   ls.bf16 = std::is_same<E, __bf16>::value;
   if (FEAT) snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d,%s>", ls.bf16 ? "bf16" : "f16", D, FEAT == FEAT_CAP ? "softcap" : "alibi");
+  else if (PAGED) snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d,paged>", ls.bf16 ? "bf16" : "f16", D);
   else snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d>", ls.bf16 ? "bf16" : "f16", D);
   return 0;
 }
@@ -957,6 +1029,11 @@ int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream) {
     if (d == 64) return launch_fwd_w64_t<_Float16, 64, FEAT_ALIBI>(p, stream);
     return -2;
   }
+  if (p.block_table) {
+    if (d == 128) return launch_fwd_w64_t<_Float16, 128, 0, true>(p, stream);
+    if (d == 64) return launch_fwd_w64_t<_Float16, 64, 0, true>(p, stream);
+    return -2;
+  }
   if (d == 128) return launch_fwd_w64_t<_Float16, 128>(p, stream);
   if (d == 64) return launch_fwd_w64_t<_Float16, 64>(p, stream);
   return -2;
@@ -974,17 +1051,25 @@ int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream) {
     if (d == 64) return launch_fwd_w64_t<__bf16, 64, FEAT_ALIBI>(p, stream);
     return -2;
   }
+  if (p.block_table) {
+    if (d == 128) return launch_fwd_w64_t<__bf16, 128, 0, true>(p, stream);
+    if (d == 64) return launch_fwd_w64_t<__bf16, 64, 0, true>(p, stream);
+    return -2;
+  }
   if (d == 128) return launch_fwd_w64_t<__bf16, 128>(p, stream);
   if (d == 64) return launch_fwd_w64_t<__bf16, 64>(p, stream);
   return -2;
 }
-// 4 waves x 64 query rows per workgroup.  Plain attention, softcap, or ALiBi under a causal right bound (no dropout / split keys / paged KV, not softcap AND ALiBi).
+// 4 waves x 64 query rows per workgroup.  Plain attention (contiguous or paged keys / values), softcap, or ALiBi under a causal right bound (no dropout / split
+// keys, not softcap AND ALiBi, features only on contiguous keys / values).
 int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
-  if (p.rng != nullptr || p.n_splits > 1 || p.block_table != nullptr) return -2;
+  if (p.rng != nullptr || p.n_splits > 1) return -2;
   if (p.softcap > 0.f && p.alibi != nullptr) return -2;
+  if (p.block_table != nullptr && (p.softcap > 0.f || p.alibi != nullptr || p.leftpad_k != nullptr || p.kv_batch_idx != nullptr || p.page_size % 64 != 0)) return -2;
   if (p.alibi != nullptr && p.wr != 0) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal
   // buffer addressing: 32-bit byte offsets from the (batch, kv-head) base
-  const uint64_t span = ((uint64_t)(p.sk > 0 ? p.sk : 1) + 128) * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u;
+  // (a paged cache is addressed tile by tile: the offsets only span 64 rows)
+  const uint64_t span = ((uint64_t)(p.block_table ? 64 : (p.sk > 0 ? p.sk : 1)) + 128) * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u;
   if (span >= (1ull << 32)) return -3;
   if (256ull * (uint64_t)(p.q_rs > p.o_rs ? p.q_rs : p.o_rs) * 2u >= (1ull << 32)) return -3;   // Q / O: 32-bit byte offsets over a block's 256 rows
   return dtype_bf16 ? launch_fwd_w64_bf16(p, d, stream) : launch_fwd_w64_f16(p, d, stream);

@@ -72,7 +72,8 @@ def test_feature_and_head_dim_fallbacks(lib):
     assert q(lib, fwd_params(4, 4096, 4096, 32, 32, 128, alibi_slopes=1)) == 8   # not causal: |i - j| is not linear in j
     assert q(lib, fwd_params(**big, alibi_slopes=1, softcap=30.0)) == 8
     assert q(lib, fwd_params(**big, p_dropout=0.1)) == 8
-    assert q(lib, fwd_params(**big, block_table=1)) == 8
+    assert q(lib, fwd_params(**big, block_table=1, page_block_size=256)) == 64   # round 5: a paged cache runs on the 64-rows-per-wave kernel (a descriptor per tile)
+    assert q(lib, fwd_params(**big, block_table=1, page_block_size=256, softcap=30.0)) == 8   # ... plain attention only
     for d in (32, 96, 192, 256, 72, 160):                               # trimmed / bounded / 256: the 4-wave lock-step kernel
         assert q(lib, fwd_params(4, 4096, 4096, 32, 32, d, causal=True)) == 4, d
     assert q(lib, fwd_params(2, 1024, 1024, 8, 8, 128, softcap=30.0)) == 4   # a pipelined choice with a feature: lock-step with the same wave count

@@ -327,3 +327,111 @@ def test_kvcache_packed_query_heads(kv, knobs, sq, h, hk, paged, num_splits, fea
         fin = np.isfinite(l_ref)
         assert max_abs(lse[b:b + 1].cpu()[torch.from_numpy(fin)], torch.from_numpy(l_ref[fin]).float()) < 2e-3
         assert max_abs(out0[b:b + 1].float().cpu(), torch.from_numpy(o_ref).float()) < 2e-2
+
+
+def _paged_pool(num_pages, page, hk, d, dtype, poison):
+    kp = torch.randn(num_pages, page, hk, d, device="cuda", dtype=dtype)
+    vp = torch.randn_like(kp)
+    return kp, vp
+
+
+@pytest.mark.parametrize("d,dtype", [(128, torch.bfloat16), (64, torch.bfloat16), (128, torch.float16)])
+@pytest.mark.parametrize("page", [256, 512])
+@pytest.mark.parametrize("mask", [(False, -1, -1), (True, -1, -1), (True, 300, 0)], ids=["full", "causal", "local_causal"])
+def test_paged_prefill_on_the_w64_kernel(knobs, d, dtype, page, mask):
+    """Round 5: plain attention over a PAGED cache on the 64-rows-per-wave forward (fa_fwd_w64_kernel<.., paged>: a buffer descriptor per 64-key tile, the table entry
+    of the tile after next requested an iteration ahead; reference: the block_table path of mha_varlen_fwd / mha_fwd_kvcache, flash_api.cpp:586-649, :1243-1531).
+    Packed queries against a shuffled page table, lengths that end inside a tile and inside a page, grouped heads; the rows of the last page behind a sequence's
+    end hold NaN (a cache page holds whatever was there: the kernel must not let it into a product -- the tile's descriptor ends at the last key).  Against the
+    fp64 oracle on the logical sequences, within 2x the error of the lock-step kernel that served paged caches before."""
+    from flash_attn_amd import backend as be
+    from oracle import attention_oracle as orc
+    causal, wl, wr = mask
+    torch.manual_seed(page + d)
+    H, hk = 8, 2
+    lens_q = [700, 1300, 64, 2048, 1]
+    lens_k = [700, 1300 + 77, 1024, 2048 + 300, 513]
+    per = (max(lens_k) + page - 1) // page
+    B = len(lens_q)
+    kp, vp = _paged_pool(B * per + 3, page, hk, d, dtype, True)
+    table = torch.randperm(B * per + 3, device="cuda")[: B * per].reshape(B, per).to(torch.int32)
+    for b in range(B):   # poison what lies behind the sequence's end in its last page
+        pg, r = lens_k[b] // page, lens_k[b] % page
+        if r:
+            kp[int(table[b, pg]), r:] = float("nan"); vp[int(table[b, pg]), r:] = float("nan")
+    cu_q = torch.tensor([0] + list(np.cumsum(lens_q)), dtype=torch.int32, device="cuda")
+    cu_k = torch.tensor([0] + list(np.cumsum(lens_k)), dtype=torch.int32, device="cuda")
+    q = torch.randn(sum(lens_q), H, d, device="cuda", dtype=dtype)
+    run = lambda: be.varlen_fwd(q, kp, vp, None, cu_q, cu_k, None, None, table, None, max(lens_q), max(lens_k), 0.0, d ** -0.5, False, causal, wl, wr, 0.0, False, None)[:2]
+    knobs.set("FA_FWD_NW", "64")
+    out, lse = run()
+    s = be.last_schedule()
+    assert s["fwd_kernel"] == 3 and "paged" in s["name"], s
+    out_b, lse_b = run()
+    assert torch.equal(out, out_b) and torch.equal(lse, lse_b), "run-to-run"
+    knobs.set("FA_FWD_NW", "8")
+    out8, lse8 = run()
+    assert be.last_schedule()["fwd_kernel"] == 1
+    knobs.unset("FA_FWD_NW")
+    assert torch.isfinite(out.float()).all()
+    k_log, v_log = kp[table.long()].reshape(B, per * page, hk, d), vp[table.long()].reshape(B, per * page, hk, d)
+    tol_o, tol_l = (1.2e-2, 8e-3) if dtype == torch.bfloat16 else (4e-3, 2e-3)
+    for b in range(B):
+        qs = slice(int(cu_q[b]), int(cu_q[b + 1]))
+        o_ref, l_ref = orc.attention_fwd(q[qs][None], k_log[b:b + 1, :lens_k[b]], v_log[b:b + 1, :lens_k[b]], None, causal, (wl, wr))
+        o_ref, l_ref = torch.from_numpy(o_ref[0]).float(), torch.from_numpy(l_ref[0]).float()
+        e64, e8 = max_abs(out[qs].float().cpu(), o_ref), max_abs(out8[qs].float().cpu(), o_ref)
+        assert e64 < max(2 * e8, tol_o), (b, e64, e8)
+        fin = torch.isfinite(l_ref)
+        assert torch.equal(torch.isposinf(lse[:, qs].cpu()), ~fin)
+        assert max_abs(lse[:, qs].cpu()[fin], l_ref[fin]) < tol_l, b
+
+
+def test_paged_kvcache_chunked_prefill_and_a_pool_above_4_gib(knobs):
+    """fwd_kvcache with a paged cache and a long query chunk takes the same kernel (append first, then attention over cache + chunk); and a pool whose pages lie
+    more than 4 GiB apart (the per-tile descriptor carries a 64-bit base: no 32-bit offset ever spans more than a tile)."""
+    from flash_attn_amd import backend as be
+    from oracle import attention_oracle as orc
+    torch.manual_seed(4)
+    B, H, hk, d, page, sq = 2, 8, 2, 128, 256, 1024
+    n_pages = 9000     # x 256 rows x 2 heads x 128 x 2 B = 1.2 GB per tensor; the > 4 GiB case follows below
+    kp = torch.randn(n_pages, page, hk, d, device="cuda", dtype=torch.bfloat16)
+    vp = torch.randn_like(kp)
+    lens = torch.tensor([1500, 333], dtype=torch.int32, device="cuda")
+    per = (1500 + sq + page - 1) // page
+    table = torch.tensor([[8999 - 7 * i for i in range(per)], [5 + 11 * i for i in range(per)]], dtype=torch.int32, device="cuda")
+    q = torch.randn(B, sq, H, d, device="cuda", dtype=torch.bfloat16)
+    kn = torch.randn(B, sq, hk, d, device="cuda", dtype=torch.bfloat16)
+    vn = torch.randn_like(kn)
+    knobs.set("FA_FWD_NW", "64")
+    out, lse = be.fwd_kvcache(q, kp, vp, kn, vn, lens, None, None, None, None, table, None, None, d ** -0.5, True, -1, -1, 0.0, True, 1)
+    s = be.last_schedule()
+    assert s["fwd_kernel"] == 3 and "paged" in s["name"], s
+    knobs.unset("FA_FWD_NW")
+    for b in range(B):
+        L = int(lens[b]) + sq
+        kl = kp[table[b].long()].reshape(per * page, hk, d)[:L]
+        vl = vp[table[b].long()].reshape(per * page, hk, d)[:L]
+        assert torch.equal(kl[L - sq:], kn[b])
+        o_ref, l_ref = orc.attention_fwd(q[b:b + 1], kl[None], vl[None], None, True)
+        assert max_abs(out[b].float().cpu(), torch.from_numpy(o_ref[0]).float()) < 1.2e-2
+        assert max_abs(lse[b].cpu(), torch.from_numpy(l_ref[0]).float()) < 8e-3
+    # pages more than 4 GiB apart: 40000 pages x 256 rows x 1 head x 128 x 2 B = 2.6 GB per 10000 pages -> page 39999 sits 10.5 GB behind page 0
+    hk1, n_big = 1, 40000
+    kp = torch.zeros(n_big, page, hk1, d, device="cuda", dtype=torch.bfloat16)
+    vp = torch.zeros_like(kp)
+    ids = torch.tensor([39999, 3, 20001, 17000], dtype=torch.int64, device="cuda")
+    kp[ids] = torch.randn(4, page, hk1, d, device="cuda", dtype=torch.bfloat16)
+    vp[ids] = torch.randn(4, page, hk1, d, device="cuda", dtype=torch.bfloat16)
+    table = ids.to(torch.int32)[None].contiguous()
+    L = 4 * page - 100
+    q = torch.randn(1, 600, 4, d, device="cuda", dtype=torch.bfloat16)
+    knobs.set("FA_FWD_NW", "64")
+    out, lse = be.fwd_kvcache(q, kp, vp, None, None, torch.tensor([L], dtype=torch.int32, device="cuda"), None, None, None, None, table, None, None, d ** -0.5, True,
+                              -1, -1, 0.0, True, 1)
+    s = be.last_schedule()
+    knobs.unset("FA_FWD_NW")
+    assert s["fwd_kernel"] == 3 and "paged" in s["name"], s
+    kl, vl = kp[ids].reshape(4 * page, hk1, d)[:L], vp[ids].reshape(4 * page, hk1, d)[:L]
+    o_ref, l_ref = orc.attention_fwd(q, kl[None], vl[None], None, True)
+    assert max_abs(out.float().cpu(), torch.from_numpy(o_ref).float()) < 1.2e-2 and max_abs(lse.cpu(), torch.from_numpy(l_ref).float()) < 8e-3
