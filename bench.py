@@ -260,6 +260,15 @@ def feature_rows(be, dev, sync, B, H, S, D):
         _, mb = time_kernel(h, 8, 2, sync)
         out["causal_softcap"] = {"fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
                                  "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name}
+        # ... and with dropout 0.1 (round 5: forward on the 64-rows-per-wave kernel's dropout variant; the backward on the feature kernels of fa_bwd.hip)
+        f = lambda: be.fwd(q, k, v, None, None, 0.1, sc, True, -1, -1, 0.0, False, None)
+        _, ms = time_kernel(f, 20, 5, sync)
+        name = be.last_schedule()["name"]
+        o, l, _, rng = f()
+        h = lambda: be.bwd(g, q, k, v, o, l, None, None, None, None, 0.1, sc, True, -1, -1, 0.0, False, None, rng)
+        _, mb = time_kernel(h, 8, 2, sync)
+        out["causal_dropout"] = {"fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
+                                 "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name}
         return out
     except Exception as e:   # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
@@ -615,6 +624,9 @@ def main(argv=None):
             cs = extras["features"].get("causal_softcap")
             if cs:
                 res["causal_softcap"] = [cs["fwd_tflops"], cs["bwd_tflops"], cs["fwd_bwd_tflops"]]
+            cd = extras["features"].get("causal_dropout")
+            if cd:
+                res["causal_dropout"] = [cd["fwd_tflops"], cd["bwd_tflops"], cd["fwd_bwd_tflops"]]
         if world == 1 and not a.no_parity:
             extras["parity"] = parity_report(be, dev, q, k, v, causal)
             t = extras["parity"].get("tensors")

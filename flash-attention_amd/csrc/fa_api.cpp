@@ -229,18 +229,20 @@ int check_common(int b, int h, int h_k, int d, int dtype, float softcap, bool fo
 // What the heuristic's pick becomes once the features have had their say (shared by do_fwd and fa_fwd_schedule_query):
 //   64 = the 64-rows-per-wave kernel: plain attention, ALiBi under a right bound on the diagonal (its FEAT_ALIBI variant: the bias rides in the
 //        score chains' C operand, key tiles walked downwards), or softcap (FEAT_CAP, round 5: seven vector instructions per score, staged over three
-//        gaps), and plain attention over a paged cache (round 5: a buffer descriptor per 64-key tile); anything else that asked for it runs the 8-wave
-//        lock-step kernel on the same 256-row blocks;
+//        gaps), dropout without the random-byte output (FEAT_DROP, round 5: eight Philox calls per step spread two rounds per gap), and plain attention over
+//        a paged cache (round 5: a buffer descriptor per 64-key tile); anything else that asked for it runs the 8-wave lock-step kernel on the same 256-row blocks;
 //   34 / 38 = the software-pipelined kernel with 4 / 8 waves: plain attention only, else the lock-step kernel with the same wave count.
 int resolve_fwd_features(const FaFwdParams* a, int nw, int wr, int n_splits, int pack, bool bounded, bool& w64, bool& il) {
-  const bool base0 = !(a->p_dropout > 0.f) && n_splits == 1 && pack == 1 && !bounded;
+  const bool shape_ok = n_splits == 1 && pack == 1 && !bounded;
+  const bool base0 = !(a->p_dropout > 0.f) && shape_ok;
   const bool base = base0 && !(a->softcap > 0.f);
   const bool plain = base && !a->alibi_slopes;
   const bool w64_alibi = base && a->alibi_slopes && wr == 0;
   const bool w64_cap = base0 && a->softcap > 0.f && !a->alibi_slopes;
+  const bool w64_drop = shape_ok && a->p_dropout > 0.f && !a->randval && !(a->softcap > 0.f) && !a->alibi_slopes && !a->block_table;   // (no random-byte output there)
   // (a paged cache: the plain variant only, and not together with a batch index or left padding -- the API rejects those combinations anyway)
   const bool paged_ok = !a->block_table || (plain && !a->cache_batch_idx && !a->leftpad_k && a->page_block_size % 64 == 0);
-  w64 = nw == 64 && (plain || w64_alibi || w64_cap) && paged_ok;
+  w64 = nw == 64 && (plain || w64_alibi || w64_cap || w64_drop) && paged_ok;
   if (nw == 64 && !w64) nw = 8;
   il = (nw == 34 || nw == 38) && plain;
   if ((nw == 34 || nw == 38) && !il) nw -= 30;

@@ -104,6 +104,13 @@ template <typename E, int T> FA_DEVINL void mfma_o_acc(u32x4 a, u32x4 b) {
 // monotone) and the decision maps the row maximum once per row and step.  Elements are spread 20 : 12 over the two halves of the step instead of 24 : 8 (the
 // score half has the K reads and the DMA, the other half the packing and the tree).
 //
+// FEAT_DROP = dropout (round 5; reference: flash_fwd_kernel.h:357-368 + dropout.h; the random stream is fa_device.h drop_bytes, the same element -> byte map the
+// lock-step kernel and both backward kernels use, so the mask is the same whatever kernel draws it).  Four consecutive keys of a row share one Philox2x32-7 call
+// and they are the four accumulator rows 4*g .. 4*g+3 of a lane: eight calls per step and lane, 7 rounds x 3 instructions each (the round keys are per (batch,
+// head): scalars), spread two rounds per gap over the step; a finished word waits until its elements are packed for the P.V product, where the dropped ones
+// become zeros (byte compare + select per element).  The row sums keep the un-dropped probabilities; 1/(1-p) meets O in the epilogue.  No random-byte output
+// (return_softmax): the lock-step kernel serves that.
+//
 // PAGED = keys and values live in a paged cache (FwdK::block_table; reference: the block_table path of compute_attn_1rowblock_splitkv, flash_fwd_kernel.h:505-1078,
 // and of mha_varlen_fwd, flash_api.cpp:538-788).  A page holds a multiple of 256 keys, so a 64-key tile never straddles two: every tile gets its own buffer
 // descriptor -- base = pool + table[b][page] * page_stride + the tile's rows inside the page, range = the tile's rows that exist -- made from scalars at the
@@ -114,8 +121,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   constexpr bool ALIBI = FEAT == FEAT_ALIBI;
   static_assert(!PAGED || FEAT == 0, "the paged variant serves plain attention");
   constexpr bool SOFTCAP = FEAT == FEAT_CAP;
+  constexpr bool DROP = FEAT == FEAT_DROP;
   constexpr bool DESC = ALIBI;   // iteration u scores key tile n_tiles - 1 - u instead of tile u
-  static_assert(FEAT == 0 || FEAT == FEAT_ALIBI || FEAT == FEAT_CAP, "feature variants of this schedule: none, causal ALiBi, softcap");
+  static_assert(FEAT == 0 || FEAT == FEAT_ALIBI || FEAT == FEAT_CAP || FEAT == FEAT_DROP, "feature variants of this schedule: none, causal ALiBi, softcap, dropout");
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   constexpr int NW = 4, QB = 2, BM = NW * 64, BN = 64, CPR = D / 8;
@@ -474,6 +482,16 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     cap_m2c = -2.f * capc;
     capoff[0] = capc; capoff[1] = capc;
   }
+  // (DROP) the seven round keys of this (batch, head) -- uniform --, the keep threshold, and each lane's row (the second word of the Philox counter)
+  unsigned drop_kr[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u}, drop_thr = 255u, drop_row[QB] = {0u, 0u};
+  if constexpr (DROP) {
+    const unsigned k0_ = (unsigned)__builtin_amdgcn_readfirstlane((int)drop_bh_key(p.rng, b * p.h + h));
+#pragma unroll
+    for (int r = 0; r < 7; ++r) drop_kr[r] = k0_ + (unsigned)r * 0x9E3779B9u;
+    drop_thr = (unsigned)__builtin_amdgcn_readfirstlane((int)p.drop_thr8);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) drop_row[qb] = (unsigned)(w_row0 + 32 * qb + qi);
+  }
   constexpr float kCapTiny = 7.888609052210118e-31f;   // 2^-100: y * tiny vanishes for every finite y and keeps a masked score's -inf
   unsigned long long lag_mask = 0ull;   // wave-uniform, all ones or zero: some o_lag != 1 is waiting to be applied to O
   f32x16 negm[QB];     // the C operand of every score chain's first MFMA: -m broadcast (0 while m = -inf), plus the ALiBi bias of the step's keys
@@ -626,9 +644,13 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   //   checked in the ISA by tools/isa_blocks.py --m0).
   auto fast_step = [&](auto halfc, auto parc, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
                        const u32x4 (&pf_prev)[QB][2], u32x4 (&pf_cur)[QB][2], const u32x4& dma_srd, const unsigned (&dma_off)[DPW],
-                       unsigned dma_toff, unsigned dma_dst, u32x4 (&kfr)[FA_W64_AH + 1]) __attribute__((always_inline)) {
+                       unsigned dma_toff, unsigned dma_dst, u32x4 (&kfr)[FA_W64_AH + 1], int drop_k0q = 0) __attribute__((always_inline)) {
     constexpr int half = decltype(halfc)::value, par = decltype(parc)::value;
     constexpr int QKG = 2 * KS, PVG = 4 * DB, NG = QKG + PVG;
+    // (DROP) group G = 4*qb + g (elements 16*qb + 4*g .. + 3 = keys k0 + 8*g + 4*hi .. + 3 of the step whose probabilities this step makes, k0 = 4 * drop_k0q):
+    // round r of its Philox call sits in gap ((7*G + r) * (NG - 2)) / 56 -- two rounds per gap at D = 128, the last group done one gap before its elements are packed
+    auto drop_gap = [](int G, int r) constexpr { return ((7 * G + r) * (NG - 2)) / 56; };
+    unsigned ph_c0[8], ph_c1[8];
     constexpr int KOFF = par * TILE_BYTES + half * 32 * ROW_BYTES;                       // K_u: buffer u & 1
     constexpr int VOFF = (2 + (par ^ 1)) * TILE_BYTES + half * 32 * ROW_BYTES;           // V_{u-1}: buffer (u - 1) & 1
     constexpr int AH = FA_W64_AH, RING = AH + 1;  // operand reads run AH fragment slots (2 gaps each) ahead of their MFMAs
@@ -709,6 +731,20 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
           negm[e >> 4][e & 15] = nv;
         }
       }
+      if constexpr (DROP) {
+#pragma unroll
+        for (int G = 0; G < 8; ++G)
+#pragma unroll
+          for (int r = 0; r < 7; ++r)
+            if (drop_gap(G, r) == x) {
+              if (r == 0) { ph_c0[G] = (unsigned)(drop_k0q + 2 * (G & 3)) + (unsigned)hi; ph_c1[G] = drop_row[G >> 2]; }
+              const unsigned mh = __umulhi(0xD256D193u, ph_c0[G]), ml = 0xD256D193u * ph_c0[G];
+              unsigned x3;   // mh ^ round key ^ c1 in ONE instruction (the key is a scalar operand; hipcc renders the C expression as two v_xor)
+              asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(x3) : "v"(mh), "s"(drop_kr[r]), "v"(ph_c1[G]));
+              ph_c0[G] = x3;
+              ph_c1[G] = ml;
+            }
+      }
       if constexpr (SOFTCAP) {
         // three stages, oldest elements first: C = exp2 + row sum, B = rcp + the exponent, A = the mask carrier, exp2 and +1
 #pragma unroll
@@ -742,8 +778,15 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
           const int j = c >> 2, m = c & 3, cq = j >> 1, t = j & 1;
           using V2 = __attribute__((ext_vector_type(2))) E;
           V2 pr;
-          pr[0] = (E)pe[cq][8 * t + 2 * m];
-          pr[1] = (E)pe[cq][8 * t + 2 * m + 1];
+          float pv0 = pe[cq][8 * t + 2 * m], pv1 = pe[cq][8 * t + 2 * m + 1];
+          if constexpr (DROP) {   // element r = 8*t + 2*m: byte r & 3 of its group's word; kept iff byte <= threshold (fa_kernel_params.h drop_thr8)
+            const int r0 = 8 * t + 2 * m;
+            const unsigned w = ph_c0[4 * cq + (r0 >> 2)];
+            pv0 = (((w >> (8 * (r0 & 3))) & 0xffu) > drop_thr) ? 0.f : pv0;
+            pv1 = (((w >> (8 * ((r0 + 1) & 3))) & 0xffu) > drop_thr) ? 0.f : pv1;
+          }
+          pr[0] = (E)pv0;
+          pr[1] = (E)pv1;
           unsigned pw = __builtin_bit_cast(unsigned, pr);
           asm volatile("" : "+v"(pw));   // pinned to this gap (hipcc otherwise sinks the conversions into the next step's head)
           pf_cur[cq][t][m] = pw;
@@ -883,9 +926,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     // (each test on a freshly laundered scalar: as one hoisted boolean hipcc keeps a lane mask and spends five instructions per test)
     auto masked = [&]() __attribute__((always_inline)) { int c = im32; asm volatile("" : "+s"(c)); return c != 0; };
     if (__builtin_expect(masked(), 0)) set_mask(2 * u);
-    fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, srd_k, koff_l, tk_, dst_k, kring);
+    fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, srd_k, koff_l, tk_, dst_k, kring, DROP ? step_key(2 * us - 1) >> 2 : 0);
     if (__builtin_expect(masked(), 0)) set_mask(2 * u + 1);
-    fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, srd_v, voff_l, tv_, dst_v, kring);
+    fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, srd_v, voff_l, tv_, dst_v, kring, DROP ? step_key(2 * us) >> 2 : 0);
     if (__builtin_expect(masked(), 0)) clear_mask(2 * u + 2);
     iter_end();
   };
@@ -941,7 +984,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     });
     const float l_tot = half_sum(l_run[qb][0] + l_run[qb][1]);
     const bool dead = (l_tot == 0.f) || (l_tot != l_tot);
-    const float inv = (dead ? 1.f : 1.f / l_tot) * o_lag[qb];   // normalisation and the pending rescale factor in one multiply per element
+    const float inv = (dead ? 1.f : 1.f / l_tot) * o_lag[qb] * (DROP ? p.rp_keep : 1.f);   // normalisation, the pending rescale factor (and 1/(1-p) under dropout) in one multiply per element
     const int row0 = w_row0 + 32 * qb;
     if (row0 < sq) {
       // 32 rows through this wave's staging rows, then whole-row stores through the block's O descriptor: rows past the sequence
@@ -1004,7 +1047,7 @@ static int launch_fwd_w64_t(const FwdK& p, hipStream_t stream) {
   LastSchedule& ls = last_schedule();
   ls.fwd_kernel = 3; ls.fwd_nw = 4; ls.fwd_feat = FEAT; ls.fwd_splits = 1; ls.fwd_list = p.work_list != nullptr; ls.d = D;
   ls.bf16 = std::is_same<E, __bf16>::value;
-  if (FEAT) snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d,%s>", ls.bf16 ? "bf16" : "f16", D, FEAT == FEAT_CAP ? "softcap" : "alibi");
+  if (FEAT) snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d,%s>", ls.bf16 ? "bf16" : "f16", D, FEAT == FEAT_CAP ? "softcap" : FEAT == FEAT_DROP ? "dropout" : "alibi");
   else if (PAGED) snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d,paged>", ls.bf16 ? "bf16" : "f16", D);
   else snprintf(ls.name, sizeof(ls.name), "fa::fa_fwd_w64_kernel<%s,%d>", ls.bf16 ? "bf16" : "f16", D);
   return 0;
@@ -1019,6 +1062,11 @@ int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream);
 int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream);
 #if FA_W64_PART != 1
 int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream) {
+  if (p.rng) {
+    if (d == 128) return launch_fwd_w64_t<_Float16, 128, FEAT_DROP>(p, stream);
+    if (d == 64) return launch_fwd_w64_t<_Float16, 64, FEAT_DROP>(p, stream);
+    return -2;
+  }
   if (p.softcap > 0.f) {
     if (d == 128) return launch_fwd_w64_t<_Float16, 128, FEAT_CAP>(p, stream);
     if (d == 64) return launch_fwd_w64_t<_Float16, 64, FEAT_CAP>(p, stream);
@@ -1041,6 +1089,11 @@ int launch_fwd_w64_f16(const FwdK& p, int d, hipStream_t stream) {
 #endif
 #if FA_W64_PART != 2
 int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream) {
+  if (p.rng) {
+    if (d == 128) return launch_fwd_w64_t<__bf16, 128, FEAT_DROP>(p, stream);
+    if (d == 64) return launch_fwd_w64_t<__bf16, 64, FEAT_DROP>(p, stream);
+    return -2;
+  }
   if (p.softcap > 0.f) {
     if (d == 128) return launch_fwd_w64_t<__bf16, 128, FEAT_CAP>(p, stream);
     if (d == 64) return launch_fwd_w64_t<__bf16, 64, FEAT_CAP>(p, stream);
@@ -1060,10 +1113,11 @@ int launch_fwd_w64_bf16(const FwdK& p, int d, hipStream_t stream) {
   if (d == 64) return launch_fwd_w64_t<__bf16, 64>(p, stream);
   return -2;
 }
-// 4 waves x 64 query rows per workgroup.  Plain attention (contiguous or paged keys / values), softcap, or ALiBi under a causal right bound (no dropout / split
-// keys, not softcap AND ALiBi, features only on contiguous keys / values).
+// 4 waves x 64 query rows per workgroup.  Plain attention (contiguous or paged keys / values), softcap, dropout, or ALiBi under a causal right bound (no split
+// keys, one feature at a time, features only on contiguous keys / values).
 int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
-  if (p.rng != nullptr || p.n_splits > 1) return -2;
+  if (p.n_splits > 1) return -2;
+  if (p.rng != nullptr && (p.randval != nullptr || p.softcap > 0.f || p.alibi != nullptr || p.block_table != nullptr)) return -2;   // dropout: alone, and without the random-byte output
   if (p.softcap > 0.f && p.alibi != nullptr) return -2;
   if (p.block_table != nullptr && (p.softcap > 0.f || p.alibi != nullptr || p.leftpad_k != nullptr || p.kv_batch_idx != nullptr || p.page_size % 64 != 0)) return -2;
   if (p.alibi != nullptr && p.wr != 0) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal

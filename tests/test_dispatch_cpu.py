@@ -66,12 +66,13 @@ def test_sweep_rows_and_grid_fill(lib):
 def test_feature_and_head_dim_fallbacks(lib):
     big = dict(B=4, Sq=4096, Sk=4096, H=32, Hk=32, D=128, causal=True)
     assert q(lib, fwd_params(**big, softcap=30.0)) == 64                # round 5: the softcap variant of the 64-rows-per-wave kernel
-    assert q(lib, fwd_params(**big, p_dropout=0.1)) == 8                # other features: 8-wave lock-step on the same 256-row blocks
+    assert q(lib, fwd_params(**big, p_dropout=0.1)) == 64               # ... and its dropout variant
+    assert q(lib, fwd_params(**big, p_dropout=0.1, randval=1)) == 8     # the random-byte output (return_softmax) and feature products: 8-wave lock-step on the same 256-row blocks
     assert q(lib, fwd_params(**big, alibi_slopes=1)) == 64               # causal ALiBi: the variant of the 64-rows-per-wave kernel
     assert q(lib, fwd_params(**big, alibi_slopes=1, bf16=False)) == 64
     assert q(lib, fwd_params(4, 4096, 4096, 32, 32, 128, alibi_slopes=1)) == 8   # not causal: |i - j| is not linear in j
     assert q(lib, fwd_params(**big, alibi_slopes=1, softcap=30.0)) == 8
-    assert q(lib, fwd_params(**big, p_dropout=0.1)) == 8
+    assert q(lib, fwd_params(**big, p_dropout=0.1, softcap=30.0)) == 8
     assert q(lib, fwd_params(**big, block_table=1, page_block_size=256)) == 64   # round 5: a paged cache runs on the 64-rows-per-wave kernel (a descriptor per tile)
     assert q(lib, fwd_params(**big, block_table=1, page_block_size=256, softcap=30.0)) == 8   # ... plain attention only
     for d in (32, 96, 192, 256, 72, 160):                               # trimmed / bounded / 256: the 4-wave lock-step kernel

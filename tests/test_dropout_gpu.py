@@ -194,3 +194,82 @@ def test_dropout_combined_with_alibi_or_softcap(be, feature):
     rq, rk, rvv, _ = orc.attention_bwd(do, q, k, v, None, None, scale, True, (-1, -1), cap, al, p, keep)
     for got, ref in ((dq, rq), (dk, rk), (dv, rvv)):
         assert max_abs(got.float().cpu(), torch.from_numpy(ref)) < 6e-2 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("mask", [(False, -1, -1), (True, -1, -1), (True, 300, 0)], ids=["full", "causal", "local_causal"])
+@pytest.mark.parametrize("p,dtype", [(0.17, torch.bfloat16), (0.5, torch.bfloat16), (0.25, torch.float16)])
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D", [(2, 1024, 1024, 4, 4, 128), (1, 1500, 1700, 6, 2, 128), (1, 1700, 700, 2, 2, 128), (2, 2048, 2048, 4, 2, 64)])
+def test_w64_dropout_forward(knobs, B, Sq, Sk, H, Hk, D, p, dtype, mask):
+    """Round 5: dropout on the 64-rows-per-wave forward (fa_fwd_w64_kernel<.., dropout>; reference: flash_fwd_kernel.h:357-368 + dropout.h).  The random stream is a
+    pure function of (rng_state, batch, head, row, key), so this kernel must drop exactly the pairs the lock-step kernel drops: the mask is taken from the lock-step
+    kernel's return_softmax payload under the SAME seeded generator and fed to the fp64 oracle; the two kernels' outputs then differ by rounding only, the LSE is that
+    of the un-dropped scores, and a backward driven by this forward's (out, lse, rng_state) meets the oracle's gradients (the backward kernels regenerate the mask)."""
+    from flash_attn_amd import backend as be
+    from oracle import attention_oracle as orc
+    causal, wl, wr = mask
+    torch.manual_seed(B * Sq + D)
+    q = torch.randn(B, Sq, H, D, device="cuda", dtype=dtype)
+    k = torch.randn(B, Sk, Hk, D, device="cuda", dtype=dtype)
+    v, do = torch.randn_like(k), torch.randn_like(q)
+    sc = D ** -0.5
+    knobs.set("FA_FWD_NW", "8")
+    torch.manual_seed(77)
+    out8, lse8, rv, rng8 = be.fwd(q, k, v, None, None, p, sc, causal, wl, wr, 0.0, True, None)
+    assert be.last_schedule()["fwd_kernel"] == 1
+    knobs.set("FA_FWD_NW", "64")
+    torch.manual_seed(77)
+    out, lse, _, rng = be.fwd(q, k, v, None, None, p, sc, causal, wl, wr, 0.0, False, None)
+    s = be.last_schedule()
+    assert s["fwd_kernel"] == 3 and "dropout" in s["name"], s
+    assert torch.equal(rng, rng8)
+    torch.manual_seed(77)
+    out_b, lse_b, _, _ = be.fwd(q, k, v, None, None, p, sc, causal, wl, wr, 0.0, False, None)
+    assert torch.equal(out, out_b) and torch.equal(lse, lse_b), "same generator state => the same output"
+    torch.manual_seed(77)
+    be.fwd(q, k, v, None, None, p, sc, causal, wl, wr, 0.0, True, None)      # the random-byte output is not this kernel's: the lock-step kernel takes over
+    assert be.last_schedule()["fwd_kernel"] == 1
+    knobs.unset("FA_FWD_NW")
+    keep = _keep(rv, p).cpu().numpy()
+    o_ref, l_ref = orc.attention_fwd(q, k, v, sc, causal, (wl, wr), 0.0, None, p, keep)
+    o_ref, l_ref = torch.from_numpy(o_ref).float(), torch.from_numpy(l_ref).float()
+    assert torch.isfinite(out.float()).all()
+    e64, e8 = max_abs(out.float().cpu(), o_ref), max_abs(out8.float().cpu(), o_ref)
+    assert e64 < max(2 * e8, (1.2e-2 if dtype == torch.bfloat16 else 4e-3) / (1 - p)), (e64, e8)
+    fin = torch.isfinite(l_ref)
+    assert torch.equal(torch.isposinf(lse.cpu()), ~fin)
+    assert max_abs(lse.cpu()[fin], l_ref[fin]) < (8e-3 if dtype == torch.bfloat16 else 2e-3)
+    if Sq * Sk <= 1100 * 1100:   # (the fp64 backward oracle on the larger shapes takes minutes)
+        dq, dk, dv, _ = be.bwd(do, q, k, v, out, lse, None, None, None, None, p, sc, causal, wl, wr, 0.0, False, None, rng)
+        rq, rk, rvv, _ = orc.attention_bwd(do, q, k, v, out, lse, sc, causal, (wl, wr), 0.0, None, p, keep)
+        for nm, got, ref in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rvv)):
+            gtol = (4e-2 if dtype == torch.bfloat16 else 8e-3) * max(1.0, float(np.abs(ref).max())) / (1 - p)
+            assert max_abs(got.float().cpu(), torch.from_numpy(ref)) < gtol, nm
+
+
+def test_w64_dropout_default_dispatch_and_varlen(knobs):
+    from flash_attn_amd import backend as be
+    import itertools
+    q = torch.randn(2, 4096, 8, 128, device="cuda", dtype=torch.bfloat16)
+    k, v = torch.randn_like(q), torch.randn_like(q)
+    be.fwd(q, k, v, None, None, 0.1, 128 ** -0.5, True, -1, -1, 0.0, False, None)
+    s = be.last_schedule()
+    assert s["fwd_kernel"] == 3 and "dropout" in s["name"], s
+    be.fwd(q, k, v, None, None, 0.1, 128 ** -0.5, True, -1, -1, 25.0, False, None)     # dropout AND softcap: the lock-step kernel
+    assert be.last_schedule()["fwd_kernel"] == 1
+    # packed batch: each sequence's rows and keys count from 0 in the random stream, as in the lock-step kernel (same mask => outputs equal to rounding)
+    lens = [700, 33, 1500, 256, 1, 900]
+    cu = torch.tensor([0] + list(itertools.accumulate(lens)), dtype=torch.int32, device="cuda")
+    qq = torch.randn(sum(lens), 4, 128, device="cuda", dtype=torch.bfloat16)
+    kk = torch.randn(sum(lens), 2, 128, device="cuda", dtype=torch.bfloat16)
+    vv = torch.randn_like(kk)
+    args = (qq, kk, vv, None, cu, cu, None, None, None, None, max(lens), max(lens), 0.3, 128 ** -0.5, False, True, -1, -1, 0.0, False, None)
+    knobs.set("FA_FWD_NW", "64")
+    torch.manual_seed(9)
+    o64, l64 = be.varlen_fwd(*args)[:2]
+    s = be.last_schedule()
+    assert s["fwd_kernel"] == 3 and "dropout" in s["name"], s
+    knobs.set("FA_FWD_NW", "8")
+    torch.manual_seed(9)
+    o8, l8 = be.varlen_fwd(*args)[:2]
+    knobs.unset("FA_FWD_NW")
+    assert max_abs(o64.float(), o8.float()) < 3e-2 and max_abs(l64, l8) < 8e-3
