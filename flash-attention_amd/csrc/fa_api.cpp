@@ -370,9 +370,12 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
 // dQ schedule (fa_launch.h Knobs::bwd_dq_nw).  Measured on MI355X (profiles/r02_bwd_schedules.txt): the 64-rows-per-wave
 // kernel wins from ~2k keys at head dim 128 (config 3: dQ 955 vs 997 us, S = 16k non-causal 1383 vs 1584 us) and loses on
 // short sequences, where its 256-row blocks leave CUs idle.
-// What the 64-per-wave backward kernels cover besides plain attention: ALiBi under a causal right bound (the bias is linear in the key there)
-bool bwd_w64_features_ok(const FaBwdParams* a) {
-  if (a->softcap > 0.f || a->p_dropout > 0.f) return false;
+// What the 64-per-wave backward kernels cover besides plain attention: ALiBi under a causal right bound (the bias is linear in the key there) in both of them;
+// softcap and dropout -- one feature at a time -- in the dQ kernel (round 5; the dK/dV kernel's softmax phase has no room for them: DESIGN.md section 8)
+bool bwd_w64_features_ok(const FaBwdParams* a, bool dq_kernel) {
+  const int n = (a->softcap > 0.f) + (a->p_dropout > 0.f) + (a->alibi_slopes != nullptr);
+  if (n > 1) return false;
+  if (a->softcap > 0.f || a->p_dropout > 0.f) return dq_kernel && a->d == 128;   // (head dim 64: the 4-wave feature kernel measured 2-4 % ahead)
   return !a->alibi_slopes || a->is_causal || a->window_right == 0;
 }
 
@@ -382,7 +385,7 @@ int bwd_dq_schedule(const FaBwdParams* a) {
   if (head_dim_trimmed(head_dim_kernel(a->d)) || !head_dim_native(a->d) || a->d > 128) return 4;
   const int knob = fa::knobs().bwd_dq_nw;
   if (knob == 4 || knob == 8 || knob == 64) return knob;
-  const bool plain = bwd_w64_features_ok(a);
+  const bool plain = bwd_w64_features_ok(a, true);
   if (a->d == 64) {
     // round 4 (profiles/r04_bwd_schedules.txt): at head dim 64 the 64-rows-per-wave kernel wins from ~2k visible keys per query row ON AVERAGE -- non-causal
     // S >= 2048 (+5.5 .. +7.5 % on the whole backward), causal S >= 8192 (+5.6 .. +7.4 %); it ties at causal S = 4096 and loses below
@@ -401,7 +404,7 @@ int bwd_dq_schedule(const FaBwdParams* a) {
 // wins from 2k query rows per key block (+1 % at S = 2048, +3 .. +6 % on the whole backward from S = 4096, GQA included) and loses below (its pipeline fill /
 // drain and 160 KB of LDS per workgroup cost more than they save on a short walk); at head dim 64 it ties or loses everywhere.
 int bwd_dkdv_schedule(const FaBwdParams* a) {
-  const bool plain = bwd_w64_features_ok(a);
+  const bool plain = bwd_w64_features_ok(a, false);
   if (!plain || !head_dim_native(a->d) || head_dim_trimmed(head_dim_kernel(a->d)) || (a->d != 128 && a->d != 64)) return 8;
   const int knob = fa::knobs().bwd_dkdv;
   if (knob == 8 || knob == 64) return knob;

@@ -74,8 +74,17 @@ template <typename E, int T> FA_DEVINL void mfma_q_acc(u32x4 a, u32x4 b) {
 // Element r of a step scores key k0 + 4*hi + acc_row(r, 0): slope*log2e * acc_row(r, 0) rides in the score chains' C operand next to -LSE*log2e (per block),
 // slope*log2e * (k0 + 4*hi - row - shift) -- one value per lane, query block and step, from an integer difference -- is added to every score of the step
 // in front of its exp2: one more vector instruction per element (32 per 48 MFMAs).
-template <typename E, int D, bool FUSE_DELTA, bool ALIBI>
+//
+// FEAT_CAP (softcap, round 5; reference flash_bwd_kernel.h:588 + utils.h:395-409): Q carries scale/softcap * 2*log2e, the score chains start from C = 0 and deliver
+// y = 2*log2e * z (z = score*scale/softcap); with r = 1/(2^y + 1) and c = softcap*log2e: P = 2^(c - LSE*log2e - 2c*r), 1 - tanh^2(z) = 4 * (r - r^2).  Ten vector
+// instructions per element instead of three, in three stages a gap apart (none waits for its predecessor); the factor 4 meets softmax_scale in the epilogue.
+// FEAT_DROP (dropout; reference flash_bwd_kernel.h + dropout.h): the random stream of fa_device.h drop_bytes -- four consecutive keys of a row share a Philox2x32-7
+// call and are four accumulator rows of one lane: eight calls per step and lane, their rounds spread over the gaps ahead of their elements (scalar round keys);
+// dS = P * (keep ? dP / (1-p) : 0 - delta).
+template <typename E, int D, bool FUSE_DELTA, int FEAT>
 __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
+  constexpr bool ALIBI = FEAT == FEAT_ALIBI, CAP = FEAT == FEAT_CAP, DROP = FEAT == FEAT_DROP;
+  static_assert(FEAT == 0 || ALIBI || CAP || DROP, "feature variants of this schedule: none, causal ALiBi, softcap, dropout");
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   constexpr int NW = 4, QB = 2, BM = NW * 64, BN = 64, CPR = D / 8;
@@ -141,7 +150,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   const int w_kmin = (p.wl >= 0) ? max(0, w_row0 + shift - p.wl) : 0;
   const int w_full_hi = (p.wr >= 0) ? min(sk - 1, w_row0 + shift + p.wr) : sk - 1;
   const int w_full_lo = (p.wl >= 0) ? (w_row1 + shift - p.wl) : 0;
-  const float cs = p.scale_log2;
+  const float cs = CAP ? p.scale * 2.885390081777927f / p.softcap : p.scale_log2;   // (softcap: the chains deliver 2*log2e * score*scale/softcap)
   float slope2 = 0.f;   // ALiBi slope of this head in log2 units
   if constexpr (ALIBI) slope2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.alibi[(int64_t)b * p.alibi_bs + h] * kLog2eW)));   // (uniform; said so: one scalar register)
   int lim_hi[QB], lim_lo[QB];
@@ -343,6 +352,27 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
       nlse[qb][r] = ALIBI ? __builtin_fmaf(slope2, (float)acc_row(r, 0), -lse_l[qb]) : -lse_l[qb];
     }
   }
+  // (CAP) c = softcap*log2e, -2c, and per row c - LSE*log2e (-inf for a row past the end: P = 0)
+  float cap_m2c = 0.f, cap_off[QB] = {0.f, 0.f};
+  if constexpr (CAP) {
+    const float capc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.softcap * kLog2eW)));
+    cap_m2c = -2.f * capc;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) cap_off[qb] = capc - lse_l[qb];
+  }
+  constexpr float kCapTiny = 7.888609052210118e-31f;   // 2^-100: y * tiny vanishes for a finite y and keeps a masked score's -inf
+  // (DROP) the seven round keys of this (batch, head), the keep threshold, 1 / (1 - p), each lane's row
+  unsigned drop_kr[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u}, drop_thr = 255u, drop_row[QB] = {0u, 0u};
+  float drop_rp = 1.f;
+  if constexpr (DROP) {
+    const unsigned k0_ = (unsigned)__builtin_amdgcn_readfirstlane((int)drop_bh_key(p.rng, b * p.h + h));
+#pragma unroll
+    for (int r = 0; r < 7; ++r) drop_kr[r] = k0_ + (unsigned)r * 0x9E3779B9u;
+    drop_thr = (unsigned)__builtin_amdgcn_readfirstlane((int)p.drop_thr8);
+    drop_rp = p.rp_keep;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) drop_row[qb] = (unsigned)(w_row0 + 32 * qb + qi);
+  }
   bool have_cur = false, have_prev = false;
 
   lds_dma_wait_all();
@@ -355,9 +385,21 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
   };
   // dS_i of one element
   auto ds_elem = [&](float sv, float dpv, int qb, float sb) __attribute__((always_inline)) {
+    if constexpr (CAP) {   // (one element in one go: the head / tail steps; the steady-state step stages this over three gaps)
+      const float rr = __builtin_amdgcn_rcpf(fast_exp2(sv) + 1.f);
+      const float pv = fast_exp2(__builtin_fmaf(rr, cap_m2c, __builtin_fmaf(sv, kCapTiny, cap_off[qb])));
+      return pv * (dpv - delta_l[qb]) * __builtin_fmaf(-rr, rr, rr);
+    }
     if constexpr (ALIBI) sv += sb;
+    // (DROP: the chains start from C = 0 and LSE is subtracted here -- one more instruction per element in a variant that has ten, for the 32 registers of the
+    // broadcast: with them the D = 128 instantiation spilled five)
+    if constexpr (DROP) sv -= lse_l[qb];
     const float pv = fast_exp2(sv);   // sv = s*scale*log2e - LSE*log2e (the subtraction rode in the chain's C operand)
     return pv * (dpv - delta_l[qb]);
+  };
+  // (DROP) dP of a kept pair is scaled by 1 / (1 - p), a dropped pair contributes -delta alone; w = the Philox word of the element's group, byte r & 3 its random byte
+  auto drop_dp = [&](float dpv, unsigned w, int r) __attribute__((always_inline)) {
+    return (((w >> (8 * (r & 3))) & 0xffu) > drop_thr) ? 0.f : dpv * drop_rp;
   };
   // (ALIBI) the step's per-lane part of the bias, slope*log2e * (first key of the step + 4*hi - row - shift), from the same integer the masked steps compare
   // against: rel_hi = (row + shift) - k0 - 4*hi is the lane's right bound under the causal mask this variant requires (a row past the end, where the bound is
@@ -390,8 +432,13 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
         const u32x4 kf = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[ks] + HOFF);
         const u32x4 vf = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[ks] + HOFF + V_RING);
         if constexpr (ks == 0) {
-          mfma_v_first<E, BW_Q_BASE>(s_nxt[0], kf, nlse[0]);
-          mfma_v_first<E, BW_Q_BASE + 4 * KS>(s_nxt[1], kf, nlse[1]);
+          if constexpr (CAP || DROP) {
+            mfma_v_first0<E, BW_Q_BASE>(s_nxt[0], kf);
+            mfma_v_first0<E, BW_Q_BASE + 4 * KS>(s_nxt[1], kf);
+          } else {
+            mfma_v_first<E, BW_Q_BASE>(s_nxt[0], kf, nlse[0]);
+            mfma_v_first<E, BW_Q_BASE + 4 * KS>(s_nxt[1], kf, nlse[1]);
+          }
           mfma_v_first0<E, BW_DO_BASE>(dp_nxt[0], vf);
           mfma_v_first0<E, BW_DO_BASE + 4 * KS>(dp_nxt[1], vf);
         } else {
@@ -417,7 +464,9 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
           const int off = acc_row(r, 0);
           float sv = s_cur[qb][r];
           if (mask) sv = ((off <= rel_hi) && (off >= rel_lo)) ? sv : -INFINITY;
-          dsv[r] = ds_elem(sv, dp_cur[qb][r], qb, sbq);
+          float dpv = dp_cur[qb][r];
+          if constexpr (DROP) dpv = drop_dp(dpv, drop_bytes(drop_kr[0], (int)drop_row[qb], (k0 + 8 * (r >> 2) + 4 * hi) >> 2), r);
+          dsv[r] = ds_elem(sv, dpv, qb, sbq);
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) f_cur[qb][c >> 2][c & 3] = pack2(dsv[2 * c], dsv[2 * c + 1]);
@@ -465,8 +514,19 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
         fr[f % RNG] = rd_tr(ta0[db] + HOFF + 16 * t * ROW_BYTES, ta1[db] + HOFF + 16 * t * ROW_BYTES);
       }
     };
-    // elements of dS_i done before gap x (e = 16*qb + r), all 32 before the last gap; pairs are packed one gap later
-    auto el_end = [](int x) constexpr { return x <= 0 ? 0 : ((32 * x + NG - 2) / (NG - 1) > 32 ? 32 : (32 * x + NG - 2) / (NG - 1)); };
+    // elements of dS_i whose (first) stage was issued before gap x (e = 16*qb + r); the last stage of all 32 before the last gap, pairs are packed one gap later.
+    // CAP: three stages a gap apart (LAT = 2 more gaps); DROP: the first elements wait E0 gaps for their group's Philox word
+    constexpr int E0 = DROP ? (D == 128 ? 4 : 2) : 0, LAT = CAP ? 2 : 0, ESPAN = NG - 1 - LAT - E0;
+    auto el_end = [](int x) constexpr { return x <= E0 ? 0 : ((32 * (x - E0) + ESPAN - 1) / ESPAN > 32 ? 32 : (32 * (x - E0) + ESPAN - 1) / ESPAN); };
+    // (DROP) round r of the Philox call of group G = 4*qb + g (elements 16*qb + 4*g .. + 3) sits in gap drop_gap(G, r): done no later than the gap of its first element
+    auto drop_gap = [](int G, int r) constexpr { return ((7 * G + r) * (NG - 2 * E0)) / 56; };
+    constexpr bool drop_in_time = [&]() constexpr {
+      for (int G = 0; G < 8; ++G) { int x = 0; while (el_end(x + 1) <= 4 * G) ++x; if (drop_gap(G, 6) > x) return false; }
+      return true;
+    }();
+    static_assert(!DROP || drop_in_time, "a Philox word is finished before its first element is processed");
+    unsigned ph_c0[8], ph_c1[8];
+    float cap_a1[32], cap_d[32], cap_arg[32], cap_w[32];   // (CAP) values in flight between the stages
     float dsv[QB][16];
     float sbv = 0.f;   // (ALIBI) the bias of the query block whose elements are being processed: made when its first element comes up
     int rel_hi[QB] = {0, 0}, rel_lo[QB] = {0, 0};
@@ -491,7 +551,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
         __builtin_amdgcn_s_waitcnt(0xC07F | (out << 8));
       }
       if constexpr (x < QKG) {
-        if constexpr (f == 0) mfma_v_first<E, BW_Q_BASE + 4 * (qb * KS)>(s_nxt[qb], fr[f % RNG], nlse[qb]);
+        if constexpr (f == 0 && (CAP || DROP)) mfma_v_first0<E, BW_Q_BASE + 4 * (qb * KS)>(s_nxt[qb], fr[f % RNG]);
+        else if constexpr (f == 0) mfma_v_first<E, BW_Q_BASE + 4 * (qb * KS)>(s_nxt[qb], fr[f % RNG], nlse[qb]);
         else mfma_v_acc<E, BW_Q_BASE + 4 * (qb * KS + f)>(s_nxt[qb], fr[f % RNG]);
       } else if constexpr (x < 2 * QKG) {
         constexpr int ks = f - KS;
@@ -509,6 +570,33 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
         else
           asm volatile("buffer_load_dwordx4 %0, %1, %3 offen offset:%c2 lds" : : "v"(dma_off[pc]), "s"(dma_srd), "i"(1024 * pc), "s"(dma_toff) : "memory");
       }
+      if constexpr (DROP) {
+#pragma unroll
+        for (int G = 0; G < 8; ++G)
+#pragma unroll
+          for (int r = 0; r < 7; ++r)
+            if (drop_gap(G, r) == x) {
+              if (r == 0) { ph_c0[G] = (unsigned)((k0c >> 2) + 2 * (G & 3)) + (unsigned)hi; ph_c1[G] = drop_row[G >> 2]; }
+              const unsigned mh = __umulhi(0xD256D193u, ph_c0[G]), ml = 0xD256D193u * ph_c0[G];
+              unsigned x3;   // mh ^ round key ^ c1 in one instruction (the key is a scalar operand)
+              asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(x3) : "v"(mh), "s"(drop_kr[r]), "v"(ph_c1[G]));
+              ph_c0[G] = x3;
+              ph_c1[G] = ml;
+            }
+      }
+      if constexpr (CAP) {   // oldest elements first: C = the probability and dS, B = 1/(2^y + 1), the exponent and 1 - tanh^2, A = the mask carrier, 2^y + 1
+#pragma unroll
+        for (int e = el_end(x - 2); e < el_end(x - 1); ++e) {
+          const int eq = e >> 4, r = e & 15;
+          dsv[eq][r] = fast_exp2(cap_arg[e]) * (dp_cur[eq][r] - delta_l[eq]) * cap_w[e];
+        }
+#pragma unroll
+        for (int e = el_end(x - 1); e < el_end(x); ++e) {
+          const float rr = __builtin_amdgcn_rcpf(cap_d[e]);
+          cap_arg[e] = __builtin_fmaf(rr, cap_m2c, cap_a1[e]);
+          cap_w[e] = __builtin_fmaf(-rr, rr, rr);
+        }
+      }
 #pragma unroll
       for (int e = el_end(x); e < el_end(x + 1); ++e) {
         const int eq = e >> 4, r = e & 15;
@@ -518,10 +606,17 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
           const int off = acc_row(r, 0);
           sv = ((off <= rel_hi[eq]) && (off >= rel_lo[eq])) ? sv : -INFINITY;
         }
-        dsv[eq][r] = ds_elem(sv, dp_cur[eq][r], eq, sbv);
+        if constexpr (CAP) {
+          cap_a1[e] = __builtin_fmaf(sv, kCapTiny, cap_off[eq]);
+          cap_d[e] = fast_exp2(sv) + 1.f;
+        } else {
+          float dpv = dp_cur[eq][r];
+          if constexpr (DROP) dpv = drop_dp(dpv, ph_c0[4 * eq + (r >> 2)], r);
+          dsv[eq][r] = ds_elem(sv, dpv, eq, sbv);
+        }
       }
 #pragma unroll
-      for (int c = el_end(x - 1) / 2; c < el_end(x) / 2; ++c) {
+      for (int c = el_end(x - 1 - LAT) / 2; c < el_end(x - LAT) / 2; ++c) {
         const int cq = c >> 3, r = 2 * (c & 7);
         unsigned pw = pack2(dsv[cq][r], dsv[cq][r + 1]);
         asm volatile("" : "+v"(pw));   // pinned to this gap
@@ -621,16 +716,16 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dq_w64_kernel(const BwdK p) {
     // (the lane index made again from the hardware counter: as `lane` it is one more register alive across the tile loop -- the ALiBi variant at D = 128 spilled it)
     const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (row0 < sq)
-      store_tile_via_lds<E, D>(lds + (wave * 64 + qb * 32) * (ROW_BYTES + 16), o_v, p.scale, dqtile + (int64_t)(32 * qb) * p.dq_rs, p.dq_rs,
+      store_tile_via_lds<E, D>(lds + (wave * 64 + qb * 32) * (ROW_BYTES + 16), o_v, CAP ? 4.f * p.scale : p.scale, dqtile + (int64_t)(32 * qb) * p.dq_rs, p.dq_rs,
                                sq - row0, lane_e);
   });
 }
 
-template <typename E, int D, bool FUSE_DELTA, bool ALIBI>
+template <typename E, int D, bool FUSE_DELTA, int FEAT>
 static int launch_bwd_dq_w64_f(const BwdK& p, hipStream_t stream) {
   constexpr int TILE = 64 * D * 2, RINGS = 2 * 3 * TILE, STAGE_IN = 2 * 256 * D * 2, STAGE_OUT = 256 * (D * 2 + 16);
   constexpr int smem = (RINGS > STAGE_IN ? (RINGS > STAGE_OUT ? RINGS : STAGE_OUT) : (STAGE_IN > STAGE_OUT ? STAGE_IN : STAGE_OUT));
-  auto kern = fa_bwd_dq_w64_kernel<E, D, FUSE_DELTA, ALIBI>;
+  auto kern = fa_bwd_dq_w64_kernel<E, D, FUSE_DELTA, FEAT>;
   static std::atomic<unsigned long long> attr_mask{0};
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
   const long long total = p.q_list ? (long long)p.q_bound * p.h : units_grid(p.q_units, p.q_unit_size);
@@ -641,14 +736,22 @@ static int launch_bwd_dq_w64_f(const BwdK& p, hipStream_t stream) {
 
 template <typename E, int D>
 static int launch_bwd_dq_w64_t(const BwdK& p, hipStream_t stream) {
-  if (p.alibi) return p.fuse_delta ? launch_bwd_dq_w64_f<E, D, true, true>(p, stream) : launch_bwd_dq_w64_f<E, D, false, true>(p, stream);
-  return p.fuse_delta ? launch_bwd_dq_w64_f<E, D, true, false>(p, stream) : launch_bwd_dq_w64_f<E, D, false, false>(p, stream);
+  // (softcap / dropout: built for the fused-delta order only -- the order the dispatch uses; FA_BWD_FUSE_DELTA=0 falls back to fa_bwd.hip's feature kernels -- and for
+  // head dim 128 only: at head dim 64, twice the vector work per MFMA, they measured 2-4 % behind the 4-wave feature kernel, profiles/r05_bwd_features_w64.txt)
+  if constexpr (D == 128) {
+    if (p.softcap > 0.f) return p.fuse_delta ? launch_bwd_dq_w64_f<E, D, true, FEAT_CAP>(p, stream) : -2;
+    if (p.rng) return p.fuse_delta ? launch_bwd_dq_w64_f<E, D, true, FEAT_DROP>(p, stream) : -2;
+  } else if (p.softcap > 0.f || p.rng) {
+    return -2;
+  }
+  if (p.alibi) return p.fuse_delta ? launch_bwd_dq_w64_f<E, D, true, FEAT_ALIBI>(p, stream) : launch_bwd_dq_w64_f<E, D, false, FEAT_ALIBI>(p, stream);
+  return p.fuse_delta ? launch_bwd_dq_w64_f<E, D, true, 0>(p, stream) : launch_bwd_dq_w64_f<E, D, false, 0>(p, stream);
 }
 
-// 4 waves x 64 query rows per workgroup (the caller sized nmb / the work list for 256-row blocks).  Plain attention, or ALiBi under a causal right bound;
-// -2 = not covered, the caller falls back to fa_bwd_dq_kernel<.., 8, ..> on the same blocks.
+// 4 waves x 64 query rows per workgroup (the caller sized nmb / the work list for 256-row blocks).  Plain attention, softcap, dropout, or ALiBi under a causal
+// right bound -- one feature at a time; -2 = not covered, the caller falls back to fa_bwd_dq_kernel<.., 8, ..> on the same blocks.
 int launch_bwd_dq_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
-  if (p.softcap > 0.f || p.rng != nullptr) return -2;
+  if ((p.softcap > 0.f) + (p.rng != nullptr) + (p.alibi != nullptr) > 1) return -2;
   if (p.alibi != nullptr && p.wr != 0) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal
   const uint64_t span = ((uint64_t)(p.sk > 0 ? p.sk : 1) + 128) * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u;
   if (span >= (1ull << 32)) return -2;   // buffer addressing: 32-bit byte offsets from the (batch, kv-head) base

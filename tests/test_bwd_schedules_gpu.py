@@ -92,21 +92,23 @@ def test_dq_w64_kernel_matches_recomputing_kernel_and_fp32(be, knobs, dtype, sha
 
 
 def test_dq_w64_default_dispatch_and_fallbacks(be, knobs):
-    """Heuristic (fa_api.cpp bwd_dq_schedule): 64 rows per wave from 2k keys at head dim 128 for plain attention; everything
-    else on the 32-rows-per-wave kernels.  A forced 64 falls back to the 8-wave kernel (same 256-row blocks) where the
-    schedule does not apply (dropout) -- and still computes the right thing."""
+    """Heuristic (fa_api.cpp bwd_dq_schedule): 64 rows per wave from 2k keys at head dim 128 for plain attention and (round 5) for ONE of softcap / dropout /
+    causal ALiBi; everything else on the 32-rows-per-wave kernels.  A forced 64 falls back to the 8-wave kernel (same 256-row blocks) where the schedule
+    does not apply (a product of features) -- and still computes the right thing."""
     knobs.unset("FA_BWD_DQ_NW")
     torch.manual_seed(1)
     q = torch.randn(1, 2048, 2, 128, device="cuda", dtype=torch.bfloat16)
     k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
     assert run_bwd(be, q, k, v, do, True)[3]["bwd_dq_nw"] == 64
     assert run_bwd(be, q[:, :1024], k[:, :1024], v[:, :1024], do[:, :1024], True)[3]["bwd_dq_nw"] == 4
-    assert run_bwd(be, q, k, v, do, True, p_drop=0.1)[3]["bwd_dq_nw"] == 4
+    assert run_bwd(be, q, k, v, do, True, p_drop=0.1)[3]["bwd_dq_nw"] == 64
+    assert run_bwd(be, q, k, v, do, True, softcap=20.0)[3]["bwd_dq_nw"] == 64
+    assert run_bwd(be, q, k, v, do, True, p_drop=0.1, softcap=20.0)[3]["bwd_dq_nw"] == 4
     knobs.set("FA_BWD_DQ_NW", 64)
-    d_forced = run_bwd(be, q, k, v, do, True, p_drop=0.1)
+    d_forced = run_bwd(be, q, k, v, do, True, p_drop=0.1, softcap=20.0)
     assert d_forced[3]["bwd_dq_nw"] == 8
     knobs.set("FA_BWD_DQ_NW", 4)
-    d_ref = run_bwd(be, q, k, v, do, True, p_drop=0.1)
+    d_ref = run_bwd(be, q, k, v, do, True, p_drop=0.1, softcap=20.0)
     assert float((d_forced[0].float() - d_ref[0].float()).abs().max()) < 1e-2
     q96 = torch.randn(1, 2048, 2, 96, device="cuda", dtype=torch.bfloat16)   # (head dim 64 has the kernel since round 4; trimmed head dims do not)
     knobs.set("FA_BWD_DQ_NW", 64)

@@ -120,7 +120,10 @@ def test_backward_dq_schedule(lib, monkeypatch):
     assert dq(bp(8, 2048, 32, 64, is_causal=1)) == 4
     assert dq(bp(2, 8192, 32, 64, is_causal=1)) == 64
     assert dq(bp(16, 1024, 32, 64)) == 4
-    assert dq(bp(4, 4096, 32, 128, softcap=20.0)) == 4
+    assert dq(bp(4, 4096, 32, 128, softcap=20.0)) == 64                   # round 5: softcap / dropout variants of the 64-rows-per-wave dQ kernel at head dim 128
+    assert dq(bp(4, 4096, 32, 128, p_dropout=0.1)) == 64
+    assert dq(bp(4, 4096, 32, 64, softcap=20.0)) == 4                     # ... not at head dim 64 (the 4-wave feature kernel measured ahead), not for products of features
+    assert dq(bp(4, 4096, 32, 128, softcap=20.0, p_dropout=0.1)) == 4
     assert dq(bp(4, 4096, 32, 128, alibi_slopes=1, is_causal=1)) == 64    # round 5: ALiBi under a causal bound runs on the 64-rows-per-wave kernel too
     assert dq(bp(4, 4096, 32, 128, alibi_slopes=1)) == 4                  # ... not without it (|key - row| is not linear in the key)
     monkeypatch.setenv("FA_BWD_DQ_NW", "64"); lib.fa_knobs_reload()
