@@ -371,11 +371,12 @@ int do_fwd(const FaFwdParams* a, void* stream, bool varlen, bool kvcache = false
 // kernel wins from ~2k keys at head dim 128 (config 3: dQ 955 vs 997 us, S = 16k non-causal 1383 vs 1584 us) and loses on
 // short sequences, where its 256-row blocks leave CUs idle.
 // What the 64-per-wave backward kernels cover besides plain attention: ALiBi under a causal right bound (the bias is linear in the key there) in both of them;
-// softcap and dropout -- one feature at a time -- in the dQ kernel (round 5; the dK/dV kernel's softmax phase has no room for them: DESIGN.md section 8)
+// softcap in both at head dim 128, dropout in the dQ kernel at head dim 128 -- one feature at a time (round 5; profiles/r05_bwd_features_w64.txt)
 bool bwd_w64_features_ok(const FaBwdParams* a, bool dq_kernel) {
   const int n = (a->softcap > 0.f) + (a->p_dropout > 0.f) + (a->alibi_slopes != nullptr);
   if (n > 1) return false;
-  if (a->softcap > 0.f || a->p_dropout > 0.f) return dq_kernel && a->d == 128;   // (head dim 64: the 4-wave feature kernel measured 2-4 % ahead)
+  if (a->softcap > 0.f) return a->d == 128;                   // (head dim 64: the 4-wave feature kernel measured 2-4 % ahead)
+  if (a->p_dropout > 0.f) return dq_kernel && a->d == 128;
   return !a->alibi_slopes || a->is_causal || a->window_right == 0;
 }
 

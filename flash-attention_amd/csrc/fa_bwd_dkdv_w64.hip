@@ -67,8 +67,15 @@ template <typename E, int T> FA_DEVINL void kv_mfma_tile(u32x4 a, u32x4 b) {
 // With q0 = the tile's first row: the row's part, -slope * (row - q0), rides with -LSE in the score chains' C operand (stream_aux), the key's part,
 // slope*log2e * (key - q0 - shift) -- one value per lane, key block and tile, from an integer difference --, is the addend of the fused multiply-add that
 // applies scale*log2e (a plain multiply without ALiBi): no instruction per element.  The slopes of the group's query heads wait in a small LDS table.
-template <typename E, int D, bool ALIBI>
+//
+// FEAT_CAP (softcap, round 5; reference flash_bwd_kernel.h:588 + utils.h:395-409): the cap is not linear, so LSE cannot ride in the score chains' C operand: the chains
+// start from C = 0, the tile stream stores c - LSE*log2e (c = softcap*log2e) per row instead of -LSE/scale, and phase B reads those rows four at a time one group of
+// elements ahead.  With y = score * scale/softcap * 2*log2e and r = 1/(2^y + 1): P = 2^(c - LSE*log2e - 2c*r), 1 - tanh^2 = 4*(r - r^2) -- twelve vector instructions
+// per element instead of five, in three stages a gap apart; the 4 meets softmax_scale in dK's epilogue.
+template <typename E, int D, int FEAT>
 __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
+  constexpr bool ALIBI = FEAT == FEAT_ALIBI, CAP = FEAT == FEAT_CAP;
+  static_assert(FEAT == 0 || ALIBI || CAP, "feature variants of this schedule: none, causal ALiBi, softcap");
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   constexpr int NW = 4, KB = 2, BNK = NW * 64, TQ = 32;
@@ -208,6 +215,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   float aux_reg = 0.f;
   const unsigned wave_dst = (unsigned)(wave * PW * 1024);
   const float rscale = 1.f / p.scale;
+  const float cap_c = CAP ? p.softcap * 1.4426950408889634f : 0.f, cap_m2c = -2.f * cap_c;   // (CAP) c = softcap*log2e: the capped scores live in [-c, c] log2 units
   // Request of tile t2 into ring slot `slot` in three parts: the scalars (before phase A), the two DMA statements (in phase A's gaps 1 and 3; a tile past the
   // last one is zero-filled through an empty descriptor), and -- after phase A -- wave 0's load of the tile's LSE / delta rows + the stream's advance.
   struct Strm { u32x4 srd_q, srd_d; unsigned toff_q, toff_d, dst_q, dst_d; int m0; bool real; };
@@ -247,7 +255,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     float x = aux_h[max(min(r, sq - 1), 0)];
     const bool ok = r < lim;
     if constexpr (ALIBI) x = hi ? x : __builtin_fmaf(s_slope, kif, x);   // LSE + slope * (row - q0)
-    aux_reg = hi ? (ok ? -x : 0.f) : (ok ? -x * rscale : -INFINITY);
+    if constexpr (CAP) aux_reg = hi ? (ok ? -x : 0.f) : (ok ? __builtin_fmaf(x, -1.4426950408889634f, cap_c) : -INFINITY);   // c - LSE*log2e: the exponent's row part
+    else aux_reg = hi ? (ok ? -x : 0.f) : (ok ? -x * rscale : -INFINITY);
   };
   auto stream_advance = [&]() __attribute__((always_inline)) {
     ++t2;
@@ -286,7 +295,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     asm volatile("" : "+v"(zf));
     acc_zero_tuples_mfma<0>(zf, std::make_integer_sequence<int, 4 * DB>{});
   }
-  const float cs = p.scale_log2;
+  // (softcap: y = score * scale/softcap * 2*log2e; the quotient comes out of the vector ALU: back into a scalar register, said uniform)
+  const float cs = CAP ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.scale * 2.885390081777927f / p.softcap))) : p.scale_log2;
 
   // ---- prologue: tiles 0 and 1 --------------------------------------------------------------------------------------------
   if (n_steps > 0) stream_head();
@@ -339,10 +349,14 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
       const int auxp = opaque(aux_lane) + slot * AUX_SLOT;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + 32 * g);
         const f32x4 d4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + 32 * g + TQ * 4);
+        if constexpr (!CAP) {
+          const f32x4 l4 = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(auxp + 32 * g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s[0][4 * g + j] = l4[j]; dp[0][4 * g + j] = d4[j]; }
+          for (int j = 0; j < 4; ++j) s[0][4 * g + j] = l4[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dp[0][4 * g + j] = d4[j];
       }
     }
     const int qa = opaque(k0) + slot * SLOT, kva = opaque(kv0);
@@ -364,10 +378,12 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
       // k-step 0: key block 1's chain goes FIRST and takes key block 0's preloaded tuple as its C operand (one copy of -LSE/scale and -delta is loaded per step,
       // not two); block 0's chain then accumulates onto it in place.  The matrix pipe is in order: the second MFMA's write follows the first one's read.
       if constexpr (kind == 0) {
-        if constexpr (ks == 0) kv_mfma_from<E>(s[1], ring[0], kf1[0], s[0]);
+        if constexpr (ks == 0 && CAP) kv_mfma_c0<E>(s[1], ring[0], kf1[0]);
+        else if constexpr (ks == 0) kv_mfma_from<E>(s[1], ring[0], kf1[0], s[0]);
         else kv_mfma_acc<E>(s[0], ring[(4 * ks) % NR], kf0[ks]);
       } else if constexpr (kind == 1) {
-        if constexpr (ks == 0) kv_mfma_acc<E>(s[0], ring[0], kf0[0]);
+        if constexpr (ks == 0 && CAP) kv_mfma_c0<E>(s[0], ring[0], kf0[0]);
+        else if constexpr (ks == 0) kv_mfma_acc<E>(s[0], ring[0], kf0[0]);
         else if constexpr (ks < KS - KL) kv_mfma_acc<E>(s[1], ring[(4 * ks) % NR], kf1[ks]);
         else kv_mfma_acc<E>(s[1], ring[(4 * ks) % NR], kx[ks & 1]);
       } else if constexpr (kind == 2) {
@@ -420,8 +436,9 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   // stage 1 (multiply by scale*log2e, mask, exp2) in gap e and stage 2 (dS = P * (dP - delta), packing of a finished pair) one gap later -- a v_exp's
   // consumer in the same gap costs a wait state.  DO_B / DO_SM switch the halves off (pipeline fill / drain, a wave outside its visible range).
   auto phase_b = [&](auto dobc, auto dosmc, auto maskc, int slot_b, int q0, const u32x4 (&pr)[KB][2], const u32x4 (&dr)[KB][2],
-                     u32x4 (&pw)[KB][2], u32x4 (&dw)[KB][2]) __attribute__((always_inline)) {
+                     u32x4 (&pw)[KB][2], u32x4 (&dw)[KB][2], int slot_sm = 0) __attribute__((always_inline)) {
     constexpr bool DO_B = decltype(dobc)::value != 0, DO_SM = decltype(dosmc)::value != 0, MASK = decltype(maskc)::value != 0;
+    static_assert(!CAP || (D == 128 && DO_B), "the softcap variant: head dim 128 (one element per gap), inside the fused phase");
     constexpr int NG = 2 * NFB;   // MFMA gaps (8 * DB)
     constexpr int EPG = 32 / NG;  // elements per gap: 1 at D = 128, 2 at D = 64
     // MASK: bit o of vis[kb] = the lane's key of block kb is visible to tile row 4*hi + o (the rows of the accumulator elements are acc_row(r, 0) above 4*hi);
@@ -451,6 +468,42 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
       lb[1] = slope_v * (f0 + 32.f);
     }
     float pv[32], dv[32];   // P and dS of the tile's elements (each lives for a gap or two)
+    // (CAP) three stages: A = scale, mask, the mask carrier + the row's c - LSE*log2e, 2^y + 1; B = r = 1/(2^y + 1), the exponent, r - r^2; C = P, dS, packing.
+    // The rows' values come four at a time (elements 4g .. 4g+3 of either key block = rows 8g + 4*hi .. + 3), requested one group ahead.
+    float cap_a1[32], cap_d[32], cap_arg[32], cap_w[32];
+    f32x4 nl4[2];
+    const int nl_addr = opaque(aux_lane) + slot_sm * AUX_SLOT;
+    auto nl_read = [&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      nl4[g & 1] = *(const f32x4 FA_LDS*)(unsigned long)(unsigned)(nl_addr + 32 * (g & 3));
+    };
+    auto capA = [&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value, kb = e >> 4, r = e & 15;
+      float xv = s[kb][r] * c_l;
+      if constexpr (MASK) {
+        unsigned t;
+        asm volatile("v_bfe_i32 %1, %2, %c3, 1\n\tv_bfi_b32 %0, %1, %0, %4" : "+v"(xv), "=&v"(t) : "v"(vis[kb]), "i"(acc_row(r, 0)), "v"(ninf));
+      }
+      cap_a1[e] = __builtin_fmaf(xv, 7.888609052210118e-31f, nl4[(e >> 2) & 1][e & 3]);   // (2^-100: nothing for a finite score, -inf for a masked one)
+      cap_d[e] = fast_exp2(xv) + 1.f;
+    };
+    auto capB = [&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value;
+      const float rr = __builtin_amdgcn_rcpf(cap_d[e]);
+      cap_arg[e] = __builtin_fmaf(rr, cap_m2c, cap_a1[e]);
+      cap_w[e] = __builtin_fmaf(-rr, rr, rr);
+    };
+    auto capC = [&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value, kb = e >> 4, r = e & 15;
+      pv[e] = fast_exp2(cap_arg[e]);
+      dv[e] = pv[e] * dp[kb][r] * cap_w[e];
+      if constexpr ((r & 1) == 1) {
+        unsigned pwv = pack2(pv[e - 1], pv[e]), dwv = pack2(dv[e - 1], dv[e]);
+        asm volatile("" : "+v"(pwv), "+v"(dwv));   // pinned to this gap
+        pw[kb][r >> 3][(r & 7) >> 1] = pwv;
+        dw[kb][r >> 3][(r & 7) >> 1] = dwv;
+      }
+    };
     auto sm1 = [&](auto ec) __attribute__((always_inline)) {
       constexpr int e = decltype(ec)::value, kb = e >> 4, r = e & 15;
       float xv = ALIBI ? __builtin_fmaf(s[kb][r], c_l, lb[kb]) : s[kb][r] * c_l;
@@ -472,6 +525,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     };
     if constexpr (DO_B) {
       const int t0p = opaque(tr_base[0]) + slot_b * SLOT, t1p = opaque(tr_base[1]) + slot_b * SLOT;
+      if constexpr (CAP && DO_SM) nl_read(ICw<0>{});   // (ahead of the transposed reads: older than every read the counted waits below leave in flight)
       static_for<AHT>([&](auto Fc) __attribute__((always_inline)) { rd_t(Fc, t0p, t1p); });
       __builtin_amdgcn_sched_barrier(0);
       static_for<NG>([&](auto xc) __attribute__((always_inline)) {
@@ -485,7 +539,13 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
         }
         if constexpr (src == 0) kv_mfma_tile<E, kb * DB + db>(ring[F % NT], pr[kb][t]);
         else kv_mfma_tile<E, 2 * DB + kb * DB + db>(ring[F % NT], dr[kb][t]);
-        if constexpr (DO_SM) {
+        if constexpr (DO_SM && CAP) {
+          // (the next group's rows: requested behind this gap's counted wait and its MFMA -- at the next counted wait, four gaps on, every read issued since is newer)
+          if constexpr ((x & 3) == 0 && x + 4 < 32) nl_read(ICw<((x + 4) / 4)>{});
+          if constexpr (x >= 2) capC(ICw<(x >= 2 ? x - 2 : 0)>{});
+          if constexpr (x >= 1) capB(ICw<(x >= 1 ? x - 1 : 0)>{});
+          capA(ICw<x>{});
+        } else if constexpr (DO_SM) {
           static_for<EPG>([&](auto ic) __attribute__((always_inline)) {
             constexpr int e = x * EPG + decltype(ic)::value;
             sm1(ICw<e>{});
@@ -494,7 +554,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      if constexpr (DO_SM) static_for<EPG>([&](auto ic) __attribute__((always_inline)) { sm2(ICw<32 - EPG + decltype(ic)::value>{}); });
+      if constexpr (DO_SM && CAP) { capB(ICw<31>{}); capC(ICw<30>{}); capC(ICw<31>{}); }
+      else if constexpr (DO_SM) static_for<EPG>([&](auto ic) __attribute__((always_inline)) { sm2(ICw<32 - EPG + decltype(ic)::value>{}); });
     } else if constexpr (DO_SM) {
       static_for<16>([&](auto hc) __attribute__((always_inline)) {   // pair by pair: few values alive at a time
         constexpr int e = 2 * decltype(hc)::value;
@@ -571,8 +632,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
               pc[kb][t][i] = z0; dc[kb][t][i] = z1;
             }
       }
-      if (__builtin_expect(c.act && c.msk, 0)) phase_b(Y{}, Y{}, Y{}, c.slot_b, c.q0, pc, dc, pn, dn);
-      else phase_b(Y{}, Y{}, N{}, c.slot_b, c.q0, pc, dc, pn, dn);
+      if (__builtin_expect(c.act && c.msk, 0)) phase_b(Y{}, Y{}, Y{}, c.slot_b, c.q0, pc, dc, pn, dn, c.slot_a);
+      else phase_b(Y{}, Y{}, N{}, c.slot_b, c.q0, pc, dc, pn, dn, c.slot_a);
     }
     preload_a((st + 1) & 3, nxt.hq);   // (tile st + 1 was published by the previous barrier.  Unconditional: a conditional definition keeps the 96 registers of
                                // S / dP / the fragment rings alive across phase B in hipcc's eyes; past the last tile it reads a stale slot nobody uses)
@@ -595,19 +656,20 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
       E* dvtile = (E*)p.dv + dv_boff + (k_row0 + kb0) * p.dv_rs + (int64_t)hk * p.dv_hs;
       f32x16 tt[DB];
       static_for<DB>([&](auto dbc) __attribute__((always_inline)) { acc_read_tuple<16 * (2 * DB + kb * DB + decltype(dbc)::value)>(tt[decltype(dbc)::value]); });
-      store_tile_via_lds<E, D>(stage, tt, p.scale, dktile, p.dk_rs, sk - kb0, lane);
+      store_tile_via_lds<E, D>(stage, tt, CAP ? 4.f * p.scale : p.scale, dktile, p.dk_rs, sk - kb0, lane);
       static_for<DB>([&](auto dbc) __attribute__((always_inline)) { acc_read_tuple<16 * (kb * DB + decltype(dbc)::value)>(tt[decltype(dbc)::value]); });
       store_tile_via_lds<E, D>(stage, tt, 1.f, dvtile, p.dv_rs, sk - kb0, lane);
     }
   });
 }
 
-template <typename E, int D, bool ALIBI>
+template <typename E, int D, int FEAT>
 static int launch_dkdv_w64_f(const BwdK& p, hipStream_t stream) {
+  constexpr bool ALIBI = FEAT == FEAT_ALIBI;
   constexpr int base = 4 * 2 * 32 * D * 2 + 256 * D * 2 + 4 * 2 * 32 * 4 + (D == 128 ? 4 * (D / 16 - 1) * 1024 : 0);   // tile ring | V block | aux ring | K overflow
   const int smem = base + (ALIBI ? (4 * (p.hk_ratio + 1) + 15) / 16 * 16 : 0);                                          // | (ALIBI) slope table
   if (smem > 160 * 1024) return -2;
-  auto kern = fa_bwd_dkdv_w64_kernel<E, D, ALIBI>;
+  auto kern = fa_bwd_dkdv_w64_kernel<E, D, FEAT>;
   static std::atomic<unsigned long long> attr_mask{0};
   if (ensure_dyn_lds(attr_mask, (const void*)kern, 160 * 1024, true) != 0) return -1;
   const long long total = p.k_list ? (long long)p.k_bound * p.h_k : units_grid(p.k_units, p.k_unit_size);
@@ -617,13 +679,16 @@ static int launch_dkdv_w64_f(const BwdK& p, hipStream_t stream) {
 }
 template <typename E, int D>
 static int launch_dkdv_w64_t(const BwdK& p, hipStream_t stream) {
-  return p.alibi ? launch_dkdv_w64_f<E, D, true>(p, stream) : launch_dkdv_w64_f<E, D, false>(p, stream);
+  if constexpr (D == 128) { if (p.softcap > 0.f) return launch_dkdv_w64_f<E, D, FEAT_CAP>(p, stream); }
+  if (p.softcap > 0.f) return -2;   // (the softcap variant: head dim 128)
+  return p.alibi ? launch_dkdv_w64_f<E, D, FEAT_ALIBI>(p, stream) : launch_dkdv_w64_f<E, D, 0>(p, stream);
 }
 
 // 4 waves x 64 keys per workgroup (the same 256-key blocks as fa_bwd_dkdv_kernel: grid and work list unchanged).  Plain attention or ALiBi under a causal right
 // bound, head dim 64 / 128; -2 = not covered, the caller runs fa_bwd_dkdv_kernel.
 int launch_bwd_dkdv_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
-  if (p.softcap > 0.f || p.rng != nullptr || p.ds_ws != nullptr || p.d_chunks > 0) return -2;
+  if (p.rng != nullptr || p.ds_ws != nullptr || p.d_chunks > 0) return -2;
+  if (p.softcap > 0.f && p.alibi != nullptr) return -2;
   if (p.alibi != nullptr && p.wr != 0) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal
   if (d != 128 && d != 64) return -2;
   // buffer addressing of the streamed tiles: 32-bit byte offsets from the head's first row

@@ -114,3 +114,38 @@ def test_dq_w64_features_packed_batch(be, knobs, feature):
     assert torch.isfinite(w[0].float()).all()
     assert float((a[0].float() - w[0].float()).abs().max()) <= 4e-2 * max(1.0, float(a[0].float().abs().max()))
     assert torch.equal(a[2], w[2])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("shape", SHAPES + [(1, 4096, 4096, 2, 2, True, -1, -1), (1, 3000, 3000, 4, 1, True, 1024, 0)], ids=lambda s: "B%d_Sq%d_Sk%d_H%d_%d_c%d_w%d_%d" % s)
+def test_dkdv_w64_softcap(be, knobs, shape, dtype):
+    """Softcap on the 64-keys-per-wave dK/dV kernel (fa_bwd_dkdv_w64_kernel<.., FEAT_CAP>, head dim 128): the chains start from C = 0, the rows' c - LSE*log2e are
+    read in phase B, the cap and its derivative take three staged gaps per element.  FA_BWD_DKDV = 64 against 8 (the eight-wave feature kernel) with the dQ kernel
+    held fixed: dK / dV under the 3x-PyTorch rule and within 2x the eight-wave kernel's error (both scale every score in fp32), bitwise run-to-run, dQ untouched."""
+    B, Sq, Sk, H, Hk, causal, wl, wr = shape
+    d, cap = 128, 25.0
+    torch.manual_seed(0)
+    q = torch.randn(B, Sq, H, d, device="cuda", dtype=dtype)
+    k = torch.randn(B, Sk, Hk, d, device="cuda", dtype=dtype)
+    v, do = torch.randn_like(k), torch.randn_like(q)
+    sc = d ** -0.5
+    out, lse, _, _ = be.fwd(q, k, v, None, None, 0.0, sc, causal, wl, wr, cap, False, None)
+    bwd = lambda: be.bwd(do, q, k, v, out, lse, None, None, None, None, 0.0, sc, causal, wl, wr, cap, False, None, None)
+    knobs.set("FA_BWD_DQ_NW", 4)
+    knobs.set("FA_BWD_DKDV", 8)
+    g8 = bwd()
+    assert be.last_schedule()["bwd_dkdv_nw"] == 8
+    knobs.set("FA_BWD_DKDV", 64)
+    g64 = bwd()
+    assert be.last_schedule()["bwd_dkdv_nw"] == 64, be.last_schedule()
+    again = bwd()
+    assert all(torch.equal(a, b) for a, b in zip(g64[:3], again[:3])), "run-to-run"
+    assert torch.equal(g8[0], g64[0]), "dQ is not this kernel's"
+    r = torch_grads(q, k, v, do, causal, wl, wr, cap, None, 0.0, True)
+    pt = torch_grads(q, k, v, do, causal, wl, wr, cap, None, 0.0, False)
+    floor = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    for i, name in ((1, "dk"), (2, "dv")):
+        assert torch.isfinite(g64[i].float()).all(), name
+        e8, e64, e_pt = [float((x[i].float() - r[i]).abs().max()) for x in (g8, g64, pt)]
+        assert e64 <= max(3 * e_pt, floor), (name, e64, e_pt)
+        assert e64 <= max(2 * e8, floor), (name, e64, e8)
