@@ -61,7 +61,9 @@ def test_default_picks_it_from_2k_query_rows_at_head_dim_128(be):
         assert run_bwd(be, q, k, v, do, True)[3]["bwd_dkdv_nw"] == want, (S, d)
     q = torch.randn(1, 4096, 2, 128, device="cuda", dtype=torch.bfloat16)
     k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
-    assert run_bwd(be, q, k, v, do, True, softcap=20.0)[3]["bwd_dkdv_nw"] == 8   # feature variants stay on the eight-wave kernel
+    assert run_bwd(be, q, k, v, do, True, softcap=20.0)[3]["bwd_dkdv_nw"] == 64   # round 5: the softcap variant of this kernel (head dim 128)
+    assert run_bwd(be, q, k, v, do, True, p_drop=0.1)[3]["bwd_dkdv_nw"] == 8      # dropout and products of features stay on the eight-wave kernel
+    assert run_bwd(be, q, k, v, do, True, softcap=20.0, alibi=torch.full((2,), 0.1, device="cuda"))[3]["bwd_dkdv_nw"] == 8
 
 
 @pytest.mark.parametrize("d", [128, 64])
