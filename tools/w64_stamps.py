@@ -35,6 +35,7 @@ for (B, S, H, D, causal, blocks) in ((4, 4096, 32, 128, True, (15, 8, 2, 0)), (4
                 print(f"    u={u:2d}: " + " ".join(f"{x:6d}" for x in d))
     # per query block (all batch entries and heads): where the clocks go, wave 3 (the last to finish under a causal mask)
     st = st_all.reshape(B, H, S // 256, 4, 64)[:, :, :, 3, :]   # (B, H, m_block, 64)
+    print("  (58 iteration stamps fit the payload: for a block of more iterations -- n_it printed as 58 -- the last column is the iterations past the 58th PLUS the epilogue)")
     print("  m_block  n_it |  total | to_bar  qconv  to_loop |   u=0   mean u=1..n-5  last5 (sum) | epilogue")
     for mb in range(S // 256):
         n_it = min(((mb * 256 + 256 + 63) // 64 + 1) if causal else S // 64 + 1, 58)
