@@ -644,8 +644,13 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
   //   checked in the ISA by tools/isa_blocks.py --m0).
   auto fast_step = [&](auto halfc, auto parc, f32x16 (&s_cur)[QB], f32x16 (&s_nxt)[QB],
                        const u32x4 (&pf_prev)[QB][2], u32x4 (&pf_cur)[QB][2], const u32x4& dma_srd, const unsigned (&dma_off)[DPW],
-                       unsigned dma_toff, unsigned dma_dst, u32x4 (&kfr)[FA_W64_AH + 1], int drop_k0q = 0) __attribute__((always_inline)) {
+                       unsigned dma_toff, unsigned dma_dst, u32x4 (&kfr)[FA_W64_AH + 1], int drop_k0q = 0, auto modec = ICw<0>{}) __attribute__((always_inline)) {
     constexpr int half = decltype(halfc)::value, par = decltype(parc)::value;
+    // MODE (round 5): a wave's FIRST iteration has no previous probabilities (P = 0 by construction: its P.V MFMAs, and in its first step the exp2 work, are dead) and
+    // its LAST one scores no key of its own (the chains would be masked end to end): 1 = score chains only, 2 = score chains + this step's P, 3 = this step's P + P.V
+    // (+ the pending rescale), 4 = P.V only.  The dead halves' MFMAs, LDS reads and vector work are not issued: two of a block's iterations cost about a third of one.
+    constexpr int MODE = decltype(modec)::value;
+    constexpr bool DO_QK = MODE <= 2, DO_P = MODE == 0 || MODE == 2 || MODE == 3, DO_PV = MODE == 0 || MODE >= 3;
     constexpr int QKG = 2 * KS, PVG = 4 * DB, NG = QKG + PVG;
     // (DROP) group G = 4*qb + g (elements 16*qb + 4*g .. + 3 = keys k0 + 8*g + 4*hi .. + 3 of the step whose probabilities this step makes, k0 = 4 * drop_k0q):
     // round r of its Philox call sits in gap ((7*G + r) * (NG - 2)) / 56 -- two rounds per gap at D = 128, the last group done one gap before its elements are packed
@@ -659,8 +664,8 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     s16x4 vlo[RING], vhi[RING];
     auto rd_frag = [&](int f) __attribute__((always_inline)) {
       if (f < KS) {
-        kfr[f % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[f] + KOFF);
-      } else if (f < NF) {
+        if constexpr (DO_QK) kfr[f % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[f] + KOFF);
+      } else if (f < NF && DO_PV) {
         const int op = f - KS;
         const char FA_LDS* a0 = (const char FA_LDS*)(unsigned long)(unsigned)(va[op % DB] + VOFF + (16 * (op / DB)) * ROW_BYTES);
         vlo[f % RING] = lds_read_tr16(a0);
@@ -699,11 +704,13 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       // after it may still be in flight: slots f + 2 .. f + AH, one LDS instruction per K fragment, two per transposed V fragment).  hipcc
       // models an explicit s_waitcnt and drops its own wait in front of slot f + 1 -- sixteen fewer instructions per iteration.
       if constexpr (qb == 0 && (f & 1) == 0 && f + 1 < NF) {
-        constexpr auto ops = [](int g) constexpr { return g < KS ? 1 : g < NF ? 2 : 0; };
+        constexpr auto ops = [](int g) constexpr { return g < KS ? (DO_QK ? 1 : 0) : g < NF ? (DO_PV ? 2 : 0) : 0; };
         constexpr int out = [&]() constexpr { int n = 0; for (int g = f + 2; g <= f + AH; ++g) n += ops(g); return n; }();
-        __builtin_amdgcn_s_waitcnt(0xC07F | (out << 8));
+        if constexpr (f < KS ? DO_QK : DO_PV) __builtin_amdgcn_s_waitcnt(0xC07F | (out << 8));
       }
-      if constexpr (x < QKG) {
+      if constexpr (x < QKG ? !DO_QK : !DO_PV) {
+        // (a dead half: no MFMA in this gap)
+      } else if constexpr (x < QKG) {
         if constexpr (f == 0) mfma_s_first<E, qb * KS>(s_nxt[qb], kfr[f % RING], negm[qb]);
         else mfma_s_acc<E, qb * KS + f>(s_nxt[qb], kfr[f % RING]);
       } else {
@@ -764,7 +771,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       }
       // exp2 + row sums (two running sums per query block, carried across steps)
 #pragma unroll
-      for (int e = el_end(x); e < el_end(x + 1); ++e) {
+      for (int e = (DO_P ? el_end(x) : 32); e < (DO_P ? el_end(x + 1) : 32); ++e) {
         const int eq = e >> 4, r = e & 15;
         pe[eq][r] = fast_exp2(s_cur[eq][r]);
         l_run[eq][r & 1] += pe[eq][r];
@@ -774,7 +781,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
         // packing of P_i: PVG gaps, 16 conversions (one packed register each)
         constexpr int CPG = 16 / PVG > 0 ? 16 / PVG : 1;
 #pragma unroll
-        for (int c = y * CPG; c < (y + 1) * CPG && c < 16; ++c) {
+        for (int c = (DO_P ? y * CPG : 16); c < (y + 1) * CPG && c < 16; ++c) {
           const int j = c >> 2, m = c & 3, cq = j >> 1, t = j & 1;
           using V2 = __attribute__((ext_vector_type(2))) E;
           V2 pr;
@@ -793,7 +800,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
         }
         // the row-max tree of the fresh scores, the cross-half combine
 #pragma unroll
-        for (int mq = 0; mq < QB; ++mq) {
+        for (int mq = (DO_QK ? 0 : QB); mq < QB; ++mq) {
           const int g0 = tree_g0(mq);
           if (y >= g0 && y < g0 + 8 / UPG) {
 #pragma unroll
@@ -822,7 +829,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       }
       // carry: behind this step's last LDS wait (gap NG - 4: slot NF - 2, everything landed) the K ring is free -- request the first AH fragments of the SECOND
       // step's score chain (half 1 of the same K tile), one per gap; that step's waits count them exactly as if it had issued them itself
-      if constexpr (half == 0 && x >= NG - AH) {
+      if constexpr (half == 0 && x >= NG - AH && DO_QK) {   // (MODE 1 is followed by MODE 2, which scores; MODE 3 by MODE 4, which does not)
         constexpr int fn = x - (NG - AH);
         kfr[fn % RING] = *(const u32x4 FA_LDS*)(unsigned long)(unsigned)(ka[fn] + par * TILE_BYTES + 32 * ROW_BYTES);
       }
@@ -830,10 +837,12 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     });
 #pragma unroll
     for (int mq = 0; mq < QB; ++mq)
-      if (hm_gap(mq) >= PVG) tmax[mq] = vhalf_max(tmax[mq]);   // (no gap left for it)
+      if (hm_gap(mq) >= PVG && DO_QK) tmax[mq] = vhalf_max(tmax[mq]);   // (no gap left for it)
     static_assert(!SOFTCAP || QB + 8 / UPG < PVG - 1, "softcap: the capped maximum is made inside the gaps");
     if constexpr (SOFTCAP) { tmax[0] = cap_gt[0]; tmax[1] = cap_gt[1]; }   // (the decision's operand: the capped maximum relative to the row's base)
-    decide_and_rescale(tmax, s_nxt);
+    // (MODE 3: no fresh scores -- tmax = -inf moves nothing -- but a rescale factor decided one step ago is still pending: it has to meet O BEFORE the next step
+    // accumulates the probabilities that were made at the new base.  MODE 4: nothing can be pending.)
+    if constexpr (MODE != 4) decide_and_rescale(tmax, s_nxt);
   };
 
   // Iteration u (0 .. n_tiles) = two steps: 2u-1 and 2u score K_u (K buffer u & 1) and multiply by V_{u-1} (V buffer (u - 1) & 1);
@@ -889,8 +898,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       pg_page_n = nn / pg_tpp; pg_tin_n = nn - pg_page_n * pg_tpp;
     }
   };
-  auto step_pair = [&](auto parc, int u) __attribute__((always_inline)) {
-    constexpr int par = decltype(parc)::value;
+  // pmc: 0 = a full iteration, 1 = the wave's first (its P.V halves and the first step's exp2 work are dead: fast_step MODE 1 + 2), 2 = its last (its score
+  // chains are dead: MODE 3 + 4; no mask rewrites either)
+  auto step_pair = [&](auto parc, int u, auto pmc) __attribute__((always_inline)) {
+    constexpr int par = decltype(parc)::value, PM = decltype(pmc)::value;
+    using M0 = ICw<(PM == 1 ? 1 : PM == 2 ? 3 : 0)>; using M1 = ICw<(PM == 1 ? 2 : PM == 2 ? 4 : 0)>;
     // K_{u+1} rides in the first step, V_u in the second.  A tile past the block's last one is requested like any other: past the last key
     // the descriptor's range check zero-fills it, before that it is a real tile nobody looks at (its scores are masked, its V rows meet P = 0)
     // -- one tile of extra traffic per block against two descriptor selects per iteration.  Everything scalar the steps need is made HERE,
@@ -925,11 +937,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     asm volatile("" : "+s"(tk_), "+s"(tv_), "+s"(dst_k), "+s"(dst_v), "+s"(im32));
     // (each test on a freshly laundered scalar: as one hoisted boolean hipcc keeps a lane mask and spends five instructions per test)
     auto masked = [&]() __attribute__((always_inline)) { int c = im32; asm volatile("" : "+s"(c)); return c != 0; };
-    if (__builtin_expect(masked(), 0)) set_mask(2 * u);
-    fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, srd_k, koff_l, tk_, dst_k, kring, DROP ? step_key(2 * us - 1) >> 2 : 0);
-    if (__builtin_expect(masked(), 0)) set_mask(2 * u + 1);
-    fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, srd_v, voff_l, tv_, dst_v, kring, DROP ? step_key(2 * us) >> 2 : 0);
-    if (__builtin_expect(masked(), 0)) clear_mask(2 * u + 2);
+    if constexpr (PM != 2) { if (__builtin_expect(masked(), 0)) set_mask(2 * u); }
+    fast_step(ICw<0>{}, parc, sA, sB, pfA, pfB, srd_k, koff_l, tk_, dst_k, kring, DROP ? step_key(2 * us - 1) >> 2 : 0, M0{});
+    if constexpr (PM != 2) { if (__builtin_expect(masked(), 0)) set_mask(2 * u + 1); }
+    fast_step(ICw<1>{}, parc, sB, sA, pfB, pfA, srd_v, voff_l, tv_, dst_v, kring, DROP ? step_key(2 * us) >> 2 : 0, M1{});
+    if constexpr (PM != 2) { if (__builtin_expect(masked(), 0)) clear_mask(2 * u + 2); }
     iter_end();
   };
   auto idle_iter = [&](int u) __attribute__((always_inline)) {
@@ -948,12 +960,27 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     if (active) {
       pg_enter(u);
       if constexpr (ALIBI) { if (u > 0) clear_mask(2 * u); }   // (the broadcasts were initialised for step 0)
+      if constexpr (FEAT == 0) {
+        // (round 5) the first and the last iteration of the wave's range are peeled: u_last > ua whenever the wave is active at all (a key seen in iteration u is
+        // multiplied by V one iteration later); ua is even
+        step_pair(ICw<0>{}, u, ICw<1>{}); ++u;
 #pragma unroll 1
-      for (;;) {
-        step_pair(ICw<0>{}, u); ++u;
-        if (u > u_last) break;
-        step_pair(ICw<1>{}, u); ++u;
-        if (u > u_last) break;
+        for (;;) {
+          if (u >= u_last) break;
+          step_pair(ICw<1>{}, u, ICw<0>{}); ++u;
+          if (u >= u_last) break;
+          step_pair(ICw<0>{}, u, ICw<0>{}); ++u;
+        }
+        if (u & 1) step_pair(ICw<1>{}, u, ICw<2>{}); else step_pair(ICw<0>{}, u, ICw<2>{});
+        ++u;
+      } else {
+#pragma unroll 1
+        for (;;) {
+          step_pair(ICw<0>{}, u, ICw<0>{}); ++u;
+          if (u > u_last) break;
+          step_pair(ICw<1>{}, u, ICw<0>{}); ++u;
+          if (u > u_last) break;
+        }
       }
     }
 #pragma unroll 1
