@@ -710,6 +710,9 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
       }
       if constexpr (x < QKG ? !DO_QK : !DO_PV) {
         // (a dead half: no MFMA in this gap)
+        // MODE 1 / 2: the row-max tree (gaps QKG + 1 ..) reads the score chains a few instructions behind their last MFMAs -- in a full step sixteen P.V MFMAs sit
+        // in between; the MFMAs are inline asm, hipcc pads nothing: the wait states of "matrix pipe writes a VGPR, VALU reads it" are spent here
+        if constexpr (x == QKG && DO_QK) mfma_drain_acc();
       } else if constexpr (x < QKG) {
         if constexpr (f == 0) mfma_s_first<E, qb * KS>(s_nxt[qb], kfr[f % RING], negm[qb]);
         else mfma_s_acc<E, qb * KS + f>(s_nxt[qb], kfr[f % RING]);

@@ -52,7 +52,7 @@ def test_baseline_configs_pick_the_measured_schedules(lib):
 
 
 def test_sweep_rows_and_grid_fill(lib):
-    for S, want_nc, want_c in ((512, 64, 34), (1024, 64, 64), (2048, 64, 64), (4096, 64, 64), (16384, 64, 64)):
+    for S, want_nc, want_c in ((512, 64, 64), (1024, 64, 64), (2048, 64, 64), (4096, 64, 64), (16384, 64, 64)):   # (causal S = 512: the 64-rows kernel since round 5's peeled iterations)
         B = max(1, 16384 // S)
         assert q(lib, fwd_params(B, S, S, 16, 16, 128)) == want_nc, S
         assert q(lib, fwd_params(B, S, S, 16, 16, 128, causal=True)) == want_c, S

@@ -1,0 +1,45 @@
+"""The built kernels' MFMA results are never touched before the matrix pipe has written them (tools/isa_mfma_hazards.py).
+
+The hand-placed kernels issue MFMAs from inline asm: hipcc pads no wait states around them, and a variant that removes instructions between a score chain and its
+row-max tree (round 5's peeled first iteration) read registers the pipe had not written yet -- correct within tolerance, not reproducible, invisible to any
+standalone run.  This scans the disassembly of every object of the shipped library: seconds, no GPU."""
+import glob
+import importlib.util
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("isa_mfma_hazards", os.path.join(ROOT, "tools", "isa_mfma_hazards.py"))
+haz = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(haz)
+
+OBJS = sorted(glob.glob(os.path.join(ROOT, "flash-attention_amd", "csrc", "*.o")))
+
+
+def _device_objects():
+    return [o for o in OBJS if b".hip_fatbin" in subprocess.check_output([f"{haz.LLVM}/llvm-objdump", "-h", o])]
+
+
+def test_the_scan_sees_a_planted_hazard_and_honours_nops_and_mfmas_in_between():
+    mf = "\tv_mfma_f32_32x32x16_bf16 v[50:65], v[82:85], a[188:191], v[50:65]\n"
+    pad = "\tv_add_f32 v1, v2, v3\n"
+    early = "_Zk:\n" + mf + pad * 3 + "\tv_max3_f32 v4, v50, v51, v52\n"
+    assert [(h[1], h[2]) for h in haz.scan(early)] == [(3, 11)]
+    assert haz.scan("_Zk:\n" + mf + pad * 11 + "\tv_max3_f32 v4, v50, v51, v52\n") == []
+    assert haz.scan("_Zk:\n" + mf + "\ts_nop 15\n\tv_max3_f32 v4, v50, v51, v52\n") == []
+    other = "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[90:93], v[94:97], a[0:15]\n"
+    assert [(h[1], h[2]) for h in haz.scan("_Zk:\n" + mf + other + "\tv_max3_f32 v4, v50, v51, v52\n")] == [(8, 11)]   # one MFMA behind it: 8 passes, three short
+    assert haz.scan("_Zk:\n" + mf + other + other + "\tv_max3_f32 v4, v50, v51, v52\n") == []
+    assert [(h[1], h[2]) for h in haz.scan("_Zk:\n" + other + "\tv_accvgpr_read_b32 v1, a3\n")] == [(0, 11)]            # accumulator registers too
+    assert haz.scan("_Zk:\n" + mf + "\tv_mfma_f32_32x32x16_bf16 v[50:65], v[86:89], a[192:195], v[50:65]\n" + pad * 12) == []   # accumulating on: interlocked
+
+
+@pytest.mark.skipif(not OBJS, reason="library not built")
+def test_no_mfma_result_is_touched_early_in_the_shipped_objects():
+    objs = _device_objects()
+    assert len(objs) >= 10, objs
+    for o in objs:
+        hits = haz.scan(haz.disassemble(o))
+        assert not hits, (os.path.basename(o), hits[:3])

@@ -1,0 +1,123 @@
+"""Wait-state check of the hand-placed kernels: every MFMA result register against the first non-MFMA instruction that touches it.
+
+The 64-per-wave kernels issue their MFMAs from inline asm (operand register classes are part of the design), so hipcc's hazard recognizer pads nothing around
+them: "matrix pipe writes a VGPR / AGPR, another unit reads or overwrites it" needs passes + 3 wait states (CDNA3 ISA guide 4.5, "XDL write VGPR -> VALU
+read / write, VMEM / LDS / FLAT read": 5 / 11 / 19 for 2 / 8 / 16 passes) and nothing in the tool chain inserts them.  In a full step the distance is there by
+construction (a dozen MFMAs between a score chain's end and its row-max tree); a variant that REMOVES instructions can lose it -- round 5's peeled first
+iteration read a chain 3 instructions behind its last MFMA and the row maxima came from whatever the registers held before (results within tolerance,
+but not reproducible: 17 run-to-run failures in the GPU suite, none standalone).
+
+Counts along the straight-line order of the disassembly (conditional branches fall through, the count restarts behind an unconditional branch): a non-MFMA
+instruction = 1 wait state, s_nop N = N + 1, an MFMA in between = its passes (the matrix pipe takes the next one that many quads later).  A dependent MFMA
+(accumulating into the same tuple, or the register as its A / B operand) is not checked: back-to-back accumulation is interlocked, and no kernel here feeds
+an MFMA result to an A / B operand without a VALU conversion in between.
+
+usage: isa_mfma_hazards.py [file.o | file.s | file.dis ...]      (default: every object of flash-attention_amd/csrc)
+exit code 1 if any distance is below passes + 3."""
+import glob, os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def disassemble(obj):
+    """gfx950 code object of a hipcc host object -> llvm-objdump text."""
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "k.co")
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, os.path.join(td, "copy.o")])
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+        return subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", co], text=True)
+
+
+def passes_of(op):
+    m = re.match(r"v_mfma_\w+?_(\d+)x(\d+)x(\d+)_?(\w*)", op)
+    if not m:
+        return 16
+    mm, _, kk, ty = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4)
+    if ty in ("bf16", "f16"):   # gfx950: 32x32x16 = 8 passes, 16x16x32 = 4; the half-K forms of gfx942 take as long for half the work
+        return 8 if mm == 32 else 4
+    if ty.startswith(("f8", "bf8", "fp8")) or "f8f6f4" in op:
+        return 8 if mm == 32 else 4
+    return 16 if mm == 32 else 8    # f32 / xf32 / f64 / i8: priced at the slow end (none in the hot kernels)
+
+
+def regs_of(text):
+    """{('v', n), ('a', n), ...} named in an operand string."""
+    out = set()
+    for kind, lo, hi in re.findall(r"\b([va])\[(\d+):(\d+)\]", text):
+        out.update((kind, r) for r in range(int(lo), int(hi) + 1))
+    for kind, n in re.findall(r"\b([va])(\d+)\b", text):
+        out.add((kind, int(n)))
+    return out
+
+
+def scan(text):
+    """-> [(function, wait states, needed, mfma line, consumer line)] for every MFMA result touched too early."""
+    func, pending, found = "?", [], []   # pending: [dst regs, waited, needed, line]
+    for raw in text.split("\n"):
+        m = re.match(r"^(?:[0-9a-f]+ <)?(_Z\w+)>?:", raw)
+        if m:
+            func, pending = m.group(1), []
+            continue
+        line = re.split(r"//|;", raw)[0].strip()
+        if not line or line.startswith(".") or line.endswith(":") or not re.match(r"^[a-z]", line):
+            continue
+        op, _, rest = line.partition(" ")
+        if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+            p = passes_of(op)
+            dst = rest.split(",")[0]
+            srcs = rest.split(",", 1)[1] if "," in rest else ""
+            touched = regs_of(srcs)
+            keep = []
+            for ent in pending:
+                ent[1] += p
+                if ent[1] < ent[2] and (ent[0] & touched) and not (ent[0] & regs_of(dst)):   # an MFMA result as another tuple's operand: say so, it is not interlocked either
+                    found.append((func, ent[1] - p, ent[2], ent[3], line))
+                    continue
+                if ent[1] < ent[2] and not (ent[0] & regs_of(dst)):
+                    keep.append(ent)
+            pending = keep + [[regs_of(dst), 0, p + 3, line]]
+            continue
+        if op == "s_nop":
+            n = int(rest.strip() or 0) + 1
+            for ent in pending:
+                ent[1] += n
+            pending = [e for e in pending if e[1] < e[2]]
+            continue
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            pending = []
+            continue
+        touched = regs_of(rest) if not op.startswith("s_") else set()
+        keep = []
+        for ent in pending:
+            if ent[0] & touched:
+                found.append((func, ent[1], ent[2], ent[3], line))
+                continue
+            ent[1] += 1
+            if ent[1] < ent[2]:
+                keep.append(ent)
+        pending = keep
+    return found
+
+
+def main(argv):
+    files = argv or sorted(glob.glob(os.path.join(ROOT, "flash-attention_amd", "csrc", "*.o")))
+    bad = 0
+    for f in files:
+        if f.endswith(".o"):
+            if b".hip_fatbin" not in subprocess.check_output([f"{LLVM}/llvm-objdump", "-h", f]):
+                continue   # a host-only object
+            text = disassemble(f)
+        else:
+            text = open(f).read()
+        n_mfma = len(re.findall(r"\bv_mfma", text))
+        hits = scan(text)
+        print(f"{os.path.basename(f)}: {n_mfma} MFMAs, {len(hits)} result registers touched early")
+        for func, ws, need, mf, use in hits:
+            print(f"    {func[:70]}: {ws} of {need} wait states\n        {mf}\n        {use}")
+        bad += len(hits)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
