@@ -34,6 +34,9 @@ def test_the_scan_sees_a_planted_hazard_and_honours_nops_and_mfmas_in_between():
     assert haz.scan("_Zk:\n" + mf + other + other + "\tv_max3_f32 v4, v50, v51, v52\n") == []
     assert [(h[1], h[2]) for h in haz.scan("_Zk:\n" + other + "\tv_accvgpr_read_b32 v1, a3\n")] == [(0, 11)]            # accumulator registers too
     assert haz.scan("_Zk:\n" + mf + "\tv_mfma_f32_32x32x16_bf16 v[50:65], v[86:89], a[192:195], v[50:65]\n" + pad * 12) == []   # accumulating on: interlocked
+    # across a loop's back edge (a hipcc -S listing with labels; the objdump form resolves targets from the instruction addresses)
+    loop = "_Zk:\n.LBB0_1:\n\tv_max3_f32 v4, v50, v51, v52\n" + mf + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n"
+    assert [(h[1], h[2]) for h in haz.scan(loop)] == [(1, 11)]
 
 
 @pytest.mark.skipif(not OBJS, reason="library not built")

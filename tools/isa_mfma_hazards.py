@@ -7,8 +7,8 @@ construction (a dozen MFMAs between a score chain's end and its row-max tree); a
 iteration read a chain 3 instructions behind its last MFMA and the row maxima came from whatever the registers held before (results within tolerance,
 but not reproducible: 17 run-to-run failures in the GPU suite, none standalone).
 
-Counts along the straight-line order of the disassembly (conditional branches fall through, the count restarts behind an unconditional branch): a non-MFMA
-instruction = 1 wait state, s_nop N = N + 1, an MFMA in between = its passes (the matrix pipe takes the next one that many quads later).  A dependent MFMA
+Counts along the fall-through order of the disassembly AND across every branch to its target (loop back edges, the jumps into and out of cold code; three branches
+deep): a non-MFMA instruction = 1 wait state, s_nop N = N + 1, an MFMA in between = its passes (the matrix pipe takes the next one that many quads later).  A dependent MFMA
 (accumulating into the same tuple, or the register as its A / B operand) is not checked: back-to-back accumulation is interlocked, and no kernel here feeds
 an MFMA result to an A / B operand without a VALU conversion in between.
 
@@ -51,52 +51,102 @@ def regs_of(text):
     return out
 
 
-def scan(text):
-    """-> [(function, wait states, needed, mfma line, consumer line)] for every MFMA result touched too early."""
-    func, pending, found = "?", [], []   # pending: [dst regs, waited, needed, line]
+def parse(text):
+    """-> [(function, [(op, operands, branch target index or None)])]: llvm-objdump -d text (targets from the instruction addresses) or a hipcc -S listing (labels)."""
+    funcs, cur, labels, addrs = [], None, {}, {}
     for raw in text.split("\n"):
         m = re.match(r"^(?:[0-9a-f]+ <)?(_Z\w+)>?:", raw)
         if m:
-            func, pending = m.group(1), []
+            cur, labels, addrs = [], {}, {}
+            funcs.append((m.group(1), cur, labels, addrs))
+            continue
+        if cur is None:
+            continue
+        m = re.match(r"^(\.L\w+):", raw)
+        if m:
+            labels[m.group(1)] = len(cur)
             continue
         line = re.split(r"//|;", raw)[0].strip()
         if not line or line.startswith(".") or line.endswith(":") or not re.match(r"^[a-z]", line):
             continue
+        m = re.search(r"//\s*([0-9A-Fa-f]+):", raw)
+        if m:
+            addrs[int(m.group(1), 16)] = len(cur)
         op, _, rest = line.partition(" ")
-        if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+        cur.append([op, rest.strip(), int(m.group(1), 16) if m else None])
+    out = []
+    for name, ins, labels, addrs in funcs:
+        res = []
+        for op, rest, addr in ins:
+            tgt = None
+            if op.startswith(("s_branch", "s_cbranch")):
+                if rest in labels:
+                    tgt = labels[rest]
+                elif addr is not None and re.match(r"^-?\d+$", rest):
+                    off = int(rest)
+                    tgt = addrs.get(addr + 4 + 4 * (off - 65536 if off >= 32768 else off))
+            res.append((op, rest, tgt))
+        out.append((name, res))
+    return out
+
+
+def scan(text):
+    """-> [(function, wait states, needed, mfma line, consumer line)] for every MFMA result touched too early.  The walk follows the fall-through order; at every
+    branch (conditional or not) the registers still pending are also carried to the branch target (and over further branches, three deep)."""
+    found, seen = [], set()
+
+    def step(func, ins, i, pending):
+        """one instruction against the pending list [dst regs, waited, needed, mfma text, mfma index]; returns the new list"""
+        op, rest, _ = ins[i]
+        line = f"{op} {rest}"
+        if op.startswith(("v_mfma", "v_smfmac")):
             p = passes_of(op)
-            dst = rest.split(",")[0]
-            srcs = rest.split(",", 1)[1] if "," in rest else ""
-            touched = regs_of(srcs)
+            dst = regs_of(rest.split(",")[0])
+            touched = regs_of(rest.split(",", 1)[1] if "," in rest else "")
             keep = []
             for ent in pending:
-                ent[1] += p
-                if ent[1] < ent[2] and (ent[0] & touched) and not (ent[0] & regs_of(dst)):   # an MFMA result as another tuple's operand: say so, it is not interlocked either
-                    found.append((func, ent[1] - p, ent[2], ent[3], line))
+                ent = [ent[0], ent[1] + p, ent[2], ent[3], ent[4]]
+                if ent[0] & dst:
+                    continue                         # accumulating on in the same tuple: interlocked
+                if ent[1] < ent[2] and (ent[0] & touched):   # an MFMA result as another tuple's operand: reported, it is not interlocked either
+                    if (ent[4], i) not in seen:
+                        seen.add((ent[4], i)); found.append((func, ent[1] - p, ent[2], ent[3], line))
                     continue
-                if ent[1] < ent[2] and not (ent[0] & regs_of(dst)):
+                if ent[1] < ent[2]:
                     keep.append(ent)
-            pending = keep + [[regs_of(dst), 0, p + 3, line]]
-            continue
+            return keep + [[dst, 0, p + 3, line, i]]
         if op == "s_nop":
-            n = int(rest.strip() or 0) + 1
-            for ent in pending:
-                ent[1] += n
-            pending = [e for e in pending if e[1] < e[2]]
-            continue
-        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
-            pending = []
-            continue
+            n = int(rest or 0) + 1
+            return [[e[0], e[1] + n, e[2], e[3], e[4]] for e in pending if e[1] + n < e[2]]
         touched = regs_of(rest) if not op.startswith("s_") else set()
         keep = []
         for ent in pending:
             if ent[0] & touched:
-                found.append((func, ent[1], ent[2], ent[3], line))
+                if (ent[4], i) not in seen:
+                    seen.add((ent[4], i)); found.append((func, ent[1], ent[2], ent[3], line))
                 continue
-            ent[1] += 1
-            if ent[1] < ent[2]:
-                keep.append(ent)
-        pending = keep
+            if ent[1] + 1 < ent[2]:
+                keep.append([ent[0], ent[1] + 1, ent[2], ent[3], ent[4]])
+        return keep
+
+    def side_walk(func, ins, i, pending, depth):
+        while pending and i < len(ins):
+            op, _, tgt = ins[i]
+            pending = step(func, ins, i, pending)
+            if op.startswith(("s_branch", "s_cbranch")) and tgt is not None and depth < 3 and pending:
+                side_walk(func, ins, tgt, [list(e) for e in pending], depth + 1)
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                return
+            i += 1
+
+    for func, ins in parse(text):
+        pending = []
+        for i, (op, _, tgt) in enumerate(ins):
+            pending = step(func, ins, i, pending)
+            if op.startswith(("s_branch", "s_cbranch")) and tgt is not None and pending:
+                side_walk(func, ins, tgt, [list(e) for e in pending], 1)
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                pending = []
     return found
 
 
