@@ -34,6 +34,10 @@ def test_the_scan_sees_a_planted_hazard_and_honours_nops_and_mfmas_in_between():
     assert haz.scan("_Zk:\n" + mf + other + other + "\tv_max3_f32 v4, v50, v51, v52\n") == []
     assert [(h[1], h[2]) for h in haz.scan("_Zk:\n" + other + "\tv_accvgpr_read_b32 v1, a3\n")] == [(0, 11)]            # accumulator registers too
     assert haz.scan("_Zk:\n" + mf + "\tv_mfma_f32_32x32x16_bf16 v[50:65], v[86:89], a[192:195], v[50:65]\n" + pad * 12) == []   # accumulating on: interlocked
+    # the other direction: a VALU result as an MFMA operand wants two wait states
+    cvt = "\tv_cvt_pk_bf16_f32 v82, v1, v2\n"
+    assert [(h[1], h[2]) for h in haz.scan_operands("_Zk:\n" + cvt + pad + mf)] == [(1, 2)]
+    assert haz.scan_operands("_Zk:\n" + cvt + pad * 2 + mf) == [] and haz.scan_operands("_Zk:\n" + cvt + "\ts_nop 1\n" + mf) == []
     # across a loop's back edge (a hipcc -S listing with labels; the objdump form resolves targets from the instruction addresses)
     loop = "_Zk:\n.LBB0_1:\n\tv_max3_f32 v4, v50, v51, v52\n" + mf + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n"
     assert [(h[1], h[2]) for h in haz.scan(loop)] == [(1, 11)]
@@ -44,5 +48,8 @@ def test_no_mfma_result_is_touched_early_in_the_shipped_objects():
     objs = _device_objects()
     assert len(objs) >= 10, objs
     for o in objs:
-        hits = haz.scan(haz.disassemble(o))
+        text = haz.disassemble(o)
+        hits = haz.scan(text)
         assert not hits, (os.path.basename(o), hits[:3])
+        late = haz.scan_operands(text)
+        assert not late, (os.path.basename(o), late[:3])

@@ -12,6 +12,8 @@ deep): a non-MFMA instruction = 1 wait state, s_nop N = N + 1, an MFMA in betwee
 (accumulating into the same tuple, or the register as its A / B operand) is not checked: back-to-back accumulation is interlocked, and no kernel here feeds
 an MFMA result to an A / B operand without a VALU conversion in between.
 
+Second rule, the other direction (scan_operands): a VALU result as an MFMA operand needs 2 wait states.
+
 usage: isa_mfma_hazards.py [file.o | file.s | file.dis ...]      (default: every object of flash-attention_amd/csrc)
 exit code 1 if any distance is below passes + 3."""
 import glob, os, re, subprocess, sys, tempfile
@@ -150,6 +152,27 @@ def scan(text):
     return found
 
 
+def scan_operands(text, need=2):
+    """The other direction: a VALU instruction writes a VGPR, an MFMA reads it as an operand fewer than `need` wait states later (hipcc keeps 2 in the kernels it
+    schedules itself -- fa_bwd.hip's dQ kernel has 68 operand pairs at exactly 2 and none below -- and knows nothing about the inline-asm ones).
+    -> [(function, wait states, needed, writer, mfma)]"""
+    found = []
+    for func, ins in parse(text):
+        recent = []   # [registers written, wait states since, text]
+        for op, rest, _ in ins:
+            line = f"{op} {rest}"
+            if op.startswith(("v_mfma", "v_smfmac")):
+                srcs = regs_of(rest.split(",", 1)[1] if "," in rest else "")
+                found += [(func, age, need, w, line) for regs, age, w in recent if regs & srcs]
+                recent = []
+                continue
+            n = int(rest or 0) + 1 if op == "s_nop" else 1
+            recent = [[r, a + n, w] for r, a, w in recent if a + n < need]
+            if op.startswith("v_") and not op.startswith("v_cmp") and "," in rest:
+                recent.append([regs_of(rest.split(",")[0]), 0, line])
+    return found
+
+
 def main(argv):
     files = argv or sorted(glob.glob(os.path.join(ROOT, "flash-attention_amd", "csrc", "*.o")))
     bad = 0
@@ -161,11 +184,11 @@ def main(argv):
         else:
             text = open(f).read()
         n_mfma = len(re.findall(r"\bv_mfma", text))
-        hits = scan(text)
-        print(f"{os.path.basename(f)}: {n_mfma} MFMAs, {len(hits)} result registers touched early")
-        for func, ws, need, mf, use in hits:
-            print(f"    {func[:70]}: {ws} of {need} wait states\n        {mf}\n        {use}")
-        bad += len(hits)
+        hits, ops = scan(text), scan_operands(text)
+        print(f"{os.path.basename(f)}: {n_mfma} MFMAs, {len(hits)} result registers touched early, {len(ops)} operands written late")
+        for func, ws, need, first, second in hits + ops:
+            print(f"    {func[:70]}: {ws} of {need} wait states\n        {first}\n        {second}")
+        bad += len(hits) + len(ops)
     return 1 if bad else 0
 
 
