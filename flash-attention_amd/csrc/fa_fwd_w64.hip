@@ -819,8 +819,11 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
           // cross-half combine in two statements a gap apart: the copy, then swap + max (v_permlane32_swap wants two wait states
           // after the write of its operand: the gap's other instructions provide them, no s_nop)
           if (y == hm_gap(mq) - 1 && UPG != 1) asm volatile("v_mov_b32 %0, %1" : "=v"(tcopy[mq]) : "v"(tmax[mq]));
-          if (y == hm_gap(mq))
-            asm volatile("v_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(tmax[mq]), "+v"(tcopy[mq]));
+          if (y == hm_gap(mq)) {
+            // (MODE 1 / 2: the gap's other instructions are gone -- the two wait states are spent explicitly; tools/isa_mfma_hazards.py checks the distance)
+            if constexpr (!DO_PV) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(tmax[mq]), "+v"(tcopy[mq]));
+            else asm volatile("v_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(tmax[mq]), "+v"(tcopy[mq]));
+          }
           if constexpr (SOFTCAP) {   // the decision's operand: the row maximum through the cap, relative to the row's base -- c*tanh(z_max) - m_base, -inf kept
             constexpr int last = PVG - 1;
             const int g1 = hm_gap(mq) + 1 < last ? hm_gap(mq) + 1 : last, g2 = hm_gap(mq) + 2 < last ? hm_gap(mq) + 2 : last, g3 = hm_gap(mq) + 3 < last ? hm_gap(mq) + 3 : last;

@@ -38,6 +38,12 @@ def test_the_scan_sees_a_planted_hazard_and_honours_nops_and_mfmas_in_between():
     cvt = "\tv_cvt_pk_bf16_f32 v82, v1, v2\n"
     assert [(h[1], h[2]) for h in haz.scan_operands("_Zk:\n" + cvt + pad + mf)] == [(1, 2)]
     assert haz.scan_operands("_Zk:\n" + cvt + pad * 2 + mf) == [] and haz.scan_operands("_Zk:\n" + cvt + "\ts_nop 1\n" + mf) == []
+    # ... and as a v_permlane32_swap operand; a transcendental's result wants one before a plain VALU instruction
+    mov = "\tv_mov_b32_e32 v4, v16\n"
+    assert [(h[1], h[2]) for h in haz.scan_valu_pairs("_Zk:\n" + mov + pad + "\tv_permlane32_swap_b32_e32 v16, v4\n")] == [(1, 2)]
+    assert haz.scan_valu_pairs("_Zk:\n" + mov + "\ts_nop 1\n\tv_permlane32_swap_b32_e32 v16, v4\n") == []
+    assert [(h[1], h[2]) for h in haz.scan_valu_pairs("_Zk:\n\tv_exp_f32_e32 v9, v8\n\tv_add_f32_e32 v7, v9, v7\n")] == [(0, 1)]
+    assert haz.scan_valu_pairs("_Zk:\n\tv_exp_f32_e32 v9, v8\n" + pad + "\tv_add_f32_e32 v7, v9, v7\n") == []
     # across a loop's back edge (a hipcc -S listing with labels; the objdump form resolves targets from the instruction addresses)
     loop = "_Zk:\n.LBB0_1:\n\tv_max3_f32 v4, v50, v51, v52\n" + mf + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n"
     assert [(h[1], h[2]) for h in haz.scan(loop)] == [(1, 11)]
@@ -51,5 +57,5 @@ def test_no_mfma_result_is_touched_early_in_the_shipped_objects():
         text = haz.disassemble(o)
         hits = haz.scan(text)
         assert not hits, (os.path.basename(o), hits[:3])
-        late = haz.scan_operands(text)
+        late = haz.scan_operands(text) + haz.scan_valu_pairs(text)
         assert not late, (os.path.basename(o), late[:3])

@@ -12,7 +12,8 @@ deep): a non-MFMA instruction = 1 wait state, s_nop N = N + 1, an MFMA in betwee
 (accumulating into the same tuple, or the register as its A / B operand) is not checked: back-to-back accumulation is interlocked, and no kernel here feeds
 an MFMA result to an A / B operand without a VALU conversion in between.
 
-Second rule, the other direction (scan_operands): a VALU result as an MFMA operand needs 2 wait states.
+Second rule, the other direction (scan_operands): a VALU result as an MFMA operand needs 2 wait states.  Third (scan_valu_pairs): a VALU result as an operand of
+v_permlane*_swap needs 2, a transcendental's result in a non-transcendental VALU instruction 1 -- an asm statement gets neither from hipcc.
 
 usage: isa_mfma_hazards.py [file.o | file.s | file.dis ...]      (default: every object of flash-attention_amd/csrc)
 exit code 1 if any distance is below passes + 3."""
@@ -173,6 +174,35 @@ def scan_operands(text, need=2):
     return found
 
 
+def scan_valu_pairs(text):
+    """Two VALU -> VALU distances hipcc keeps by itself and an asm statement does not get: a VALU result as a v_permlane*_swap operand (2 wait states; the compiler-
+    scheduled forwards hold 135 / 176 swaps at exactly 2, none below) and a transcendental's result in a non-transcendental VALU instruction (1).
+    -> [(function, wait states, needed, writer, reader)]"""
+    TRANS = ("v_exp", "v_log", "v_rcp", "v_rsq", "v_sqrt", "v_sin", "v_cos")
+    found = []
+    for func, ins in parse(text):
+        recent = []   # [registers written, wait states since, text, is transcendental]
+        for op, rest, _ in ins:
+            line = f"{op} {rest}"
+            if op.startswith("v_") and "," in rest and not op.startswith(("v_mfma", "v_smfmac")):
+                swap = op.startswith(("v_permlane16_swap", "v_permlane32_swap"))
+                reads = regs_of(rest) if swap else regs_of(rest.split(",", 1)[1])
+                for regs, age, w, tr in recent:
+                    if regs & reads:
+                        if swap and age < 2:
+                            found.append((func, age, 2, w, line))
+                        elif tr and age < 1 and not op.startswith(TRANS):
+                            found.append((func, age, 1, w, line))
+            n = int(rest or 0) + 1 if op == "s_nop" else 1
+            recent = [[r, a + n, w, t] for r, a, w, t in recent if a + n < 2]
+            if op.startswith("v_") and not op.startswith("v_cmp") and "," in rest:
+                written = regs_of(rest.split(",")[0])
+                if op.startswith(("v_permlane16_swap", "v_permlane32_swap", "v_swap")):
+                    written |= regs_of(rest.split(",")[1])
+                recent.append([written, 0, line, op.startswith(TRANS)])
+    return found
+
+
 def main(argv):
     files = argv or sorted(glob.glob(os.path.join(ROOT, "flash-attention_amd", "csrc", "*.o")))
     bad = 0
@@ -184,8 +214,9 @@ def main(argv):
         else:
             text = open(f).read()
         n_mfma = len(re.findall(r"\bv_mfma", text))
-        hits, ops = scan(text), scan_operands(text)
-        print(f"{os.path.basename(f)}: {n_mfma} MFMAs, {len(hits)} result registers touched early, {len(ops)} operands written late")
+        hits, ops, pairs = scan(text), scan_operands(text), scan_valu_pairs(text)
+        print(f"{os.path.basename(f)}: {n_mfma} MFMAs, {len(hits)} result registers touched early, {len(ops)} operands written late, {len(pairs)} swap / transcendental pairs too close")
+        ops = ops + pairs
         for func, ws, need, first, second in hits + ops:
             print(f"    {func[:70]}: {ws} of {need} wait states\n        {first}\n        {second}")
         bad += len(hits) + len(ops)
