@@ -44,6 +44,11 @@ def test_the_scan_sees_a_planted_hazard_and_honours_nops_and_mfmas_in_between():
     assert haz.scan_valu_pairs("_Zk:\n" + mov + "\ts_nop 1\n\tv_permlane32_swap_b32_e32 v16, v4\n") == []
     assert [(h[1], h[2]) for h in haz.scan_valu_pairs("_Zk:\n\tv_exp_f32_e32 v9, v8\n\tv_add_f32_e32 v7, v9, v7\n")] == [(0, 1)]
     assert haz.scan_valu_pairs("_Zk:\n\tv_exp_f32_e32 v9, v8\n" + pad + "\tv_add_f32_e32 v7, v9, v7\n") == []
+    # an SGPR from the VALU as a memory instruction's descriptor / offset: five
+    rfl = "\tv_readfirstlane_b32 s20, v3\n"
+    dma = "\tbuffer_load_dwordx4 v7, s[8:11], s20 offen lds\n"
+    assert [(h[1], h[2]) for h in haz.scan_sgpr_vmem("_Zk:\n" + rfl + pad * 4 + dma)] == [(4, 5)]
+    assert haz.scan_sgpr_vmem("_Zk:\n" + rfl + pad * 5 + dma) == [] and haz.scan_sgpr_vmem("_Zk:\n" + rfl + "\ts_nop 4\n" + dma) == []
     # across a loop's back edge (a hipcc -S listing with labels; the objdump form resolves targets from the instruction addresses)
     loop = "_Zk:\n.LBB0_1:\n\tv_max3_f32 v4, v50, v51, v52\n" + mf + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n"
     assert [(h[1], h[2]) for h in haz.scan(loop)] == [(1, 11)]
@@ -57,5 +62,5 @@ def test_no_mfma_result_is_touched_early_in_the_shipped_objects():
         text = haz.disassemble(o)
         hits = haz.scan(text)
         assert not hits, (os.path.basename(o), hits[:3])
-        late = haz.scan_operands(text) + haz.scan_valu_pairs(text)
+        late = haz.scan_operands(text) + haz.scan_valu_pairs(text) + haz.scan_sgpr_vmem(text)
         assert not late, (os.path.basename(o), late[:3])

@@ -13,11 +13,12 @@ deep): a non-MFMA instruction = 1 wait state, s_nop N = N + 1, an MFMA in betwee
 an MFMA result to an A / B operand without a VALU conversion in between.
 
 Second rule, the other direction (scan_operands): a VALU result as an MFMA operand needs 2 wait states.  Third (scan_valu_pairs): a VALU result as an operand of
-v_permlane*_swap needs 2, a transcendental's result in a non-transcendental VALU instruction 1 -- an asm statement gets neither from hipcc.
+v_permlane*_swap needs 2, a transcendental's result in a non-transcendental VALU instruction 1 -- an asm statement gets neither from hipcc.  Fourth (scan_sgpr_vmem):
+an SGPR written by a VALU instruction (v_readfirstlane ...) as the descriptor / offset of a memory instruction needs 5.
 
 usage: isa_mfma_hazards.py [file.o | file.s | file.dis ...]      (default: every object of flash-attention_amd/csrc)
 exit code 1 if any distance is below passes + 3."""
-import glob, os, re, subprocess, sys, tempfile
+import functools, glob, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
@@ -54,6 +55,7 @@ def regs_of(text):
     return out
 
 
+@functools.lru_cache(maxsize=2)
 def parse(text):
     """-> [(function, [(op, operands, branch target index or None)])]: llvm-objdump -d text (targets from the instruction addresses) or a hipcc -S listing (labels)."""
     funcs, cur, labels, addrs = [], None, {}, {}
@@ -203,6 +205,39 @@ def scan_valu_pairs(text):
     return found
 
 
+def sregs_of(text):
+    out = set()
+    for lo, hi in re.findall(r"\bs\[(\d+):(\d+)\]", text):
+        out.update(range(int(lo), int(hi) + 1))
+    out.update(int(n) for n in re.findall(r"\bs(\d+)\b", text))
+    if "vcc" in text:
+        out.update((106, 107))
+    return out
+
+
+def scan_sgpr_vmem(text, need=5):
+    """A VALU instruction writes an SGPR (v_readfirstlane, v_readlane, a compare, a carry out), a memory instruction reads it as descriptor / offset fewer than 5 wait
+    states later (hipcc: 44 pairs at exactly 5 in fa_bwd.hip's dK/dV kernel, none below; the tile DMAs of the 64-per-wave kernels are asm statements).
+    -> [(function, wait states, needed, writer, reader)]"""
+    found = []
+    for func, ins in parse(text):
+        recent = []
+        for op, rest, _ in ins:
+            line = f"{op} {rest}"
+            if op.startswith(("buffer_", "global_", "flat_", "scratch_")):
+                rd = sregs_of(rest)
+                found += [(func, age, need, w, line) for regs, age, w in recent if regs & rd]
+            n = int(rest or 0) + 1 if op == "s_nop" else 1
+            recent = [[r, a + n, w] for r, a, w in recent if a + n < need]
+            if op.startswith("v_") and "," in rest:
+                written = sregs_of(rest.split(",")[0])
+                if op.startswith("v_cmp") and not written:
+                    written = {106, 107}   # the e32 form writes vcc
+                if written:
+                    recent.append([written, 0, line])
+    return found
+
+
 def main(argv):
     files = argv or sorted(glob.glob(os.path.join(ROOT, "flash-attention_amd", "csrc", "*.o")))
     bad = 0
@@ -214,8 +249,8 @@ def main(argv):
         else:
             text = open(f).read()
         n_mfma = len(re.findall(r"\bv_mfma", text))
-        hits, ops, pairs = scan(text), scan_operands(text), scan_valu_pairs(text)
-        print(f"{os.path.basename(f)}: {n_mfma} MFMAs, {len(hits)} result registers touched early, {len(ops)} operands written late, {len(pairs)} swap / transcendental pairs too close")
+        hits, ops, pairs = scan(text), scan_operands(text), scan_valu_pairs(text) + scan_sgpr_vmem(text)
+        print(f"{os.path.basename(f)}: {n_mfma} MFMAs, {len(hits)} result registers touched early, {len(ops)} operands written late, {len(pairs)} swap / transcendental / scalar-operand pairs too close")
         ops = ops + pairs
         for func, ws, need, first, second in hits + ops:
             print(f"    {func[:70]}: {ws} of {need} wait states\n        {first}\n        {second}")
