@@ -58,6 +58,8 @@ def test_sweep_rows_and_grid_fill(lib):
         assert q(lib, fwd_params(B, S, S, 16, 16, 128, causal=True)) == want_c, S
     assert q(lib, fwd_params(1, 1024, 1024, 4, 4, 128)) == 34          # 16 blocks of 256 rows cannot fill 256 CUs: 128-row blocks
     assert q(lib, fwd_params(1, 16384, 16384, 2, 2, 128)) == 64        # long key loops take it regardless
+    assert q(lib, fwd_params(32, 512, 384, 16, 16, 128)) == 34         # 6 key tiles in all without a right bound: not measured on the 64-rows kernel, the old threshold stands
+    assert q(lib, fwd_params(32, 512, 768, 16, 16, 128, causal=True)) == 64   # (6 visible tiles on average under the causal bound: measured at 4)
     assert q(lib, fwd_params(64, 128, 4096, 16, 16, 128)) == 4         # short query chunks: lock-step
     assert q(lib, fwd_params(16, 1024, 1024, 16, 16, 64, causal=True)) == 34   # D = 64 under a causal mask needs 16 tiles on average
     assert q(lib, fwd_params(8, 2048, 2048, 16, 16, 64, causal=True)) == 64
