@@ -188,8 +188,9 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
       // (a left window bound keeps the old threshold: both ends of its short key range are masked iterations, and the early waves of a
       // block idle at both -- config 5, 20 tiles per block: 792 TFLOP/s on the pipelined kernel against 741-763 on this one)
       // (round 5: under a right bound from 4 tiles on average -- causal S = 512 -- since a wave's first and last iteration are peeled: 431 against 383 TFLOP/s there,
-      // profiles/r05_fwd_w64_peel.txt; without a right bound 4-7 tiles means 256-448 keys in all, which was not measured: the old threshold stands)
-      else nw = (long_loop || (tiles >= (right_bounded ? 4 : 8) && wl < 0 && a->seqlen_q >= 512 && fills)) ? 64 : fallback;
+      // profiles/r05_fwd_w64_peel.txt; without a right bound 4-7 tiles means 256-448 keys in all, and a packed batch is sized here by its LONGEST sequence (its
+      // short ones would leave most of a 256-row block empty): neither was measured, the old threshold stands for both)
+      else nw = (long_loop || (tiles >= ((right_bounded && !a->cu_seqlens_q) ? 4 : 8) && wl < 0 && a->seqlen_q >= 512 && fills)) ? 64 : fallback;
     } else if (a->d == 64) {
       const long need = right_bounded ? 16 : 32;
       nw = (!fa::knobs().strict && a->seqlen_q >= 512 && (tiles >= 64 || (tiles >= need && fills))) ? 64 : fallback;

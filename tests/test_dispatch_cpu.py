@@ -60,6 +60,8 @@ def test_sweep_rows_and_grid_fill(lib):
     assert q(lib, fwd_params(1, 16384, 16384, 2, 2, 128)) == 64        # long key loops take it regardless
     assert q(lib, fwd_params(32, 512, 384, 16, 16, 128)) == 34         # 6 key tiles in all without a right bound: not measured on the 64-rows kernel, the old threshold stands
     assert q(lib, fwd_params(32, 512, 768, 16, 16, 128, causal=True)) == 64   # (6 visible tiles on average under the causal bound: measured at 4)
+    a = fwd_params(32, 512, 512, 16, 16, 128, causal=True, cu_seqlens_q=1, cu_seqlens_k=1)   # a packed batch is sized by its longest sequence: the old threshold
+    assert q(lib, a, varlen=1) == 34
     assert q(lib, fwd_params(64, 128, 4096, 16, 16, 128)) == 4         # short query chunks: lock-step
     assert q(lib, fwd_params(16, 1024, 1024, 16, 16, 64, causal=True)) == 34   # D = 64 under a causal mask needs 16 tiles on average
     assert q(lib, fwd_params(8, 2048, 2048, 16, 16, 64, causal=True)) == 64
