@@ -49,6 +49,14 @@ def test_the_scan_sees_a_planted_hazard_and_honours_nops_and_mfmas_in_between():
     dma = "\tbuffer_load_dwordx4 v7, s[8:11], s20 offen lds\n"
     assert [(h[1], h[2]) for h in haz.scan_sgpr_vmem("_Zk:\n" + rfl + pad * 4 + dma)] == [(4, 5)]
     assert haz.scan_sgpr_vmem("_Zk:\n" + rfl + pad * 5 + dma) == [] and haz.scan_sgpr_vmem("_Zk:\n" + rfl + "\ts_nop 4\n" + dma) == []
+    # counted LDS waits: three reads in flight, the MFMA uses the first two
+    rd = lambda d: f"\tds_read_b64_tr_b16 v[{d}:{d + 1}], v1\n"
+    use = "\tv_mfma_f32_32x32x16_bf16 a[0:15], v[10:13], v[20:23], a[0:15]\n"
+    assert haz.scan_lds_waits("_Zk:\n" + rd(10) + rd(12) + rd(30) + "\ts_waitcnt lgkmcnt(1)\n" + use) == []
+    assert [h[3] for h in haz.scan_lds_waits("_Zk:\n" + rd(10) + rd(12) + rd(30) + "\ts_waitcnt lgkmcnt(2)\n" + use)] == ["ds_read_b64_tr_b16 v[12:13], v1"]
+    assert len(haz.scan_lds_waits("_Zk:\n" + rd(10) + rd(12) + use)) == 2
+    # (a scalar load shares the counter and returns out of order: lgkmcnt(1) no longer proves the second read back)
+    assert len(haz.scan_lds_waits("_Zk:\n" + rd(10) + rd(12) + "\ts_load_dword s4, s[0:1], 0x0\n\ts_waitcnt lgkmcnt(1)\n" + use)) == 1
     # across a loop's back edge (a hipcc -S listing with labels; the objdump form resolves targets from the instruction addresses)
     loop = "_Zk:\n.LBB0_1:\n\tv_max3_f32 v4, v50, v51, v52\n" + mf + "\ts_cbranch_scc1 .LBB0_1\n\ts_endpgm\n"
     assert [(h[1], h[2]) for h in haz.scan(loop)] == [(1, 11)]
@@ -62,5 +70,5 @@ def test_no_mfma_result_is_touched_early_in_the_shipped_objects():
         text = haz.disassemble(o)
         hits = haz.scan(text)
         assert not hits, (os.path.basename(o), hits[:3])
-        late = haz.scan_operands(text) + haz.scan_valu_pairs(text) + haz.scan_sgpr_vmem(text)
+        late = haz.scan_operands(text) + haz.scan_valu_pairs(text) + haz.scan_sgpr_vmem(text) + haz.scan_lds_waits(text)
         assert not late, (os.path.basename(o), late[:3])

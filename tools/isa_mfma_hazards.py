@@ -14,10 +14,12 @@ an MFMA result to an A / B operand without a VALU conversion in between.
 
 Second rule, the other direction (scan_operands): a VALU result as an MFMA operand needs 2 wait states.  Third (scan_valu_pairs): a VALU result as an operand of
 v_permlane*_swap needs 2, a transcendental's result in a non-transcendental VALU instruction 1 -- an asm statement gets neither from hipcc.  Fourth (scan_sgpr_vmem):
-an SGPR written by a VALU instruction (v_readfirstlane ...) as the descriptor / offset of a memory instruction needs 5.
+an SGPR written by a VALU instruction (v_readfirstlane ...) as the descriptor / offset of a memory instruction needs 5.  Fifth (scan_lds_waits): every register an LDS
+read returns into is covered by a counted s_waitcnt lgkmcnt before its first use (the asm-issued transposed reads have no other protection; weakening any one of the
+hand-placed waits of the forward by 2 is flagged in 12 of 15 sampled places, the rest have slack).
 
 usage: isa_mfma_hazards.py [file.o | file.s | file.dis ...]      (default: every object of flash-attention_amd/csrc)
-exit code 1 if any distance is below passes + 3."""
+exit code 1 on any finding."""
 import functools, glob, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -238,6 +240,67 @@ def scan_sgpr_vmem(text, need=5):
     return found
 
 
+def scan_lds_waits(text):
+    """Every register an LDS read returns into, against its first use: the counted s_waitcnt lgkmcnt(N) in front of the use must cover the read.  hipcc inserts these
+    waits for the loads it knows; the transposed V-fragment reads of the 64-per-wave forward (ds_read_b64_tr_b16) and a few others are asm statements, and the paired,
+    counted waits of the hand-placed steps are then the only thing between an MFMA and a register LDS has not written yet.
+    Model: cnt = an upper bound of the hardware counter (+1 per LDS / scalar-memory / flat instruction, min(cnt, N) at a wait); LDS operations return in order, so
+    the read with sequence number q among n issued is certainly back once n - q >= cnt (scalar and flat loads share the counter and return out of order: they can only
+    take slots away from LDS operations, the bound stays valid).  Walks the fall-through order and, like scan(), carries the state over every branch to its target.
+    -> [(function, reads possibly in flight, 0, the read, the use)]"""
+    found, seen = [], set()
+
+    def step(func, ins, i, st):
+        cnt, n_lds, pending = st
+        op, rest, _ = ins[i]
+        line = f"{op} {rest}"
+        if op.startswith("s_waitcnt"):
+            m = re.search(r"lgkmcnt\((\d+)\)", rest)
+            if m:
+                cnt = min(cnt, int(m.group(1)))
+            elif re.match(r"^(0x[0-9a-fA-F]+|\d+)$", rest.strip()):
+                cnt = min(cnt, (int(rest.strip(), 0) >> 8) & 0xF)
+            pending = [p for p in pending if n_lds - p[0] < cnt]
+            return [cnt, n_lds, pending]
+        touched = regs_of(rest) if not op.startswith("s_") else set()
+        keep = []
+        for pnd in pending:
+            if pnd[1] & touched:
+                if (pnd[3], i) not in seen:
+                    seen.add((pnd[3], i)); found.append((func, min(cnt, n_lds - pnd[0] + 1), 0, pnd[2], line))
+                continue
+            keep.append(pnd)
+        pending = keep
+        if op.startswith("ds_"):
+            n_lds += 1; cnt += 1
+            first = rest.split(",")[0]
+            if re.match(r"^\s*v", first) and any(k in op for k in ("read", "load", "permute", "swizzle", "consume", "append")) :
+                pending = pending + [[n_lds, regs_of(first), line, i]]
+        elif op.startswith(("s_load", "s_buffer_load", "s_scratch_load", "flat_")):
+            cnt += 1
+        return [cnt, n_lds, pending]
+
+    def side_walk(func, ins, i, st, depth, budget=600):
+        while st[2] and i < len(ins) and budget > 0:
+            op, _, tgt = ins[i]
+            st = step(func, ins, i, st)
+            if op.startswith(("s_branch", "s_cbranch")) and tgt is not None and depth < 2 and st[2]:
+                side_walk(func, ins, tgt, [st[0], st[1], [list(p) for p in st[2]]], depth + 1, budget)
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                return
+            i += 1; budget -= 1
+
+    for func, ins in parse(text):
+        st = [0, 0, []]
+        for i, (op, _, tgt) in enumerate(ins):
+            st = step(func, ins, i, st)
+            if op.startswith(("s_branch", "s_cbranch")) and tgt is not None and st[2]:
+                side_walk(func, ins, tgt, [st[0], st[1], [list(p) for p in st[2]]], 1)
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                st = [st[0], st[1], []]
+    return found
+
+
 def main(argv):
     files = argv or sorted(glob.glob(os.path.join(ROOT, "flash-attention_amd", "csrc", "*.o")))
     bad = 0
@@ -249,9 +312,10 @@ def main(argv):
         else:
             text = open(f).read()
         n_mfma = len(re.findall(r"\bv_mfma", text))
-        hits, ops, pairs = scan(text), scan_operands(text), scan_valu_pairs(text) + scan_sgpr_vmem(text)
-        print(f"{os.path.basename(f)}: {n_mfma} MFMAs, {len(hits)} result registers touched early, {len(ops)} operands written late, {len(pairs)} swap / transcendental / scalar-operand pairs too close")
-        ops = ops + pairs
+        hits, ops, pairs, lds = scan(text), scan_operands(text), scan_valu_pairs(text) + scan_sgpr_vmem(text), scan_lds_waits(text)
+        print(f"{os.path.basename(f)}: {n_mfma} MFMAs, {len(hits)} result registers touched early, {len(ops)} operands written late, {len(pairs)} swap / transcendental / scalar-operand pairs too close, "
+              f"{len(lds)} LDS reads used before their wait")
+        ops = ops + pairs + lds
         for func, ws, need, first, second in hits + ops:
             print(f"    {func[:70]}: {ws} of {need} wait states\n        {first}\n        {second}")
         bad += len(hits) + len(ops)
