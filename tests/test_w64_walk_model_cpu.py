@@ -15,8 +15,10 @@ def acc_row(r, hi):   # fa_device.h: row of accumulator element r in the 32x32 M
     return (r & 3) + 8 * (r >> 2) + 4 * hi
 
 
-def walk_counts(sq, sk, wl, wr, desc):
-    """Times each (query, key) pair is scored as visible; keys are offset by PAD so that keys < 0 and >= sk have a slot."""
+def walk_counts(sq, sk, wl, wr, desc, peel=False):
+    """Times each (query, key) pair is scored as visible; keys are offset by PAD so that keys < 0 and >= sk have a slot.
+    peel (round 5, plain attention, ascending): the wave's LAST iteration issues no score chain at all (fast_step MODE 3 / 4) and its FIRST one no P.V -- the
+    model then scores nothing in iteration u_last and checks that the two are different iterations."""
     PAD = 2 * BN
     cnt = np.zeros((sq, sk + 2 * PAD), dtype=np.int32)
     shift = sk - sq
@@ -57,7 +59,11 @@ def walk_counts(sq, sk, wl, wr, desc):
                 p_lo, p_hi = max(u_first, n_tiles - 1 - ph_t), min(u_last, n_tiles - 1 - pl_t)
             if p_hi < p_lo:
                 p_lo, p_hi = u_last + 1, u_last
+            if peel:
+                assert not desc and u_last > (u_first & ~1), (u_first, u_last)   # the peeled first and last iteration are two iterations
             for u in range(u_first & ~1, u_last + 1):
+                if peel and u == u_last:
+                    continue   # (no score chain in the last iteration: whatever it would have scored must have been invisible)
                 masked = not (p_lo <= u <= p_hi)
                 for i_step in (2 * u, 2 * u + 1):
                     k0m = step_key(i_step)
@@ -98,6 +104,8 @@ SHAPES = [(256, 256), (300, 300), (64, 200), (257, 513), (512, 384), (70, 70), (
 def test_ascending_walk_scores_each_visible_pair_once(sq, sk, wl, wr):
     cnt, pad = walk_counts(sq, sk, wl, wr, desc=False)
     assert np.array_equal(cnt, visible(sq, sk, wl, wr, pad))
+    cnt, pad = walk_counts(sq, sk, wl, wr, desc=False, peel=True)   # ... and with the last iteration's chains not issued (round 5)
+    assert np.array_equal(cnt, visible(sq, sk, wl, wr, pad))
 
 
 @pytest.mark.parametrize("sq,sk", SHAPES)
@@ -118,5 +126,7 @@ def test_random_shapes_and_windows_both_directions():
         wr = int(rng.choice([-1, 0, 1, 31, 64, 200]))
         cnt, pad = walk_counts(sq, sk, wl, wr, desc=False)
         assert np.array_equal(cnt, visible(sq, sk, wl, wr, pad)), (sq, sk, wl, wr, "ascending")
+        cnt, pad = walk_counts(sq, sk, wl, wr, desc=False, peel=True)
+        assert np.array_equal(cnt, visible(sq, sk, wl, wr, pad)), (sq, sk, wl, wr, "ascending, peeled")
         cnt, pad = walk_counts(sq, sk, wl, 0, desc=True)
         assert np.array_equal(cnt, visible(sq, sk, wl, 0, pad)), (sq, sk, wl, 0, "descending")
