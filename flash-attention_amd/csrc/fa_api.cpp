@@ -166,7 +166,8 @@ int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
   //   keys per query block on average, as long as its 256-row blocks still fill the chip (>= 200 of them; key loops of >= 32 tiles
   //   -- non-causal S >= 2048, causal S >= 4096, config 3 included -- take it regardless).  With round 3's per-block costs (one
   //   iteration body, 7k-clock prologue) it beats the 4-wave pipelined kernel by 7 % at S = 1024, 14-21 % at S = 2048 and 19-23 %
-  //   from S = 4096 (1.20-1.24 vs 1.01-1.03 PFLOP/s non-causal); at S = 512 the two tie.  Shorter loops and small grids stay on the
+  //   from S = 4096 (1.20-1.24 vs 1.01-1.03 PFLOP/s non-causal); at S = 512 the two tied until round 5 peeled a wave's first and last
+  //   iteration (fixed-length batches under a right bound now take it from 4 visible tiles on average, see below).  Shorter loops and small grids stay on the
   //   4-wave pipelined kernel (Q fragments in registers, two 128-row workgroups per CU hide each other's prologue / epilogue).
   //   FA_STRICT keeps the pipelined kernels (fp32 scaling of every score).  D = 64 has half the MFMA work per softmax element: the
   //   64-rows-per-wave kernel wins from 32 key tiles on average without a right bound (S >= 2048: +1 %, S >= 4096: +12-16 %) and from
