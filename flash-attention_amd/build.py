@@ -59,7 +59,7 @@ def build_lib(force=False):
     # helpers in fa_w64_asm.h), hence -fno-slp-vectorize there.
     units = [("fa_fwd.hip", "fa_fwd_bf16.o", ["-DFA_FWD_PART=1"]), ("fa_fwd.hip", "fa_fwd_f16.o", ["-DFA_FWD_PART=2"]), ("fa_fwd_il.hip", "fa_fwd_il.o", []), ("fa_fwd_w64.hip", "fa_fwd_w64_bf16.o", ["-fno-slp-vectorize", "-DFA_W64_PART=1"]), ("fa_fwd_w64.hip", "fa_fwd_w64_f16.o", ["-fno-slp-vectorize", "-DFA_W64_PART=2"]),
              ("fa_bwd.hip", "fa_bwd_dkdv.o", ["-DFA_BWD_PART=1"]), ("fa_bwd.hip", "fa_bwd_dq.o", ["-DFA_BWD_PART=2"]), ("fa_bwd.hip", "fa_bwd_fused.o", ["-DFA_BWD_PART=3"]),
-             ("fa_bwd_w64.hip", "fa_bwd_w64.o", ["-fno-slp-vectorize"]), ("fa_bwd_dkdv_w64.hip", "fa_bwd_dkdv_w64.o", ["-fno-slp-vectorize"]),
+             ("fa_bwd_w64.hip", "fa_bwd_w64.o", ["-fno-slp-vectorize"]), ("fa_bwd_dkdv_w64.hip", "fa_bwd_dkdv_w64.o", ["-fno-slp-vectorize", "-DFA_DKDV64_PART=1"]), ("fa_bwd_dkdv_w64.hip", "fa_bwd_c5.o", ["-fno-slp-vectorize", "-DFA_DKDV64_PART=2"]),
              ("fa_api.cpp", "fa_api.o", [])]
     hdrs += _sources(["fa_w64_asm.h", "fa_fwd_w64_regs.h"])
     objs, cmds = [], []

@@ -16,6 +16,7 @@
 #include <cstring>
 
 #include "../../include/fa_gfx950.h"
+#include "fa_device.h"
 #include "fa_kernel_params.h"
 #include "fa_launch.h"
 
@@ -51,6 +52,8 @@ const fa::Knobs* read_knobs() {
   k->bwd_mode = env_int("FA_BWD_MODE", 0);
   k->bwd_dkdv = env_int("FA_BWD_DKDV", 0);
   k->bwd_ds_cap_mb = env_int("FA_BWD_DS_CAP_MB", 8192);
+  k->bwd_c5_mix = env_int("FA_BWD_C5_MIX", 1);
+  k->bwd_c5_cap_mb = std::max(16, std::min(65536, env_int("FA_BWD_C5_CAP_MB", 1024)));
   k->fz_line = std::max(1, std::min(64, env_int("FA_FZ_LINE", 32)));
   k->w64_persist = env_int("FA_W64_PERSIST", 1);
   k->strict = env_int("FA_STRICT", 0);
@@ -484,6 +487,46 @@ int64_t bwd_fused_sync_bytes(const FaBwdParams* a) {
   return fa::fz_sync_words((int64_t)a->b * a->h * ((a->seqlen_q + 255) / 256), fa::knobs().fz_line) * 4;
 }
 
+// ---- 5-contraction backward (round 6; reference: ONE pass forms S, dP and dS and all three gradients follow from it, csrc/flash_attn/src/flash_bwd_kernel.h:457-733) ----
+// The 64-keys-per-wave dK/dV items write dS (input dtype) to a workspace, dQ = dS.K is one contraction instead of the recomputing dQ kernel's three.  The workspace is
+// bounded: the (batch, kv head) units are cut into chunks of whole XCD rounds (8 units), launch c runs the dK/dV items of chunk c and the dQ items of chunk c - 1
+// in one grid (stream order is the hand-off, nothing spins), two slots alternate.  Rows of a slot are packed (fa_device.h ds_row_start): a causal mask stores its triangle only.
+struct C5Plan {
+  int hpx, rounds, rounds_per_chunk, n_chunks;
+  int nq32, nk32, np64, c1, jb, head_tiles, nmb, nnb;
+  int64_t slot_bytes;
+};
+bool bwd_c5_plan(const FaBwdParams* a, C5Plan& pl) {
+  const int mode = fa::knobs().bwd_mode;
+  if (mode != 0 && mode != 5) return false;
+  if (a->cu_seqlens_q || a->cu_seqlens_k || a->seqused_q || a->seqused_k || (a->d != 128 && a->d != 64)) return false;
+  if (a->softcap > 0.f || a->alibi_slopes || a->p_dropout > 0.f || a->seqlen_q <= 0 || a->seqlen_k < a->seqlen_q || a->b <= 0) return false;
+  if (fa::knobs().bwd_dkdv == 8 || fa::knobs().dkdv_prescale) return false;   // (knobs that name the eight-wave dK/dV kernel)
+  int causal = a->is_causal, wl = a->window_left, wr = a->window_right;
+  normalize_window(a->seqlen_q, a->seqlen_k, false, causal, wl, wr);
+  if (wl >= 0) return false;
+  pl.nq32 = (a->seqlen_q + 31) / 32; pl.nk32 = (a->seqlen_k + 31) / 32;
+  pl.nmb = (a->seqlen_q + 255) / 256; pl.nnb = (a->seqlen_k + 255) / 256;
+  // rows of 64-key pairs (fa_device.h ds_row_start): a - 1 = key sub-tiles row block 0 sees (keys <= 31 + (sk - sq) + wr)
+  pl.np64 = (a->seqlen_k + 63) / 64;
+  pl.c1 = wr >= 0 ? (int)std::min<int64_t>(2 * pl.np64, ((int64_t)31 + (a->seqlen_k - a->seqlen_q) + wr) / 32 + 2) : 2 * pl.np64;
+  pl.jb = std::max(0, 2 * pl.np64 - pl.c1);
+  pl.head_tiles = fa::ds_row_start(pl.nq32, pl.c1, pl.jb, pl.np64);
+  const int n_units = a->b * a->h_k, ratio = a->h / a->h_k;
+  pl.hpx = (a->h_k % 8 == 0) ? a->h_k / 8 : 0;
+  pl.rounds = (n_units + 7) / 8;
+  const int64_t round_bytes = (int64_t)8 * ratio * pl.head_tiles * 2048;
+  const int64_t slot_cap = ((int64_t)fa::knobs().bwd_c5_cap_mb << 20) / 2;
+  if (round_bytes > slot_cap || round_bytes >= ((int64_t)1 << 32)) return false;
+  int rpc = (int)std::min<int64_t>(pl.rounds, slot_cap / round_bytes);
+  while ((int64_t)rpc * round_bytes >= ((int64_t)1 << 32)) --rpc;   // (32-bit buffer offsets inside a slot)
+  pl.n_chunks = (pl.rounds + rpc - 1) / rpc;
+  pl.rounds_per_chunk = (pl.rounds + pl.n_chunks - 1) / pl.n_chunks;   // balanced
+  pl.slot_bytes = ((int64_t)pl.rounds_per_chunk * round_bytes + 255) & ~(int64_t)255;
+  if (mode == 5) return true;
+  return false;   // (the measured table goes here)
+}
+
 // the dK/dV launch of either schedule (-2 from the 64-keys-per-wave launcher = not covered after all: nothing was enqueued)
 int launch_dkdv_any(const FaBwdParams* a, const fa::BwdK& k, int bf, int dk_, hipStream_t s) {
   int rc = -2, nw = 64;
@@ -497,6 +540,33 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
   fa::BwdK k;
   if (int rc = fill_bwd(a, varlen, k)) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (C5Plan pl; !varlen && a->total_q != 0 && bwd_c5_plan(a, pl) && a->workspace && a->workspace_bytes >= 2 * pl.slot_bytes) {
+    // delta pre-pass, then n_chunks + 1 mixed launches
+    const int bf = a->dtype == FA_DTYPE_BF16;
+    k.nmb = pl.nmb; k.nnb = pl.nnb;
+    k.k_units = a->b * a->h_k; k.k_unit_size = pl.nnb; k.k_unit_hpx = pl.hpx;
+    k.ds_nq32 = pl.nq32; k.ds_nk32 = pl.np64; k.ds_c1 = pl.c1; k.ds_jb = pl.jb; k.ds_head_tiles = pl.head_tiles;
+    k.c5_slot_bytes = (uint32_t)pl.slot_bytes;
+    int rc = fa::launch_bwd_delta(k, bf, a->d, s);
+    for (int c = 0; rc == 0 && c <= pl.n_chunks; ++c) {
+      const int pj0 = c * pl.rounds_per_chunk, pj1 = std::min(pl.rounds, pj0 + pl.rounds_per_chunk);
+      const int cj0 = (c - 1) * pl.rounds_per_chunk, cj1 = std::min(pl.rounds, cj0 + pl.rounds_per_chunk);
+      k.ds_ws = (char*)a->workspace + (int64_t)(c & 1) * pl.slot_bytes;
+      k.ds_rd = (const char*)a->workspace + (int64_t)((c + 1) & 1) * pl.slot_bytes;
+      k.c5_np = c < pl.n_chunks ? 8 * (pj1 - pj0) * pl.nnb : 0;
+      k.c5_nc = c >= 1 ? 8 * (cj1 - cj0) * (a->h / a->h_k) * pl.nmb : 0;
+      k.c5_pbid0 = 8 * pj0 * pl.nnb; k.c5_pj0 = pj0; k.c5_cj0 = cj0;
+      k.c5_mix = std::max(1, fa::knobs().bwd_c5_mix);
+      rc = fa::launch_bwd_c5(k, bf, a->d, s);
+    }
+    if (rc == 0) {
+      fa::LastSchedule& ls = fa::last_schedule();
+      ls.bwd_dkdv_nw = 64; ls.bwd_dq_nw = 64; ls.bwd_spill = 5; ls.bwd_list = 0;
+      return FA_OK;
+    }
+    if (rc != -2) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (int rc2 = fill_bwd(a, varlen, k)) return rc2;   // does not apply after all (nothing was enqueued but the delta pre-pass): the default path, from a clean parameter block
+  }
   if (const int64_t fz = varlen ? 0 : bwd_fused_ds_bytes(a); fz > 0 && a->workspace && a->workspace_bytes >= fz + bwd_fused_sync_bytes(a) && a->total_q != 0) {
     // delta pre-pass, then ONE launch: dK / dV and dQ = dS.K
     k.ds_ws = a->workspace;
@@ -686,6 +756,7 @@ int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {
   int64_t qe, ke;
   bwd_list_entries(params, qe, ke);
   if (const int64_t fz = bwd_fused_ds_bytes(params); fz > 0) return fz + bwd_fused_sync_bytes(params);
+  if (C5Plan pl; bwd_c5_plan(params, pl)) return 2 * pl.slot_bytes;
   return (qe ? (qe + 1) * 8 : 0) + (ke ? (ke + 1) * 8 : 0);   // (work lists: varlen only)
 }
 int fa_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, false); }

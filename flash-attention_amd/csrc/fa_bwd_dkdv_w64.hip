@@ -29,6 +29,25 @@
 // one-wait-per-MFMA variant live in experiments/ablations/fa_bwd_dkdv_w64.patch (tools/ablate_dkdv64.sh).
 #define FA_DKDV64_AHJ 6     // phase A: row-fragment reads run this many fragments (= MFMA gaps) ahead of their first MFMA
 #define FA_DKDV64_AHT 3     // phase B: transposed-fragment reads run this many fragments (two gaps each) ahead
+#ifndef FA_DS_ST_MOD
+#define FA_DS_ST_MOD ""     // cache-policy bits of the dS stores (A/B builds: " nt", " sc1", " sc0 sc1")
+#endif
+#ifndef FA_C5_ABL_NOSTORE
+#define FA_C5_ABL_NOSTORE 0
+#endif
+#ifndef FA_C5_ABL_VMCNT
+#define FA_C5_ABL_VMCNT 0
+#endif
+#ifndef FA_C5_ABL_SAMEADDR
+#define FA_C5_ABL_SAMEADDR 0
+#endif
+#ifndef FA_DS_LD_MOD
+#define FA_DS_LD_MOD ""     // ... and of the dQ part's dS loads
+#endif
+
+#ifndef FA_DKDV64_PART
+#define FA_DKDV64_PART 0    // build.py compiles this file twice side by side: 1 = the dK/dV kernels, 2 = the 5-contraction backward's mixed kernel; 0 = everything
+#endif
 
 namespace fa {
 namespace {
@@ -72,10 +91,16 @@ template <typename E, int T> FA_DEVINL void kv_mfma_tile(u32x4 a, u32x4 b) {
 // start from C = 0, the tile stream stores c - LSE*log2e (c = softcap*log2e) per row instead of -LSE/scale, and phase B reads those rows four at a time one group of
 // elements ahead.  With y = score * scale/softcap * 2*log2e and r = 1/(2^y + 1): P = 2^(c - LSE*log2e - 2c*r), 1 - tanh^2 = 4*(r - r^2) -- twelve vector instructions
 // per element instead of five, in three stages a gap apart; the 4 meets softmax_scale in dK's epilogue.
-template <typename E, int D, int FEAT>
-__global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
+//
+// DS (round 6, the 5-contraction backward, fa_bwd_c5_kernel below): the wave also hands every dS sub-tile it forms (32 queries x 32 keys, rounded to the input dtype as it
+// enters the dK contraction) to the workspace BwdK::ds_ws in the image fa_device.h ds_slot describes -- four 16-byte stores per lane and step, issued in phase A's gaps of
+// the step AFTER the one that formed them (their registers are rewritten only by that step's phase B), through a buffer descriptor whose range is zero for a step without
+// a previous tile: no branch in the step.  `bid` = the workgroup's number in the dK/dV grid (the mixed launch passes its own).
+template <typename E, int D, int FEAT, bool DS>
+static __device__ __forceinline__ void dkdv_w64_body(const BwdK p, const int bid) {   // (p by value: through a reference hipcc no longer proves the descriptor words and tile offsets uniform -- asm "s" operands arrive in vector registers)
   constexpr bool ALIBI = FEAT == FEAT_ALIBI, CAP = FEAT == FEAT_CAP;
   static_assert(FEAT == 0 || ALIBI || CAP, "feature variants of this schedule: none, causal ALiBi, softcap");
+  static_assert(!DS || FEAT == 0, "the dS hand-over: plain attention");
   using T = ElemTraits<E>;
   using V8 = typename T::v8;
   constexpr int NW = 4, KB = 2, BNK = NW * 64, TQ = 32;
@@ -105,9 +130,9 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
 
   int b, hk, n_block;
   if (p.k_list) {  // varlen: non-empty key blocks only, heaviest first
-    if (!work_list_item(p.k_list, blockIdx.x, p.h_k, p.h_k, b, hk, n_block)) return;
+    if (!work_list_item(p.k_list, bid, p.h_k, p.h_k, b, hk, n_block)) return;
   } else {
-    const int w = xcd_interleave(blockIdx.x, p.k_units, p.k_unit_size, p.k_unit_hpx);
+    const int w = xcd_interleave(bid, p.k_units, p.k_unit_size, p.k_unit_hpx);
     if (w < 0) return;
     const int bhk = w / p.nnb;
     n_block = w - bhk * p.nnb;
@@ -288,6 +313,20 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   const int aux_lane = OFF_AUX + 16 * hi;   // rows 4*hi .. of a group of eight
   const int kx_lane = OFF_KX + wave * KL * 1024 + lane * 16;
   auto opaque = [](int x) __attribute__((always_inline)) { asm volatile("" : "+v"(x)); return x; };
+  // (DS) the hand-over: descriptor of this launch's dS slot, this lane's 16-byte slot inside a half image, and the sub-tile index (2 KB each) of this wave's first
+  // key sub-tile in row 0 of the group's first query head.  Sub-tile (head g of the group, query row block i, key block k) lives at
+  // ds_unit0 + g * ds_head_tiles + ds_row_start(i) + k (fa_device.h): rows are packed -- under a right-bounded mask row i holds only the key blocks it can see.
+  u32x4 ds_srd = {0u, 0u, 0u, 0x00020000u};
+  unsigned ds_voff = 0u, ds_unit0 = 0u, ds_prev_off = 0u;
+  if constexpr (DS) {
+    const unsigned long long a = (unsigned long long)p.ds_ws;
+    ds_srd[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    ds_srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu;
+    ds_srd[2] = __builtin_amdgcn_readfirstlane(p.c5_slot_bytes);
+    ds_voff = (unsigned)ds_slot(ki, hi) * 16u;
+    const int xcd = bid & 7, jr = (bid >> 3) / p.k_unit_size - p.c5_pj0;
+    ds_unit0 = __builtin_amdgcn_readfirstlane((unsigned)((jr * 8 + xcd) * p.hk_ratio) * (unsigned)p.ds_head_tiles + (unsigned)(wk0 >> 5));
+  }
 
   // dV^T / dK^T tiles: dV (kb, db) = tile kb*DB + db, dK (kb, db) = tile 2*DB + kb*DB + db; zeroed by the matrix pipe
   {
@@ -570,7 +609,7 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   // ---- the step loop ----------------------------------------------------------------------------------------------------------------
   // Control block of a step: everything scalar it needs, made DURING the step before it (inside phase A's gaps, where the scalar ALU idles): the first version
   // made it at the step's head -- ~90 instructions and a dozen branches per 64 MFMAs with nothing to hide behind (profiles/r05_bwd_dkdv_w64.txt).
-  struct Ctl { bool act, msk; int slot_a, slot_b, slot2, q0, hq; Strm z; };
+  struct Ctl { bool act, msk; int slot_a, slot_b, slot2, q0, hq; unsigned ds_off; Strm z; };
   int c_mt = mt_first, c_left = __builtin_amdgcn_readfirstlane(nm), c_h = 0;   // tile st of the walk: tile index, tiles left in its head, head of the group
   bool act_prev = false;
   auto make_ctl = [&](int st) __attribute__((always_inline)) {   // for step st, from the counters as they stand (compute tile st, stream tile st + 2)
@@ -583,6 +622,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     c.slot_b = act_prev ? ((st - 1) & 3) : c.slot_a;
     c.q0 = c_mt * TQ;
     c.hq = c_h;
+    c.ds_off = 0u;
+    if constexpr (DS) c.ds_off = (ds_unit0 + (unsigned)c_h * (unsigned)p.ds_head_tiles + (unsigned)ds_row_start(c_mt, p.ds_c1, p.ds_jb, p.ds_nk32)) << 11;
     c.z = stream_prep(c.slot2);
     return c;
   };
@@ -592,13 +633,25 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     const bool wrap = c_left == 1;
     c_mt = wrap ? mt_first : c_mt + mt_dir;
     c_left = wrap ? nm : c_left - 1;
-    if constexpr (ALIBI) c_h = wrap ? c_h + 1 : c_h;
+    if constexpr (ALIBI || DS) c_h = wrap ? c_h + 1 : c_h;
     stream_advance();
     nxt = make_ctl(st + 1);
   };
   preload_a(0, 0);
+  auto ds_store_piece = [&](auto ic, const u32x4& srd, unsigned soff) __attribute__((always_inline)) {   // (DS) fragment (key block i >> 1, query half i & 1) of the previous tile's dS
+    constexpr int i = decltype(ic)::value;
+    const u32x4 x = dn[i >> 1][i & 1];
+    const unsigned vo = ds_voff;   // (copies: clang does not capture a variable a generic lambda names only as an asm operand)
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%c4" FA_DS_ST_MOD : : "v"(x), "v"(vo), "s"(srd), "s"(soff), "i"((i >> 1) * 2048 + (i & 1) * 1024) : "memory");
+  };
   auto step = [&](int st) __attribute__((always_inline)) {
     const Ctl c = nxt;
+    // (DS) the dS of the PREVIOUS tile -- still in dn: this step's phase B rewrites it -- leaves in four stores; a step without a previous tile stores through a
+    // descriptor of range zero (dropped by the hardware)
+    u32x4 st_srd = ds_srd;
+    const unsigned st_off = FA_C5_ABL_SAMEADDR == 1 ? (unsigned)(wave * 4096) : FA_C5_ABL_SAMEADDR > 1 ? (ds_prev_off & (unsigned)(FA_C5_ABL_SAMEADDR - 1)) : ds_prev_off;
+    if constexpr (DS) { if (c.slot_b == c.slot_a || FA_C5_ABL_NOSTORE) st_srd[2] = 0u; ds_prev_off = c.ds_off; }
+    auto ds_store = [&](auto ic) __attribute__((always_inline)) { ds_store_piece(ic, st_srd, st_off); };
     stream_aux(c.z);
     advance(c, st);   // (at the step's head: inside phase A's gaps the ~70 scalar instructions cost more than here -- 1994 -> 2329 us, profiles/r05_bwd_dkdv_w64.txt)
     if (__builtin_expect(c.act, 1)) {
@@ -606,9 +659,11 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
         constexpr int g = decltype(gc)::value;
         if constexpr (g == 1) stream_dma_q(c.z);
         if constexpr (g == 3) stream_dma_d(c.z);
+        if constexpr (DS && g >= 5 && g <= 11 && (g & 1) == 1) ds_store(ICw<(g - 5) / 2>{});
       });
     } else {
       stream_dma_q(c.z); stream_dma_d(c.z);
+      if constexpr (DS) static_for<4>(ds_store);
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -637,7 +692,8 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
     }
     preload_a((st + 1) & 3, nxt.hq);   // (tile st + 1 was published by the previous barrier.  Unconditional: a conditional definition keeps the 96 registers of
                                // S / dP / the fragment rings alive across phase B in hipcc's eyes; past the last tile it reads a stale slot nobody uses)
-    lds_dma_wait_all();        // tile st + 2 has landed (requested in this step's first gaps)
+    if constexpr (DS && FA_C5_ABL_VMCNT > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FA_C5_ABL_VMCNT) : "memory");
+    else lds_dma_wait_all();        // tile st + 2 has landed (requested in this step's first gaps)
     stream_store_aux(c.slot2);
     __syncthreads();
   };
@@ -663,6 +719,264 @@ __global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
   });
 }
 
+#if FA_DKDV64_PART != 2
+template <typename E, int D, int FEAT>
+__global__ void __launch_bounds__(256, 1) fa_bwd_dkdv_w64_kernel(const BwdK p) {
+  dkdv_w64_body<E, D, FEAT, false>(p, blockIdx.x);
+}
+#endif
+
+#if FA_DKDV64_PART != 1
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// dQ = dS . K from the dS the dK/dV items handed over: the fifth contraction of the 5-contraction backward (reference: the dQ accumulation of
+// compute_dq_dk_dv_1colblock, csrc/flash_attn/src/flash_bwd_kernel.h:682-724, which reads dS back transposed from shared memory the same way).
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// One item = one 256-row query block of one head: 4 waves x 64 rows (two 32-row blocks per wave, so that every K^T fragment feeds two MFMAs),
+//   dQ^T[d][query] += K^T[d][key] . dS^T[key][query]      A = K^T (ds_read_b64_tr_b16 of the K tile), B = dS^T (ds_read_b64_tr_b16 of the writer's image)
+// over 64-key tiles in a ring of three LDS slots (K tile + each wave's four sub-tile images, all by LDS-DMA).  No softmax, no mask arithmetic: a sub-tile either
+// was written (fa_device.h ds_tile_active) and is multiplied, or is skipped.  Bound: LDS -- 48 transposed reads per 32 MFMAs and wave, 96 KB read + 48 KB
+// written per tile and workgroup.
+template <typename E, int D>
+static __device__ __forceinline__ void dq_ds_w64_body(const BwdK p, const int cbid) {
+  using T = ElemTraits<E>;
+  using V8 = typename T::v8;
+  constexpr int NW = 4, QB = 2, BM = NW * 64, BN = 64, CPR = D / 8;
+  constexpr int ROW_BYTES = D * 2, TILE_K = BN * ROW_BYTES, DB = D / 32;
+  constexpr int DS_WAVE = QB * 2 * 2048;            // a wave's four sub-tile images of a tile: [query block][key sub-tile][query half][1 KiB]
+  constexpr int SLOT = TILE_K + NW * DS_WAVE, RING = 3;
+  constexpr int RPD = 1024 / ROW_BYTES, DPW = TILE_K / 1024 / NW;   // K: rows per 1-KiB DMA piece, pieces per wave
+  static_assert(DPW == 4 || DPW == 2, "K pieces per wave");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char FA_LDS* lds = (char FA_LDS*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+
+  // item -> (unit, head of the group, query block): the rounds of eight units the dK/dV items were dealt in, heaviest query block first under a right-bounded mask
+  const int xcd = cbid & 7, slot_i = cbid >> 3;
+  const int per_unit = p.hk_ratio * p.nmb;
+  const int jr = slot_i / per_unit, within = slot_i - jr * per_unit;
+  const int hg = within / p.nmb, mbr = within - hg * p.nmb;
+  const int j = p.c5_cj0 + jr;
+  int unit;
+  if (p.k_unit_hpx > 0) { const int bb = j / p.k_unit_hpx; unit = bb * (8 * p.k_unit_hpx) + xcd * p.k_unit_hpx + (j - bb * p.k_unit_hpx); }
+  else unit = xcd + 8 * j;
+  if (unit >= p.k_units) return;
+  const int b = unit / p.h_k, hk = unit - b * p.h_k;
+  const int h = hk * p.hk_ratio + hg;
+  const int m_block = (p.wr >= 0) ? (p.nmb - 1 - mbr) : mbr;
+  const int sq = p.sq, sk = p.sk, shift = sk - sq;
+  const int m0 = m_block * BM;
+  if (m0 >= sq) return;
+  const int blk_last = min(m0 + BM, sq) - 1;
+  const int kmax = (p.wr >= 0) ? min(sk - 1, blk_last + shift + p.wr) : sk - 1;
+  const int n_max = kmax >= 0 ? kmax / BN + 1 : 0;   // tiles 0 .. n_max - 1 (no left window on this path)
+  const int w_row0 = m0 + wave * 64;
+
+  // ---- sources: K rows through a descriptor of the (batch, kv head)'s rows (rows past the last key read as zeros), the dS images through one of the slot
+  const E* __restrict__ kp = (const E*)p.k + (int64_t)b * p.k_bs + (int64_t)hk * p.k_hs;
+  auto make_srd = [&](const void* base, unsigned long long bytes) __attribute__((always_inline)) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 sd = {(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) & 0xffffu,
+                (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bytes > 0xffffffffull ? 0xffffffffull : bytes)), 0x00020000u};
+    return sd;
+  };
+  const u32x4 k_srd = make_srd(kp, ((unsigned long long)(sk - 1) * (unsigned long long)p.k_rs + D) * 2ull);
+  const u32x4 ds_srd = make_srd(p.ds_rd, p.c5_slot_bytes);
+  unsigned koff_l[DPW];
+  {
+    const int d_row = lane / CPR, d_pc = lane % CPR;
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int row = (wave * DPW + i) * RPD + d_row;
+      const int c = d_pc ^ swz16<D>(row);
+      koff_l[i] = (unsigned)(row * (int)p.k_rs + c * 8) * 2u - (unsigned)(i * 1024);
+    }
+  }
+  // this wave's two query row blocks: byte offset of their packed rows in the slot (+ the lane's 16 bytes of a 1-KiB piece); a row block past the last row has no image
+  unsigned ds_voff[QB];
+  {
+    const unsigned head0 = (unsigned)((jr * 8 + xcd) * p.hk_ratio + hg) * (unsigned)p.ds_head_tiles;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const int q32 = min((w_row0 >> 5) + qb, p.ds_nq32 - 1);
+      ds_voff[qb] = ((head0 + (unsigned)ds_row_start(q32, p.ds_c1, p.ds_jb, p.ds_nk32)) << 11) + (unsigned)lane * 16u;
+    }
+  }
+  auto load_tile = [&](int n, int st) __attribute__((always_inline)) {
+    const unsigned kdst = __builtin_amdgcn_readfirstlane((unsigned)(st * SLOT + wave * DPW * 1024));
+    const unsigned ktoff = __builtin_amdgcn_readfirstlane((unsigned)n * (unsigned)(BN * 2) * (unsigned)p.k_rs);
+    unsigned keep;
+    if constexpr (DPW == 4)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                   "buffer_load_dwordx4 %1, %6, %7 offen lds\n\t"
+                   "buffer_load_dwordx4 %2, %6, %7 offen offset:1024 lds\n\t"
+                   "buffer_load_dwordx4 %3, %6, %7 offen offset:2048 lds\n\t"
+                   "buffer_load_dwordx4 %4, %6, %7 offen offset:3072 lds\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(koff_l[0]), "v"(koff_l[1]), "v"(koff_l[DPW - 2]), "v"(koff_l[DPW - 1]), "s"(kdst), "s"(k_srd), "s"(ktoff) : "memory");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                   "buffer_load_dwordx4 %1, %4, %5 offen lds\n\t"
+                   "buffer_load_dwordx4 %2, %4, %5 offen offset:1024 lds\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(koff_l[0]), "v"(koff_l[DPW - 1]), "s"(kdst), "s"(k_srd), "s"(ktoff) : "memory");
+    const unsigned dtoff = __builtin_amdgcn_readfirstlane((unsigned)n * 4096u);   // key sub-tiles 2n, 2n + 1 of the row
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const unsigned ddst = __builtin_amdgcn_readfirstlane((unsigned)(st * SLOT + TILE_K + wave * DS_WAVE + qb * 4096));
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "buffer_load_dwordx4 %1, %3, %4 offen lds" FA_DS_LD_MOD "\n\t"
+                   "buffer_load_dwordx4 %1, %3, %4 offen offset:1024 lds" FA_DS_LD_MOD "\n\t"
+                   "buffer_load_dwordx4 %1, %3, %4 offen offset:2048 lds" FA_DS_LD_MOD "\n\t"
+                   "buffer_load_dwordx4 %1, %3, %4 offen offset:3072 lds" FA_DS_LD_MOD "\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(ds_voff[qb]), "s"(ddst), "s"(ds_srd), "s"(dtoff) : "memory");
+    }
+  };
+  constexpr int PER_TILE = DPW + 4 * QB;   // DMA instructions per wave and tile: the same for every wave and tile, so "tile n has landed" is a literal vmcnt
+  auto wait_tile = [&](bool next_in_flight) __attribute__((always_inline)) {
+    if (next_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  // ---- per-lane LDS read offsets: transposed K fragments (fa_bwd_w64.hip), transposed dS fragments (fa_bwd.hip fa_bwd_dq_from_ds: reader half hi takes keys 4*hi .. + 3 and 8 + 4*hi ..)
+  const int tr_i = lane & 15, tr_half = (lane >> 4) & 1, tr_rr = tr_i >> 2, tr_cc = tr_i & 3;
+  int tr_base[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) tr_base[s2] = tile_off<D>(8 * s2 + 4 * hi + tr_rr, 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
+  const int ds_lane = TILE_K + wave * DS_WAVE + tr_half * 1024 + hi * 128 + (tr_cc & 1) * 64 + tr_rr * 16 + (tr_cc >> 1) * 8;
+
+  f32x16 acc[QB][DB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[qb][db][r] = 0.f;
+
+  auto rd_tr = [&](int a0, int a1) __attribute__((always_inline)) {
+    const s16x4 lo = lds_read_tr16(lds + a0), hi4 = lds_read_tr16(lds + a1);
+    return combine_tr<V8>(lo, hi4);
+  };
+  if (n_max > 0) load_tile(0, 0);
+  if (n_max > 1) load_tile(1, 1);
+  auto tile = [&](auto curc, int n) __attribute__((always_inline)) {
+    constexpr int cur = decltype(curc)::value;
+    wait_tile(n + 1 < n_max);
+    __syncthreads();   // tile n is in LDS for every wave, and every wave is done with tile n - 1, whose slot the next request overwrites
+    if (n + 2 < n_max) load_tile(n + 2, (cur + 2) % RING);
+    bool act[QB][2];
+    bool all = true;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        act[qb][kb] = ds_tile_active(w_row0 + 32 * qb, n * BN + 32 * kb, sq, sk, shift, p.wl, p.wr);
+        all = all && act[qb][kb];
+      }
+    constexpr int KOFF = cur * SLOT, DOFF = cur * SLOT;
+    if (__builtin_expect(all, 1)) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {   // k-step = 16 keys: key sub-tile kb = ks >> 1, half t = ks & 1
+        const int kb = ks >> 1, t = ks & 1;
+        V8 bf[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const int a = DOFF + ds_lane + qb * 4096 + kb * 2048 + t * 512;
+          bf[qb] = rd_tr(a, a + 256);
+        }
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const int kbase = KOFF + kb * 32 * ROW_BYTES + 16 * t * ROW_BYTES;
+          const V8 af = rd_tr(kbase + (tr_base[0] ^ (db << 6)), kbase + (tr_base[1] ^ (db << 6)));
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) acc[qb][db] = T::mfma(af, bf[qb], acc[qb][db]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        if (!(act[0][kb] || act[1][kb])) continue;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          V8 bf[QB];
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            const int a = DOFF + ds_lane + qb * 4096 + kb * 2048 + t * 512;
+            bf[qb] = rd_tr(a, a + 256);
+          }
+#pragma unroll
+          for (int db = 0; db < DB; ++db) {
+            const int kbase = KOFF + kb * 32 * ROW_BYTES + 16 * t * ROW_BYTES;
+            const V8 af = rd_tr(kbase + (tr_base[0] ^ (db << 6)), kbase + (tr_base[1] ^ (db << 6)));
+            if (act[0][kb]) acc[0][db] = T::mfma(af, bf[0], acc[0][db]);
+            if (act[1][kb]) acc[1][db] = T::mfma(af, bf[1], acc[1][db]);
+          }
+        }
+      }
+    }
+  };
+  for (int n = 0; n < n_max; n += RING) {
+    tile(ICw<0>{}, n);
+    if (n + 1 < n_max) tile(ICw<1>{}, n + 1);
+    if (n + 2 < n_max) tile(ICw<2>{}, n + 2);
+  }
+  __syncthreads();   // every wave is done with the ring: the staging below reuses it
+  E* dqtile = (E*)p.dq + (int64_t)b * p.dq_bs + (int64_t)w_row0 * p.dq_rs + (int64_t)h * p.dq_hs;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int row0 = w_row0 + 32 * qb;
+    if (row0 < sq)
+      store_tile_via_lds<E, D>(lds + (wave * 64 + qb * 32) * (ROW_BYTES + 16), acc[qb], p.scale, dqtile + (int64_t)(32 * qb) * p.dq_rs, p.dq_rs, sq - row0, lane);
+  }
+}
+
+// The mixed launch of the 5-contraction backward: workgroups 0 .. c5_np - 1 are dK/dV items (they are dealt first: the heavy ones), the rest dQ items of the chunk
+// before -- small, and independent of everything else in the launch: they fill the CUs the dK/dV items leave as they finish.
+template <typename E, int D>
+__global__ void __launch_bounds__(256, 1) fa_bwd_c5_kernel(const BwdK p) {
+  // dispatch order: the two lists interleaved c5_mix dK/dV items to one dQ item for as long as both last (the dQ items stream dS from memory -- HBM-bound on their
+  // own --, so they run beside the matrix-bound dK/dV items rather than behind them), then the rest of the longer list
+  const int bid = blockIdx.x, g = p.c5_mix + 1;
+  const int n_pairs = min(p.c5_np / p.c5_mix, p.c5_nc);
+  int kind, idx;   // kind 0 = dK/dV item idx, 1 = dQ item idx
+  if (bid < n_pairs * g) { const int q = bid / g, r = bid - q * g; kind = r == p.c5_mix; idx = kind ? q : q * p.c5_mix + r; }
+  else { const int rest = bid - n_pairs * g, p_left = p.c5_np - n_pairs * p.c5_mix; kind = rest >= p_left; idx = kind ? n_pairs + rest - p_left : n_pairs * p.c5_mix + rest; }
+  if (kind == 0) dkdv_w64_body<E, D, 0, true>(p, idx + p.c5_pbid0);
+  else dq_ds_w64_body<E, D>(p, idx);
+}
+
+template <typename E, int D>
+static int launch_c5_t(const BwdK& p, hipStream_t stream) {
+  constexpr int dkdv = 4 * 2 * 32 * D * 2 + 256 * D * 2 + 4 * 2 * 32 * 4 + (D == 128 ? 4 * (D / 16 - 1) * 1024 : 0);
+  constexpr int dq = 3 * (64 * D * 2 + 4 * 8192), stage = 256 * (D * 2 + 16);
+  constexpr int smem = dkdv > dq ? (dkdv > stage ? dkdv : stage) : (dq > stage ? dq : stage);
+  static_assert(smem <= 160 * 1024, "LDS");
+  auto kern = fa_bwd_c5_kernel<E, D>;
+  static std::atomic<unsigned long long> attr_mask{0};
+  if (ensure_dyn_lds(attr_mask, (const void*)kern, 160 * 1024, true) != 0) return -1;
+  const long long total = (long long)p.c5_np + p.c5_nc;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), smem, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// One launch of the 5-contraction backward (fa_api.cpp: do_bwd_c5 sizes the chunks and the workspace): plain attention, fixed-length batches, head dim 64 / 128, no left
+// window, sk >= sq; -2 = not covered.
+int launch_bwd_c5(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
+  if (p.rng != nullptr || p.alibi != nullptr || p.softcap > 0.f || p.d_chunks > 0 || p.cu_q || p.cu_k || p.seqused_q || p.seqused_k || p.k_list) return -2;
+  if (p.wl >= 0 || p.sk < p.sq || (d != 128 && d != 64) || (p.c5_np > 0 && !p.ds_ws) || (p.c5_nc > 0 && !p.ds_rd)) return -2;
+  const uint64_t span = ((uint64_t)(p.sq > 0 ? p.sq : 1) + 64) * (uint64_t)(p.q_rs > p.do_rs ? p.q_rs : p.do_rs) * 2u;
+  const uint64_t kspan = ((uint64_t)p.sk + 128) * (uint64_t)p.k_rs * 2u;
+  if (span >= (1ull << 32) || kspan >= (1ull << 32)) return -2;
+  if (d == 128) return dtype_bf16 ? launch_c5_t<__bf16, 128>(p, stream) : launch_c5_t<_Float16, 128>(p, stream);
+  return dtype_bf16 ? launch_c5_t<__bf16, 64>(p, stream) : launch_c5_t<_Float16, 64>(p, stream);
+}
+#endif  // FA_DKDV64_PART != 1
+
+#if FA_DKDV64_PART != 2
 template <typename E, int D, int FEAT>
 static int launch_dkdv_w64_f(const BwdK& p, hipStream_t stream) {
   constexpr bool ALIBI = FEAT == FEAT_ALIBI;
@@ -697,5 +1011,6 @@ int launch_bwd_dkdv_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream
   if (d == 128) return dtype_bf16 ? launch_dkdv_w64_t<__bf16, 128>(p, stream) : launch_dkdv_w64_t<_Float16, 128>(p, stream);
   return dtype_bf16 ? launch_dkdv_w64_t<__bf16, 64>(p, stream) : launch_dkdv_w64_t<_Float16, 64>(p, stream);
 }
+#endif  // FA_DKDV64_PART != 2
 
 }  // namespace fa

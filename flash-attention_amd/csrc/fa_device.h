@@ -215,6 +215,16 @@ FA_DEVINL bool ds_tile_active(int q0, int k0, int sq, int sk, int shift, int wl,
 // pulls the transposed fragment (lane = query) out of LDS with ds_read_b64_tr_b16: the 16 lanes of one transpose group vary
 // key bits 0-1, hi and the 8-byte half of the slot -- with those in address bits 3-6 the group covers all 32 banks once.
 FA_DEVINL int ds_slot(int key, int hi) { return (key & 3) | (hi << 2) | ((key >> 2) << 3); }
+// Packed rows of the 5-contraction backward's dS workspace (fa_bwd_dkdv_w64.hip, DS).  The unit of a row is the PAIR of key sub-tiles (64 keys) a dK/dV wave
+// writes together: row block i (32 queries) of a head holds pairs 0 .. pc(i) - 1, pc(i) = min((i + a) >> 1, np64) -- a - 1 = the key sub-tiles row block 0 can see
+// under a right-bounded mask (sk >= sq, no left window), so (i + a - 2) >> 1 is the pair of the last sub-tile row block i sees; a = 2 * np64 without a right bound --
+// and starts at sub-tile ds_row_start(i) = 2 * sum_{j < i} pc(j); with F(n) = sum_{m < n} (m >> 1) = ((n - 1)^2) >> 2 that is F(a + i) - F(a) up to row block
+// jb = max(0, 2 * np64 - a), the first one that holds every pair.  A head occupies ds_row_start(nq32) sub-tiles of 2 KB.
+__host__ __device__ inline int ds_row_start(int i, int a, int jb, int np64) {
+  const int m = i < jb ? i : jb;
+  const int n1 = a + m - 1, n0 = a - 1;
+  return 2 * (((n1 * n1) >> 2) - ((n0 * n0) >> 2) + (i > jb ? i - jb : 0) * np64);
+}
 
 // Score-transform features of the non-plain kernel variants (template int FEAT): softcap, ALiBi, dropout.  A variant
 // with exactly one feature carries only that feature's code and registers; FEAT_ALL checks the parameters at run time.

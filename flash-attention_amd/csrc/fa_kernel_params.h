@@ -120,6 +120,16 @@ struct BwdK {
   int32_t fuse_items;        // dQ items of the fused backward = b * h * nmb (256-row blocks)
   int32_t fuse_line;         // words between two arrival counters of the sync area
   int32_t fuse_total;        // key-block items of the fused backward (= the dK/dV kernel's grid)
+  // 5-contraction backward (round 6, fa_bwd_dkdv_w64.hip fa_bwd_c5_kernel): one launch = the dK/dV items of one chunk of (batch, kv head) units, which write dS to the
+  // slot ds_ws, followed by the dQ = dS.K items of the chunk BEFORE it, which read the slot ds_rd the previous launch filled (stream order is the hand-off).  Units are
+  // dealt to the XCDs in rounds of eight (k_units / k_unit_size / k_unit_hpx); a chunk is a range of rounds.
+  const void* ds_rd;         // slot read by this launch's dQ items
+  uint32_t c5_slot_bytes;    // bytes of a slot (range of the buffer descriptors)
+  int32_t c5_np, c5_nc;      // dK/dV items and dQ items of this launch
+  int32_t c5_mix;            // dispatch order: c5_mix dK/dV items, one dQ item, ... (>= 1)
+  int32_t c5_pbid0;          // number of the launch's first dK/dV item in the whole dK/dV grid
+  int32_t c5_pj0, c5_cj0;    // first round of the dK/dV items' chunk / of the dQ items' chunk
+  int32_t ds_c1, ds_jb, ds_head_tiles;   // row packing of the workspace (fa_device.h ds_row_start(i, ds_c1, ds_jb, ds_nk32): on this path ds_nk32 counts 64-key PAIRS of sub-tiles); sub-tiles per head = ds_head_tiles
   int32_t fuse_delta;        // 64-rows-per-wave dQ kernel only: 1 = compute softmax_d = rowsum(dO * O) of its own rows in the prologue (and write it for the
                              // dK/dV kernel, which is then launched BEHIND the dQ kernel); 0 = read it (fa_bwd_delta_kernel ran first)
 };

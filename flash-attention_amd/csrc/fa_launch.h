@@ -18,6 +18,10 @@ struct Knobs {
   int bwd_mode;        // FA_BWD_MODE: 0 / 1 = the dQ kernel recomputes S, dP, dS (7 contractions, no O(S^2) scratch); 3 = the dK/dV part hands dS over and dQ = dS.K
                        // (5 contractions) in ONE persistent launch (fa_bwd.hip fa_bwd_fused_kernel): plain attention, head dim 64 / 128, fixed-length batches, no
                        // left window, whose dS workspace fits FA_BWD_DS_CAP_MB.  (2 = the two-launch dS spill: experiments/ds_spill.patch only)
+                       // 5 = the 5-contraction backward in chunked mixed launches (fa_bwd_dkdv_w64.hip fa_bwd_c5_kernel; workspace bounded by FA_BWD_C5_CAP_MB);
+                       // -1 = never (the recomputing pair everywhere); 0 = the measured table (fa_api.cpp bwd_c5_plan)
+  int bwd_c5_mix;      // FA_BWD_C5_MIX: dispatch order of a mixed launch, this many dK/dV items per dQ item (default 1)
+  int bwd_c5_cap_mb;   // FA_BWD_C5_CAP_MB: workspace bound of the 5-contraction backward, both slots together (default 1024)
   int fz_line;         // FA_FZ_LINE: fused backward, int32 words between two arrival counters of the sync area (default 32 = one 128-byte line each)
   int bwd_ds_cap_mb;   // FA_BWD_DS_CAP_MB: largest dS workspace FA_BWD_MODE=3 asks for (default 8192)
   int w64_persist;     // FA_W64_PERSIST: 0 = one workgroup per block (no persistent walk) in the 64-rows-per-wave forward
@@ -131,7 +135,8 @@ int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_fused(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);   // fa_bwd.hip (FA_BWD_PART=3): dK/dV + dQ = dS.K in one launch; -2 = does not apply
 int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_dq_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
-int launch_bwd_dkdv_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);   // fa_bwd_dkdv_w64.hip: 64 keys per wave, software-pipelined; -2 = not covered
+int launch_bwd_dkdv_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
+int launch_bwd_c5(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);   // fa_bwd_dkdv_w64.hip (FA_DKDV64_PART=2): one mixed launch of the 5-contraction backward (dK/dV items of a chunk + dQ = dS.K items of the chunk before); -2 = not covered   // fa_bwd_dkdv_w64.hip: 64 keys per wave, software-pipelined; -2 = not covered
 int bwd_block_m(int dq_nw);   // query rows per dQ workgroup of schedule dq_nw (BwdK::dq_nw)
 int bwd_block_n(int d);   // key rows per dK/dV workgroup (256; 128 for head dim 256)
 

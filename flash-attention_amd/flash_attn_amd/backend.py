@@ -10,6 +10,7 @@ current stream only; all arithmetic happens in libfa_gfx950.so.  No fallback pat
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -324,6 +325,8 @@ def _run_bwd(a, device, varlen):
     ws = None
     if ws_bytes > 0:
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=device)
+        if os.environ.get("FA_DEBUG_POISON_WS"):   # tests: every 16-bit word of the workspace a NaN, so that a read of something nobody wrote shows
+            ws.fill_(0xFF)
         a.workspace, a.workspace_bytes = _ptr(ws), ws_bytes
     with torch.cuda.device(device):
         fn = lib.fa_varlen_bwd if varlen else lib.fa_bwd
