@@ -248,27 +248,33 @@ def feature_rows(be, dev, sync, B, H, S, D):
         g = torch.randn_like(o)
         h = lambda: be.bwd(g, q, k, v, o, l, None, None, None, al, 0.0, sc, True, -1, -1, 0.0, False, None, None)
         _, mb = time_kernel(h, 8, 2, sync)
+        sb = be.last_schedule()
         fl = fwd_flops(B, H, S, D, True)
         out = {"causal_alibi": {"fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
-                                "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name}}
-        # ... and with softcap 30 (round 5: forward on the 64-rows-per-wave kernel's softcap variant; the backward on the feature kernels of fa_bwd.hip)
+                                "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name,
+                                "bwd_dq_waves_x_rows": sb["bwd_dq_nw"], "bwd_dkdv_waves": sb["bwd_dkdv_nw"]}}
+        # ... and with softcap 30 (round 5: forward on the 64-rows-per-wave kernel's softcap variant; at head dim 128 the backward on the softcap variants of both 64-per-wave kernels)
         f = lambda: be.fwd(q, k, v, None, None, 0.0, sc, True, -1, -1, 30.0, False, None)
         _, ms = time_kernel(f, 20, 5, sync)
         name = be.last_schedule()["name"]
         o, l = f()[:2]
         h = lambda: be.bwd(g, q, k, v, o, l, None, None, None, None, 0.0, sc, True, -1, -1, 30.0, False, None, None)
         _, mb = time_kernel(h, 8, 2, sync)
+        sb = be.last_schedule()
         out["causal_softcap"] = {"fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
-                                 "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name}
-        # ... and with dropout 0.1 (round 5: forward on the 64-rows-per-wave kernel's dropout variant; the backward on the feature kernels of fa_bwd.hip)
+                                 "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name,
+                                 "bwd_dq_waves_x_rows": sb["bwd_dq_nw"], "bwd_dkdv_waves": sb["bwd_dkdv_nw"]}
+        # ... and with dropout 0.1 (round 5: forward on the 64-rows-per-wave kernel's dropout variant; at head dim 128 dQ on the 64-rows-per-wave kernel's dropout variant, dK/dV on the eight-wave feature kernel)
         f = lambda: be.fwd(q, k, v, None, None, 0.1, sc, True, -1, -1, 0.0, False, None)
         _, ms = time_kernel(f, 20, 5, sync)
         name = be.last_schedule()["name"]
         o, l, _, rng = f()
         h = lambda: be.bwd(g, q, k, v, o, l, None, None, None, None, 0.1, sc, True, -1, -1, 0.0, False, None, rng)
         _, mb = time_kernel(h, 8, 2, sync)
+        sb = be.last_schedule()
         out["causal_dropout"] = {"fwd_tflops": round(fl / ms / 1e9, 1), "bwd_tflops": round(2.5 * fl / mb / 1e9, 1),
-                                 "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name}
+                                 "fwd_bwd_tflops": round(3.5 * fl / (ms + mb) / 1e9, 1), "fwd_kernel": name,
+                                 "bwd_dq_waves_x_rows": sb["bwd_dq_nw"], "bwd_dkdv_waves": sb["bwd_dkdv_nw"]}
         return out
     except Exception as e:   # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}

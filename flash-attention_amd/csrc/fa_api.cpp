@@ -52,7 +52,7 @@ const fa::Knobs* read_knobs() {
   k->bwd_mode = env_int("FA_BWD_MODE", 0);
   k->bwd_dkdv = env_int("FA_BWD_DKDV", 0);
   k->bwd_ds_cap_mb = env_int("FA_BWD_DS_CAP_MB", 8192);
-  k->bwd_c5_mix = env_int("FA_BWD_C5_MIX", 1);
+  k->bwd_fused_check = env_int("FA_BWD_FUSED_CHECK", 0);
   k->bwd_c5_cap_mb = std::max(16, std::min(65536, env_int("FA_BWD_C5_CAP_MB", 1024)));
   k->fz_line = std::max(1, std::min(64, env_int("FA_FZ_LINE", 32)));
   k->w64_persist = env_int("FA_W64_PERSIST", 1);
@@ -161,6 +161,11 @@ bool w64_span_ok(const FaFwdParams* a) {
   const uint64_t rs = (uint64_t)std::max<int64_t>(a->k_row_stride, a->v_row_stride);
   const uint64_t qo = (uint64_t)std::max<int64_t>(a->q_row_stride, a->o_row_stride);
   const uint64_t keys = a->block_table ? 64 : (a->seqlen_k > 0 ? a->seqlen_k : 1);   // (a paged cache is addressed tile by tile)
+  // (paged: the kernel forms a page's and a tile's byte sizes in 32 bits -- fa_fwd_w64.hip pg_bytes_* / tl_bytes_*)
+  if (a->block_table) {
+    const uint64_t pg = (uint64_t)std::max<int64_t>(a->k_batch_stride, a->v_batch_stride) * 2u;
+    if (pg >= (1ull << 32) || (uint64_t)std::max(a->page_block_size, 1) * rs * 2u >= (1ull << 32)) return false;
+  }
   return (keys + 128) * rs * 2u < (1ull << 32) && 256ull * qo * 2u < (1ull << 32);
 }
 int fwd_schedule_nw(const FaFwdParams* a, int wl, int wr) {
@@ -407,7 +412,7 @@ int bwd_dq_schedule(const FaBwdParams* a) {
   return (a->d == 128 && plain && a->seqlen_k >= 2048 && a->seqlen_q >= 512) ? 64 : 4;
 }
 
-// dK/dV schedule (fa_launch.h Knobs::bwd_dkdv): 64 = four waves x 64 keys (fa_bwd_dkdv_w64.hip; plain attention or causal ALiBi at head dim 64 / 128), 8 = eight waves x 32 keys
+// dK/dV schedule (fa_launch.h Knobs::bwd_dkdv): 64 = four waves x 64 keys (fa_bwd_dkdv_w64.hip; plain attention or causal ALiBi at head dim 64 / 128, softcap at head dim 128), 8 = eight waves x 32 keys
 // (fa_bwd.hip: every feature variant, head dim 256, trimmed head dims).  Measured (profiles/r05_bwd_dkdv_w64.txt): at head dim 128 the 64-keys-per-wave kernel
 // wins from 2k query rows per key block (+1 % at S = 2048, +3 .. +6 % on the whole backward from S = 4096, GQA included) and loses below (its pipeline fill /
 // drain and 160 KB of LDS per workgroup cost more than they save on a short walk); at head dim 64 it ties or loses everywhere.
@@ -417,7 +422,12 @@ int bwd_dkdv_schedule(const FaBwdParams* a) {
   const int knob = fa::knobs().bwd_dkdv;
   if (knob == 8 || knob == 64) return knob;
   if (fa::knobs().dkdv_prescale) return 8;   // (FA_DKDV_PRESCALE=1 names a variant of the eight-wave kernel)
-  return (a->d == 128 && a->seqlen_q >= 2048) ? 64 : 8;
+  // (a key block's walk: the query rows that can see it -- bounded by the window under a two-sided mask; packed batches are sized by their longest sequence
+  // and stay on the eight-wave kernel below 2k rows of it)
+  long walk = a->seqlen_q;
+  const int wr = a->is_causal ? 0 : a->window_right;
+  if (a->window_left >= 0 && wr >= 0) walk = std::min<long>(walk, (long)a->window_left + wr + 256) * (a->h / a->h_k);   // (the query heads of a group are walked one after the other: config 5, 4 x 1280 rows, measured +1.5 % on this kernel)
+  return (a->d == 128 && walk >= 2048) ? 64 : 8;
 }
 
 int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {
@@ -473,15 +483,27 @@ void bwd_list_entries(const FaBwdParams* a, int64_t& q_entries, int64_t& k_entri
   if (dk_dense * 4 > dk_bound * 5 && dk_dense >= 64) k_entries = dk_bound;
 }
 
-// (The two-launch dS-spill backward, FA_BWD_MODE=2, tied with the recomputing pair -- profiles/r02_bwd_5_vs_7_contractions.txt -- and needs O(S^2) scratch: it
-// is not part of this library; experiments/ds_spill.patch + experiments/build_experiments.py put it back for measurement.)
+// (Round 2's two-launch dS-spill backward, FA_BWD_MODE=2 -- a tie with the recomputing pair, profiles/r02_bwd_5_vs_7_contractions.txt, on O(S^2) scratch -- is
+// superseded by FA_BWD_MODE=5 below: the same idea on the 64-per-wave kernels with a bounded workspace; git history keeps the old experiment.)
 // Fused backward (FA_BWD_MODE=3, fa_bwd.hip fa_bwd_fused_kernel): bytes of the dS workspace (256-B aligned) when the call qualifies, else 0; the sync
 // area (fa_kernel_params.h FZ_*) sits behind it.  Same conditions as launch_bwd_fused.
+// Round 6: it is the DEFAULT (FA_BWD_MODE=0) where it was measured ahead of the recomputing pair and its workspace stays within 1 GiB: head dim 128 under a causal
+// mask from 1k to 2k rows (+6 % at S = 1024, +9 % at S = 2048 on the sweep's shapes, profiles/r06_bwd_c5.txt: there the recomputing dQ pass runs the 32-rows-per-wave
+// kernel); it loses at S = 512, without a mask, at head dim 64, and ties from S = 4096.  FA_BWD_MODE=3 forces it wherever it applies (cap FA_BWD_DS_CAP_MB), -1 / 1 never.
+bool bwd_fused_by_table(const FaBwdParams* a) {
+  int causal = a->is_causal, wl = a->window_left, wr = a->window_right;
+  normalize_window(a->seqlen_q, a->seqlen_k, false, causal, wl, wr);
+  return a->d == 128 && wl < 0 && wr == 0 && a->seqlen_q == a->seqlen_k && a->seqlen_q >= 1024 && a->seqlen_q <= 2048 && fa::knobs().bwd_dq_nw == 0 && fa::knobs().bwd_dkdv == 0 &&
+         !fa::knobs().dkdv_prescale && !fa::knobs().strict;
+}
 int64_t bwd_fused_ds_bytes(const FaBwdParams* a) {
-  if (fa::knobs().bwd_mode != 3 || a->cu_seqlens_q || a->cu_seqlens_k || a->seqused_q || a->seqused_k || (a->d != 128 && a->d != 64)) return 0;
+  const int mode = fa::knobs().bwd_mode;
+  if ((mode != 3 && mode != 0) || a->cu_seqlens_q || a->cu_seqlens_k || a->seqused_q || a->seqused_k || (a->d != 128 && a->d != 64)) return 0;
   if (a->seqlen_q <= 0 || a->seqlen_k < a->seqlen_q || a->window_left >= 0 || a->softcap > 0.f || a->alibi_slopes || a->p_dropout > 0.f) return 0;
+  if (mode == 0 && !bwd_fused_by_table(a)) return 0;
   const int64_t bytes = (int64_t)a->b * a->h * ((a->seqlen_q + 31) / 32) * ((a->seqlen_k + 31) / 32) * 2048;
-  return bytes > ((int64_t)fa::knobs().bwd_ds_cap_mb << 20) ? 0 : ((bytes + 255) & ~(int64_t)255);
+  const int64_t cap = mode == 0 ? ((int64_t)1 << 30) : ((int64_t)fa::knobs().bwd_ds_cap_mb << 20);
+  return bytes > cap ? 0 : ((bytes + 255) & ~(int64_t)255);
 }
 int64_t bwd_fused_sync_bytes(const FaBwdParams* a) {
   return fa::fz_sync_words((int64_t)a->b * a->h * ((a->seqlen_q + 255) / 256), fa::knobs().fz_line) * 4;
@@ -556,7 +578,6 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
       k.c5_np = c < pl.n_chunks ? 8 * (pj1 - pj0) * pl.nnb : 0;
       k.c5_nc = c >= 1 ? 8 * (cj1 - cj0) * (a->h / a->h_k) * pl.nmb : 0;
       k.c5_pbid0 = 8 * pj0 * pl.nnb; k.c5_pj0 = pj0; k.c5_cj0 = cj0;
-      k.c5_mix = std::max(1, fa::knobs().bwd_c5_mix);
       rc = fa::launch_bwd_c5(k, bf, a->d, s);
     }
     if (rc == 0) {
@@ -683,6 +704,20 @@ int fa_bwd_dq_schedule_query(const FaBwdParams* a) {
   return bwd_dq_schedule(a);
 }
 
+int fa_bwd_plan_query(const FaBwdParams* a, int32_t* out, int n) {
+  if (!a || !out) return fail(FA_ERR_INVALID_ARGUMENT, "params / out is NULL");
+  if (int rc = check_common(a->b, a->h, a->h_k, a->d, a->dtype, a->softcap)) return rc;
+  int32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  C5Plan pl;
+  if (!a->cu_seqlens_q && bwd_c5_plan(a, pl)) {
+    v[0] = 5; v[1] = pl.n_chunks; v[2] = pl.rounds_per_chunk; v[3] = pl.head_tiles; v[4] = pl.np64; v[5] = pl.c1; v[6] = pl.jb; v[7] = (int32_t)(pl.slot_bytes >> 20);
+  } else if (!a->cu_seqlens_q && bwd_fused_ds_bytes(a) > 0) {
+    v[0] = 3;
+  }
+  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  return 8;
+}
+
 int fa_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, false); }
 int fa_varlen_fwd(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, true); }
 int fa_fwd_kvcache(const FaFwdParams* params, void* stream) { return do_fwd(params, stream, false, true); }
@@ -762,6 +797,10 @@ int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {
 int fa_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, false); }
 int fa_bwd_fused_status(const FaBwdParams* params, void* stream) {
   if (!params || !params->workspace || fa::last_schedule().bwd_spill != 3) return FA_OK;   // (this thread's last backward did not take the fused path: the sync area was never initialised)
+  // Reading the flag synchronises the stream.  Where the fused backward is the DEFAULT (round 6: the table of bwd_fused_by_table) the binders' call returns at once --
+  // a host sync per backward is not acceptable there, and the flag guards a wait that cannot time out while the launch's workgroups run (the publisher a consumer
+  // polls for is between two of its own instructions); FA_BWD_MODE=3 (the opt-in form) and FA_BWD_FUSED_CHECK=1 read it.
+  if (fa::knobs().bwd_mode != 3 && !fa::knobs().bwd_fused_check) return FA_OK;
   const int64_t fz = bwd_fused_ds_bytes(params);
   if (fz <= 0 || params->workspace_bytes < fz + bwd_fused_sync_bytes(params)) return FA_OK;   // the call did not (could not) take the fused path
   int32_t flag = 0;

@@ -469,7 +469,7 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
       }
     }
 
-    // (the fused backward's hand-over of dS, FA_BWD_MODE=3, and the dS-spill experiment's, experiments/ds_spill.patch; ds_ws is NULL otherwise and the branch is
+    // (the fused backward's hand-over of dS, FA_BWD_MODE=3; ds_ws is NULL otherwise and the branch is
     // not taken.  It is part of every variant: without it hipcc's register allocation of the softcap variant at D = 128 comes out two vector spills worse --
     // 12 bytes of scratch, tests/test_kernel_resources_cpu.py)
     if (p.ds_ws) {  // dS spill: this sub-tile's fragments, one 16-byte slot per lane (fa_device.h ds_slot), for the dQ contraction

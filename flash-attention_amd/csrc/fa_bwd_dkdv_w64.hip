@@ -29,21 +29,6 @@
 // one-wait-per-MFMA variant live in experiments/ablations/fa_bwd_dkdv_w64.patch (tools/ablate_dkdv64.sh).
 #define FA_DKDV64_AHJ 6     // phase A: row-fragment reads run this many fragments (= MFMA gaps) ahead of their first MFMA
 #define FA_DKDV64_AHT 3     // phase B: transposed-fragment reads run this many fragments (two gaps each) ahead
-#ifndef FA_DS_ST_MOD
-#define FA_DS_ST_MOD ""     // cache-policy bits of the dS stores (A/B builds: " nt", " sc1", " sc0 sc1")
-#endif
-#ifndef FA_C5_ABL_NOSTORE
-#define FA_C5_ABL_NOSTORE 0
-#endif
-#ifndef FA_C5_ABL_VMCNT
-#define FA_C5_ABL_VMCNT 0
-#endif
-#ifndef FA_C5_ABL_SAMEADDR
-#define FA_C5_ABL_SAMEADDR 0
-#endif
-#ifndef FA_DS_LD_MOD
-#define FA_DS_LD_MOD ""     // ... and of the dQ part's dS loads
-#endif
 
 #ifndef FA_DKDV64_PART
 #define FA_DKDV64_PART 0    // build.py compiles this file twice side by side: 1 = the dK/dV kernels, 2 = the 5-contraction backward's mixed kernel; 0 = everything
@@ -642,18 +627,17 @@ static __device__ __forceinline__ void dkdv_w64_body(const BwdK p, const int bid
     constexpr int i = decltype(ic)::value;
     const u32x4 x = dn[i >> 1][i & 1];
     const unsigned vo = ds_voff;   // (copies: clang does not capture a variable a generic lambda names only as an asm operand)
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%c4" FA_DS_ST_MOD : : "v"(x), "v"(vo), "s"(srd), "s"(soff), "i"((i >> 1) * 2048 + (i & 1) * 1024) : "memory");
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:%c4" : : "v"(x), "v"(vo), "s"(srd), "s"(soff), "i"((i >> 1) * 2048 + (i & 1) * 1024) : "memory");
   };
   auto step = [&](int st) __attribute__((always_inline)) {
     const Ctl c = nxt;
     // (DS) the dS of the PREVIOUS tile -- still in dn: this step's phase B rewrites it -- leaves in four stores; a step without a previous tile stores through a
     // descriptor of range zero (dropped by the hardware)
     u32x4 st_srd = ds_srd;
-    const unsigned st_off = FA_C5_ABL_SAMEADDR == 1 ? (unsigned)(wave * 4096) : FA_C5_ABL_SAMEADDR > 1 ? (ds_prev_off & (unsigned)(FA_C5_ABL_SAMEADDR - 1)) : ds_prev_off;
-    if constexpr (DS) { if (c.slot_b == c.slot_a || FA_C5_ABL_NOSTORE) st_srd[2] = 0u; ds_prev_off = c.ds_off; }
+    const unsigned st_off = ds_prev_off;
+    if constexpr (DS) { if (c.slot_b == c.slot_a) st_srd[2] = 0u; ds_prev_off = c.ds_off; }
     auto ds_store = [&](auto ic) __attribute__((always_inline)) { ds_store_piece(ic, st_srd, st_off); };
     stream_aux(c.z);
-    advance(c, st);   // (at the step's head: inside phase A's gaps the ~70 scalar instructions cost more than here -- 1994 -> 2329 us, profiles/r05_bwd_dkdv_w64.txt)
     if (__builtin_expect(c.act, 1)) {
       phase_a(c.slot_a, [&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
@@ -690,11 +674,19 @@ static __device__ __forceinline__ void dkdv_w64_body(const BwdK p, const int bid
       if (__builtin_expect(c.act && c.msk, 0)) phase_b(Y{}, Y{}, Y{}, c.slot_b, c.q0, pc, dc, pn, dn, c.slot_a);
       else phase_b(Y{}, Y{}, N{}, c.slot_b, c.q0, pc, dc, pn, dn, c.slot_a);
     }
-    preload_a((st + 1) & 3, nxt.hq);   // (tile st + 1 was published by the previous barrier.  Unconditional: a conditional definition keeps the 96 registers of
-                               // S / dP / the fragment rings alive across phase B in hipcc's eyes; past the last tile it reads a stale slot nobody uses)
-    if constexpr (DS && FA_C5_ABL_VMCNT > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FA_C5_ABL_VMCNT) : "memory");
-    else lds_dma_wait_all();        // tile st + 2 has landed (requested in this step's first gaps)
+    // The step's tail, in THIS order (round 6; everything here is exposed -- one wave per SIMD, no MFMA to hide behind): the DMA wait and the aux store, then the next
+    // step's operand requests, and only then the ~30 scalar instructions that make the next step's control block -- they run while the requests are in flight; the
+    // barrier's own LDS wait (hipcc drains lgkmcnt in front of every s_barrier) then finds them landed.  (Round 5 had the control block first and the requests right in
+    // front of the barrier: their whole LDS round trip was waited out there, 17 reads per step.)
+    lds_dma_wait_all();        // tile st + 2 has landed (requested in this step's first gaps)
     stream_store_aux(c.slot2);
+    __builtin_amdgcn_sched_barrier(0);
+    const int hq_n = (ALIBI || DS) ? (c_left == 1 ? c_h + 1 : c_h) : 0;   // (= nxt.hq once advance() has run)
+    preload_a((st + 1) & 3, hq_n);   // (tile st + 1 was published by the previous barrier.  Unconditional: a conditional definition keeps the 96 registers of
+                               // S / dP / the fragment rings alive across phase B in hipcc's eyes; past the last tile it reads a stale slot nobody uses)
+    __builtin_amdgcn_sched_barrier(0);
+    advance(c, st);            // (not inside phase A's gaps: there the ~70 scalar instructions cost more -- 1994 -> 2329 us, profiles/r05_bwd_dkdv_w64.txt)
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   };
 #pragma unroll 1
@@ -827,10 +819,10 @@ static __device__ __forceinline__ void dq_ds_w64_body(const BwdK p, const int cb
     for (int qb = 0; qb < QB; ++qb) {
       const unsigned ddst = __builtin_amdgcn_readfirstlane((unsigned)(st * SLOT + TILE_K + wave * DS_WAVE + qb * 4096));
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                   "buffer_load_dwordx4 %1, %3, %4 offen lds" FA_DS_LD_MOD "\n\t"
-                   "buffer_load_dwordx4 %1, %3, %4 offen offset:1024 lds" FA_DS_LD_MOD "\n\t"
-                   "buffer_load_dwordx4 %1, %3, %4 offen offset:2048 lds" FA_DS_LD_MOD "\n\t"
-                   "buffer_load_dwordx4 %1, %3, %4 offen offset:3072 lds" FA_DS_LD_MOD "\n\t"
+                   "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+                   "buffer_load_dwordx4 %1, %3, %4 offen offset:1024 lds\n\t"
+                   "buffer_load_dwordx4 %1, %3, %4 offen offset:2048 lds\n\t"
+                   "buffer_load_dwordx4 %1, %3, %4 offen offset:3072 lds\n\t"
                    "s_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(ds_voff[qb]), "s"(ddst), "s"(ds_srd), "s"(dtoff) : "memory");
     }
@@ -848,74 +840,68 @@ static __device__ __forceinline__ void dq_ds_w64_body(const BwdK p, const int cb
   for (int s2 = 0; s2 < 2; ++s2) tr_base[s2] = tile_off<D>(8 * s2 + 4 * hi + tr_rr, 2 * tr_half + (tr_cc >> 1)) + (tr_cc & 1) * 8;
   const int ds_lane = TILE_K + wave * DS_WAVE + tr_half * 1024 + hi * 128 + (tr_cc & 1) * 64 + tr_rr * 16 + (tr_cc >> 1) * 8;
 
-  f32x16 acc[QB][DB];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[qb][db][r] = 0.f;
-
+  // dQ^T accumulators: tile (qb, db) = accumulator registers a[16 * (qb*DB + db) .. + 15], named in the asm like the dK/dV part's (as C++ values hipcc gave the three
+  // ring positions three register assignments and copied all 128 registers at every tile: 128 v_accvgpr_mov per 32 MFMAs); zeroed by the matrix pipe
+  {
+    u32x4 zf = {0u, 0u, 0u, 0u};
+    asm volatile("" : "+v"(zf));
+    acc_zero_tuples_mfma<0>(zf, std::make_integer_sequence<int, QB * DB>{});
+  }
   auto rd_tr = [&](int a0, int a1) __attribute__((always_inline)) {
     const s16x4 lo = lds_read_tr16(lds + a0), hi4 = lds_read_tr16(lds + a1);
-    return combine_tr<V8>(lo, hi4);
+    return __builtin_bit_cast(u32x4, combine_tr<V8>(lo, hi4));
   };
+  // tiles 0 .. n_all - 1 are complete for this wave (all four sub-tiles written: no mask edge, every row and key exists); the rest is tested sub-tile by sub-tile
+  int n_all = n_max;
+  if (w_row0 + 64 > sq) n_all = 0;
+  n_all = min(n_all, sk / BN);
+  if (p.wr >= 0) n_all = min(n_all, (w_row0 + shift + p.wr - 1) / BN + ((w_row0 + shift + p.wr - 1) >= 0 ? 1 : 0));   // 64 n + 32 <= w_row0 + 31 + shift + wr
+  n_all = __builtin_amdgcn_readfirstlane(max(n_all, 0));
   if (n_max > 0) load_tile(0, 0);
   if (n_max > 1) load_tile(1, 1);
   auto tile = [&](auto curc, int n) __attribute__((always_inline)) {
     constexpr int cur = decltype(curc)::value;
+    constexpr int KOFF = cur * SLOT, DOFF = cur * SLOT;
     wait_tile(n + 1 < n_max);
     __syncthreads();   // tile n is in LDS for every wave, and every wave is done with tile n - 1, whose slot the next request overwrites
     if (n + 2 < n_max) load_tile(n + 2, (cur + 2) % RING);
-    bool act[QB][2];
-    bool all = true;
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        act[qb][kb] = ds_tile_active(w_row0 + 32 * qb, n * BN + 32 * kb, sq, sk, shift, p.wl, p.wr);
-        all = all && act[qb][kb];
-      }
-    constexpr int KOFF = cur * SLOT, DOFF = cur * SLOT;
-    if (__builtin_expect(all, 1)) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {   // k-step = 16 keys: key sub-tile kb = ks >> 1, half t = ks & 1
-        const int kb = ks >> 1, t = ks & 1;
-        V8 bf[QB];
+    if (__builtin_expect(n < n_all, 1)) {
+      static_for<4>([&](auto ksc) __attribute__((always_inline)) {   // k-step = 16 keys: key sub-tile kb = ks >> 1, half t = ks & 1
+        constexpr int ks = decltype(ksc)::value, kb = ks >> 1, t = ks & 1;
+        u32x4 bf[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
           const int a = DOFF + ds_lane + qb * 4096 + kb * 2048 + t * 512;
           bf[qb] = rd_tr(a, a + 256);
         }
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-          const int kbase = KOFF + kb * 32 * ROW_BYTES + 16 * t * ROW_BYTES;
-          const V8 af = rd_tr(kbase + (tr_base[0] ^ (db << 6)), kbase + (tr_base[1] ^ (db << 6)));
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) acc[qb][db] = T::mfma(af, bf[qb], acc[qb][db]);
-        }
-      }
+        static_for<DB>([&](auto dbc) __attribute__((always_inline)) {
+          constexpr int db = decltype(dbc)::value;
+          constexpr int kbase = KOFF + kb * 32 * ROW_BYTES + 16 * t * ROW_BYTES;
+          const u32x4 af = rd_tr(kbase + (tr_base[0] ^ (db << 6)), kbase + (tr_base[1] ^ (db << 6)));
+          kv_mfma_tile<E, db>(af, bf[0]);
+          kv_mfma_tile<E, DB + db>(af, bf[1]);
+        });
+      });
     } else {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        if (!(act[0][kb] || act[1][kb])) continue;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          V8 bf[QB];
+      static_for<4>([&](auto ksc) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ksc)::value, kb = ks >> 1, t = ks & 1;
+        const bool a0 = ds_tile_active(w_row0, n * BN + 32 * kb, sq, sk, shift, p.wl, p.wr), a1 = ds_tile_active(w_row0 + 32, n * BN + 32 * kb, sq, sk, shift, p.wl, p.wr);
+        if (a0 || a1) {
+          u32x4 bf[QB];
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) {
             const int a = DOFF + ds_lane + qb * 4096 + kb * 2048 + t * 512;
             bf[qb] = rd_tr(a, a + 256);
           }
-#pragma unroll
-          for (int db = 0; db < DB; ++db) {
-            const int kbase = KOFF + kb * 32 * ROW_BYTES + 16 * t * ROW_BYTES;
-            const V8 af = rd_tr(kbase + (tr_base[0] ^ (db << 6)), kbase + (tr_base[1] ^ (db << 6)));
-            if (act[0][kb]) acc[0][db] = T::mfma(af, bf[0], acc[0][db]);
-            if (act[1][kb]) acc[1][db] = T::mfma(af, bf[1], acc[1][db]);
-          }
+          static_for<DB>([&](auto dbc) __attribute__((always_inline)) {
+            constexpr int db = decltype(dbc)::value;
+            constexpr int kbase = KOFF + kb * 32 * ROW_BYTES + 16 * t * ROW_BYTES;
+            const u32x4 af = rd_tr(kbase + (tr_base[0] ^ (db << 6)), kbase + (tr_base[1] ^ (db << 6)));
+            if (a0) kv_mfma_tile<E, db>(af, bf[0]);
+            if (a1) kv_mfma_tile<E, DB + db>(af, bf[1]);
+          });
         }
-      }
+      });
     }
   };
   for (int n = 0; n < n_max; n += RING) {
@@ -924,28 +910,27 @@ static __device__ __forceinline__ void dq_ds_w64_body(const BwdK p, const int cb
     if (n + 2 < n_max) tile(ICw<2>{}, n + 2);
   }
   __syncthreads();   // every wave is done with the ring: the staging below reuses it
+  mfma_drain_acc();
   E* dqtile = (E*)p.dq + (int64_t)b * p.dq_bs + (int64_t)w_row0 * p.dq_rs + (int64_t)h * p.dq_hs;
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
+  static_for<QB>([&](auto qbc) __attribute__((always_inline)) {
+    constexpr int qb = decltype(qbc)::value;
     const int row0 = w_row0 + 32 * qb;
+    f32x16 tt[DB];
+    static_for<DB>([&](auto dbc) __attribute__((always_inline)) { acc_read_tuple<16 * (qb * DB + decltype(dbc)::value)>(tt[decltype(dbc)::value]); });
     if (row0 < sq)
-      store_tile_via_lds<E, D>(lds + (wave * 64 + qb * 32) * (ROW_BYTES + 16), acc[qb], p.scale, dqtile + (int64_t)(32 * qb) * p.dq_rs, p.dq_rs, sq - row0, lane);
-  }
+      store_tile_via_lds<E, D>(lds + (wave * 64 + qb * 32) * (ROW_BYTES + 16), tt, p.scale, dqtile + (int64_t)(32 * qb) * p.dq_rs, p.dq_rs, sq - row0, lane);
+  });
 }
 
 // The mixed launch of the 5-contraction backward: workgroups 0 .. c5_np - 1 are dK/dV items (they are dealt first: the heavy ones), the rest dQ items of the chunk
 // before -- small, and independent of everything else in the launch: they fill the CUs the dK/dV items leave as they finish.
 template <typename E, int D>
 __global__ void __launch_bounds__(256, 1) fa_bwd_c5_kernel(const BwdK p) {
-  // dispatch order: the two lists interleaved c5_mix dK/dV items to one dQ item for as long as both last (the dQ items stream dS from memory -- HBM-bound on their
-  // own --, so they run beside the matrix-bound dK/dV items rather than behind them), then the rest of the longer list
-  const int bid = blockIdx.x, g = p.c5_mix + 1;
-  const int n_pairs = min(p.c5_np / p.c5_mix, p.c5_nc);
-  int kind, idx;   // kind 0 = dK/dV item idx, 1 = dQ item idx
-  if (bid < n_pairs * g) { const int q = bid / g, r = bid - q * g; kind = r == p.c5_mix; idx = kind ? q : q * p.c5_mix + r; }
-  else { const int rest = bid - n_pairs * g, p_left = p.c5_np - n_pairs * p.c5_mix; kind = rest >= p_left; idx = kind ? n_pairs + rest - p_left : n_pairs * p.c5_mix + rest; }
-  if (kind == 0) dkdv_w64_body<E, D, 0, true>(p, idx + p.c5_pbid0);
-  else dq_ds_w64_body<E, D>(p, idx);
+  // (dispatch order = grid order: the dK/dV items first.  Interleaving the two lists -- n dK/dV items, one dQ item, ... -- was measured and removed: beside the dK/dV
+  // items the dQ items' dS stream slows those more than it hides, profiles/r06_bwd_c5.txt)
+  const int bid = blockIdx.x;
+  if (bid < p.c5_np) dkdv_w64_body<E, D, 0, true>(p, bid + p.c5_pbid0);
+  else dq_ds_w64_body<E, D>(p, bid - p.c5_np);
 }
 
 template <typename E, int D>
@@ -998,7 +983,7 @@ static int launch_dkdv_w64_t(const BwdK& p, hipStream_t stream) {
   return p.alibi ? launch_dkdv_w64_f<E, D, FEAT_ALIBI>(p, stream) : launch_dkdv_w64_f<E, D, 0>(p, stream);
 }
 
-// 4 waves x 64 keys per workgroup (the same 256-key blocks as fa_bwd_dkdv_kernel: grid and work list unchanged).  Plain attention or ALiBi under a causal right
+// 4 waves x 64 keys per workgroup (the same 256-key blocks as fa_bwd_dkdv_kernel: grid and work list unchanged).  Plain attention, softcap (head dim 128) or ALiBi under a causal right
 // bound, head dim 64 / 128; -2 = not covered, the caller runs fa_bwd_dkdv_kernel.
 int launch_bwd_dkdv_w64(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   if (p.rng != nullptr || p.ds_ws != nullptr || p.d_chunks > 0) return -2;

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fa_fwd_il_kernel(const FwdK p) {
   if (p.seqused_q) sq = min(sq, p.seqused_q[b]);
   if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; k_row0 = c0; k_boff = 0; v_boff = 0; }
   if (p.block_table) k_row0 = 0;  // paged K/V: the page table supplies the rows, cu_seqlens_k only the lengths
-  if (p.seqused_k) sk = min(p.seqused_k[b] + p.seqused_add, p.sk);  // keys in use, never beyond the addressable capacity
+  if (p.seqused_k) sk = min(p.seqused_k[b] + p.seqused_add, (p.cu_k && !p.block_table) ? sk : p.sk);  // keys in use, never beyond the addressable capacity; inside a packed batch never beyond the entry's slot (as the backward: include/fa_gfx950.h)
   if (p.leftpad_k) {  // a left-padded sequence starts at row leftpad_k[b] (reference block_info.h:17-36)
     const int lp = p.leftpad_k[b];
     sk = max(0, sk - lp);

@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     if (p.cu_q) { const int c0 = p.cu_q[k.b]; k.sq = p.cu_q[k.b + 1] - c0; k.q_row0 = c0; k.q_boff = 0; k.o_boff = 0; }
     if (p.seqused_q) k.sq = min(k.sq, p.seqused_q[k.b]);
     if (p.cu_k) { const int c0 = p.cu_k[k.b]; k.sk = p.cu_k[k.b + 1] - c0; k.k_row0 = c0; k.k_boff = 0; k.v_boff = 0; }
-    if (p.seqused_k) k.sk = min(p.seqused_k[k.b] + p.seqused_add, p.sk);
+    if (p.seqused_k) k.sk = min(p.seqused_k[k.b] + p.seqused_add, (p.cu_k && !PAGED) ? k.sk : p.sk);   // (inside a packed batch never beyond the entry's slot, as the backward)
     if (p.leftpad_k) {
       const int lp = p.leftpad_k[k.b];
       k.sk = max(0, k.sk - lp);
@@ -655,6 +655,13 @@ __global__ void __launch_bounds__(256, 1) fa_fwd_w64_kernel(const FwdK p) {
     // (DROP) group G = 4*qb + g (elements 16*qb + 4*g .. + 3 = keys k0 + 8*g + 4*hi .. + 3 of the step whose probabilities this step makes, k0 = 4 * drop_k0q):
     // round r of its Philox call sits in gap ((7*G + r) * (NG - 2)) / 56 -- two rounds per gap at D = 128, the last group done one gap before its elements are packed
     auto drop_gap = [](int G, int r) constexpr { return ((7 * G + r) * (NG - 2)) / 56; };
+    // (the word of group G is used where the group's first element is packed: gap QKG + (4*G) / CPG of the P.V half, CPG conversions per gap; the backward twin has the same check)
+    constexpr bool drop_in_time = [&]() constexpr {
+      constexpr int cpg = 16 / PVG > 0 ? 16 / PVG : 1;
+      for (int G = 0; G < 8; ++G) if (drop_gap(G, 6) >= QKG + (2 * G) / cpg) return false;
+      return true;
+    }();
+    static_assert(!DROP || drop_in_time, "a Philox word is finished before its first element is packed");
     unsigned ph_c0[8], ph_c1[8];
     constexpr int KOFF = par * TILE_BYTES + half * 32 * ROW_BYTES;                       // K_u: buffer u & 1
     constexpr int VOFF = (2 + (par ^ 1)) * TILE_BYTES + half * 32 * ROW_BYTES;           // V_{u-1}: buffer (u - 1) & 1
@@ -1153,6 +1160,8 @@ int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream) {
   if (p.rng != nullptr && (p.randval != nullptr || p.softcap > 0.f || p.alibi != nullptr || p.block_table != nullptr)) return -2;   // dropout: alone, and without the random-byte output
   if (p.softcap > 0.f && p.alibi != nullptr) return -2;
   if (p.block_table != nullptr && (p.softcap > 0.f || p.alibi != nullptr || p.leftpad_k != nullptr || p.kv_batch_idx != nullptr || p.page_size % 64 != 0)) return -2;
+  // (paged: a page's and a tile's bytes are formed in 32 bits -- pg_bytes_* / tl_bytes_* in the kernel)
+  if (p.block_table != nullptr && ((uint64_t)(p.k_bs > p.v_bs ? p.k_bs : p.v_bs) * 2u >= (1ull << 32) || (uint64_t)p.page_size * (uint64_t)(p.k_rs > p.v_rs ? p.k_rs : p.v_rs) * 2u >= (1ull << 32))) return -2;
   if (p.alibi != nullptr && p.wr != 0) return -2;   // the bias is linear in the key only where no visible key lies right of the diagonal
   // buffer addressing: 32-bit byte offsets from the (batch, kv-head) base
   // (a paged cache is addressed tile by tile: the offsets only span 64 rows)

@@ -126,7 +126,6 @@ struct BwdK {
   const void* ds_rd;         // slot read by this launch's dQ items
   uint32_t c5_slot_bytes;    // bytes of a slot (range of the buffer descriptors)
   int32_t c5_np, c5_nc;      // dK/dV items and dQ items of this launch
-  int32_t c5_mix;            // dispatch order: c5_mix dK/dV items, one dQ item, ... (>= 1)
   int32_t c5_pbid0;          // number of the launch's first dK/dV item in the whole dK/dV grid
   int32_t c5_pj0, c5_cj0;    // first round of the dK/dV items' chunk / of the dQ items' chunk
   int32_t ds_c1, ds_jb, ds_head_tiles;   // row packing of the workspace (fa_device.h ds_row_start(i, ds_c1, ds_jb, ds_nk32): on this path ds_nk32 counts 64-key PAIRS of sub-tiles); sub-tiles per head = ds_head_tiles

@@ -15,15 +15,16 @@ struct Knobs {
   int il_sched;        // FA_IL_SCHED: 0 = compiler-ordered pipelined step, else hand-placed slots
   int bwd_dq_nw;       // FA_BWD_DQ_NW: 0 = heuristic; recomputing dQ kernel of 4 or 8 waves x 32 rows, 64 = 4 waves x 64 rows (fa_bwd_w64.hip)
   int bwd_dkdv;        // FA_BWD_DKDV: 0 = heuristic; 8 = eight waves x 32 keys (fa_bwd.hip), 64 = four waves x 64 keys, software-pipelined (fa_bwd_dkdv_w64.hip)
-  int bwd_mode;        // FA_BWD_MODE: 0 / 1 = the dQ kernel recomputes S, dP, dS (7 contractions, no O(S^2) scratch); 3 = the dK/dV part hands dS over and dQ = dS.K
+  int bwd_mode;        // FA_BWD_MODE: 0 = the measured table (fa_api.cpp: the recomputing pair -- 7 contractions, no scratch -- except head dim 128 under a causal mask from 1k to 2k
+                       // rows, where the fused launch below runs on <= 1 GiB of workspace); 1 / -1 = the recomputing pair everywhere; 3 = the dK/dV part hands dS over and dQ = dS.K
                        // (5 contractions) in ONE persistent launch (fa_bwd.hip fa_bwd_fused_kernel): plain attention, head dim 64 / 128, fixed-length batches, no
-                       // left window, whose dS workspace fits FA_BWD_DS_CAP_MB.  (2 = the two-launch dS spill: experiments/ds_spill.patch only)
+                       // left window, whose dS workspace fits FA_BWD_DS_CAP_MB.  (2 = round 2's two-launch dS spill: retired, superseded by 5)
                        // 5 = the 5-contraction backward in chunked mixed launches (fa_bwd_dkdv_w64.hip fa_bwd_c5_kernel; workspace bounded by FA_BWD_C5_CAP_MB);
                        // -1 = never (the recomputing pair everywhere); 0 = the measured table (fa_api.cpp bwd_c5_plan)
-  int bwd_c5_mix;      // FA_BWD_C5_MIX: dispatch order of a mixed launch, this many dK/dV items per dQ item (default 1)
   int bwd_c5_cap_mb;   // FA_BWD_C5_CAP_MB: workspace bound of the 5-contraction backward, both slots together (default 1024)
   int fz_line;         // FA_FZ_LINE: fused backward, int32 words between two arrival counters of the sync area (default 32 = one 128-byte line each)
   int bwd_ds_cap_mb;   // FA_BWD_DS_CAP_MB: largest dS workspace FA_BWD_MODE=3 asks for (default 8192)
+  int bwd_fused_check; // FA_BWD_FUSED_CHECK=1: fa_bwd_fused_status reads the fused launch's error flag (a stream sync) also where the fused backward ran by default
   int w64_persist;     // FA_W64_PERSIST: 0 = one workgroup per block (no persistent walk) in the 64-rows-per-wave forward
   int pack_gqa;        // FA_PACK_GQA: 0 = never pack the query heads of a KV group into the rows of a block on the KV-cache path (A/B, tests)
   int dkdv_prescale;   // FA_DKDV_PRESCALE=1: the plain dK/dV kernel pre-scales K by softmax_scale*log2e (rounded to the input dtype; ~3 % faster, fa_bwd.hip: PRE);

@@ -86,7 +86,7 @@ class FaBwdParams(C.Structure):
 
 EXPORTS = (
     "fa_abi_version", "fa_sizeof_fwd_params", "fa_sizeof_bwd_params", "fa_sizeof_kvappend_params", "fa_sizeof_rotary_params",
-    "fa_last_error", "fa_rotary", "fa_knobs_reload", "fa_last_schedule", "fa_last_kernel_name", "fa_fwd_schedule_query", "fa_bwd_dq_schedule_query",
+    "fa_last_error", "fa_rotary", "fa_knobs_reload", "fa_last_schedule", "fa_last_kernel_name", "fa_fwd_schedule_query", "fa_bwd_dq_schedule_query", "fa_bwd_plan_query",
     "fa_fwd", "fa_varlen_fwd", "fa_fwd_kvcache", "fa_kvcache_append", "fa_set_rng_state", "fa_fwd_workspace_bytes",
     "fa_bwd_workspace_bytes", "fa_bwd", "fa_varlen_bwd", "fa_bwd_fused_status",
 )
@@ -138,6 +138,8 @@ def load():
     lib.fa_fwd_schedule_query.restype = C.c_int
     lib.fa_bwd_dq_schedule_query.argtypes = [C.POINTER(FaBwdParams)]
     lib.fa_bwd_dq_schedule_query.restype = C.c_int
+    lib.fa_bwd_plan_query.argtypes = [C.POINTER(FaBwdParams), C.POINTER(C.c_int32), C.c_int]
+    lib.fa_bwd_plan_query.restype = C.c_int
     lib.fa_rotary.argtypes = [C.POINTER(FaRotaryParams), C.c_void_p]
     lib.fa_rotary.restype = C.c_int
     lib.fa_set_rng_state.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]

@@ -191,9 +191,11 @@ typedef struct FaBwdParams {
   const int32_t* seqused_q;     /* ABI v6, optional (B): as FaFwdParams::seqused_q; dq rows past it are not written */
   const int32_t* seqused_k;     /* ABI v6, optional (B): keys of entry b in use.  In the backward it can only SHORTEN an entry: the length is
                                    min(seqused_k[b], the cu_seqlens_k length) (fixed-length: min(seqused_k[b], seqlen_k)) -- the key-block work
-                                   list is sized from cu_seqlens_k, so a longer value could not be honoured by every kernel (round 5; the forward's
-                                   seqused_k REPLACES the length, for KV caches).  A forward / backward pair of a padded batch (seqused <= the slot
-                                   length, what flash_attn_padded_func passes) sees the same keys; dk / dv rows past it are not written */
+                                   list is sized from cu_seqlens_k, so a longer value could not be honoured by every kernel (round 5).  Round 6: the
+                                   forward applies the same rule inside a packed batch (cu_seqlens_k without a block table): min(seqused_k[b] +
+                                   seqused_k_add, the cu_seqlens_k length); only against a KV cache (no cu_seqlens_k, or a paged one) does
+                                   seqused_k REPLACE the length.  A forward / backward pair therefore always sees the same keys; dk / dv rows
+                                   past it are not written */
 } FaBwdParams;
 
 /* ABI version of the loaded library (== FA_ABI_VERSION of the header it was built from). */
@@ -226,6 +228,12 @@ const char* fa_last_kernel_name(void);
  * schedule of the backward (4 / 8 waves x 32 rows, 64 = 4 waves x 64 rows).  Negative = FA_ERR_*.  For tests of the dispatch on a box without a GPU. */
 int fa_fwd_schedule_query(const FaFwdParams* params, int varlen);
 int fa_bwd_dq_schedule_query(const FaBwdParams* params);
+/* Which backward a fixed-length call runs and how its workspace is laid out (round 6; host logic only, for tests of the dispatch on a box without a GPU):
+ * out[0] = 0 the recomputing pair (7 contractions, no dS workspace), 3 = the fused launch (dK/dV + dQ = dS.K, FA_BWD_MODE=3 or the default table),
+ * 5 = the chunked 5-contraction backward (FA_BWD_MODE=5); for 5: out[1] = chunks, out[2] = XCD rounds (8 units) per chunk, out[3] = dS sub-tiles (2 KB) per
+ * head with packed rows, out[4] = 64-key pairs per row, out[5] / out[6] = the row packing's a / jb (csrc/fa_device.h ds_row_start), out[7] = MiB per slot.
+ * Returns the number of fields (8) or a negative FA_ERR_*. */
+int fa_bwd_plan_query(const FaBwdParams* params, int32_t* out, int n);
 
 /* Forward, fixed-length batch.  cu_seqlens_* must be NULL.  `stream` is a hipStream_t. */
 int fa_fwd(const FaFwdParams* params, void* stream);

@@ -1,6 +1,6 @@
 """The 64-keys-per-wave dK/dV kernel (csrc/fa_bwd_dkdv_w64.hip; reference: the dK/dV half of compute_dq_dk_dv_1colblock, csrc/flash_attn/src/flash_bwd_kernel.h:457-733),
 the default at head dim 128 from 2k query rows: pinned with FA_BWD_DKDV=64 on every shape below and compared with
-  * an fp32 PyTorch reference (the reference suite's rule: error <= 2x the error of the established eight-wave kernel, floors 1e-2 bf16 / 2e-3 fp16),
+  * an fp32 PyTorch reference (the reference suite's rule: error <= 3x the error of PyTorch attention computed in the input dtype; and <= 2x the established eight-wave kernel's),
   * itself, run twice (bitwise: no atomics, fixed accumulation order),
   * the same batch packed (varlen, key-block work list) against its sequences one by one (bitwise: the kernel's walk depends on the sequence alone).
 dQ does not come from this kernel; it is checked to be untouched by the knob (bitwise equal)."""
@@ -47,18 +47,26 @@ def test_dkdv_w64_against_fp32_and_the_eight_wave_kernel(be, knobs, shape, dtype
     assert all(torch.equal(a, b) for a, b in zip(g64[:3], again[:3])), "run-to-run"
     assert torch.equal(g8[0], g64[0]), "dq is not this kernel's"
     r = ref_grads(q, k, v, do, causal, wl, wr)
-    floor = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    pt = ref_grads(q, k, v, do, causal, wl, wr, upcast=False)   # PyTorch in the input dtype: the reference's yardstick
     for i in (1, 2):
         assert torch.isfinite(g64[i].float()).all()
-        e8, e64 = float((g8[i].float() - r[i]).abs().max()), float((g64[i].float() - r[i]).abs().max())
-        assert e64 <= max(2 * e8, floor), (i, e64, e8)
+        e8, e64, ept = (float((x.float() - r[i]).abs().max()) for x in (g8[i], g64[i], pt[i]))
+        # the reference's rule (tests/test_flash_attn.py: gradients within 3x the error of PyTorch in the input dtype, + 1e-5 where that error is exactly zero),
+        # and no worse than twice the established kernel (round 5's clause had a floor of 1e-2: at these shapes the size of the error itself)
+        assert e64 <= 3 * ept + 1e-5, (i, e64, ept)
+        assert e64 <= 2 * e8 + 1e-5, (i, e64, e8)
 
 
 def test_default_picks_it_from_2k_query_rows_at_head_dim_128(be):
-    for (S, d, want) in ((4096, 128, 64), (2048, 128, 64), (1024, 128, 8), (4096, 64, 8)):
+    for (S, d, causal, want) in ((4096, 128, True, 64), (2048, 128, False, 64), (1024, 128, False, 8), (4096, 64, True, 8)):
         q = torch.randn(1, S, 2, d, device="cuda", dtype=torch.bfloat16)
         k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
-        assert run_bwd(be, q, k, v, do, True)[3]["bwd_dkdv_nw"] == want, (S, d)
+        g = run_bwd(be, q, k, v, do, causal)
+        assert g[3]["bwd_dkdv_nw"] == want and g[3]["bwd_spill"] == 0, (S, d, g[3])
+    # (round 6: head dim 128 under a causal mask from 1k to 2k rows is the fused launch's by default -- its dK/dV part is the eight-wave kernel's text)
+    q = torch.randn(1, 2048, 2, 128, device="cuda", dtype=torch.bfloat16)
+    k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
+    assert run_bwd(be, q, k, v, do, True)[3]["bwd_spill"] == 3
     q = torch.randn(1, 4096, 2, 128, device="cuda", dtype=torch.bfloat16)
     k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
     assert run_bwd(be, q, k, v, do, True, softcap=20.0)[3]["bwd_dkdv_nw"] == 64   # round 5: the softcap variant of this kernel (head dim 128)

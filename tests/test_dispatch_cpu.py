@@ -170,3 +170,84 @@ def test_fused_backward_workspace_and_conditions(lib, monkeypatch):
         assert ws(bp(4, 4096, 4096, 32, 32, 128)) == 0 and ws(bp(16, 1024, 1024, 32, 32, 128)) == expect(16, 1024, 1024, 32)
     finally:
         monkeypatch.delenv("FA_BWD_MODE", raising=False); monkeypatch.delenv("FA_BWD_DS_CAP_MB", raising=False); lib.fa_knobs_reload()
+
+
+def _bwd_params(B, Sq, Sk, H, Hk, D, **kw):
+    a = _cabi.FaBwdParams()
+    a.b, a.h, a.h_k, a.d = B, H, Hk, D
+    a.seqlen_q, a.seqlen_k, a.total_q, a.total_k = Sq, Sk, B * Sq, B * Sk
+    a.dtype = 1
+    a.softmax_scale = D ** -0.5
+    a.window_left = a.window_right = -1
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def _plan(lib, a):
+    out = (C.c_int32 * 8)()
+    assert lib.fa_bwd_plan_query(C.byref(a), out, 8) == 8
+    return list(out)
+
+
+def test_backward_plan_table(lib, monkeypatch):
+    """Round 6 (fa_api.cpp bwd_fused_by_table): the fused 5-contraction launch is the default at head dim 128 under a causal mask from 1k to 2k rows while its dS
+    workspace fits 1 GiB -- where it was measured ahead -- and nowhere else; knobs that pin a kernel of the recomputing pair keep the pair."""
+    for v in ("FA_BWD_MODE", "FA_BWD_DQ_NW", "FA_BWD_DKDV", "FA_STRICT"):
+        monkeypatch.delenv(v, raising=False)
+    lib.fa_knobs_reload()
+    plan = lambda *a, **kw: _plan(lib, _bwd_params(*a, **kw))[0]
+    assert plan(16, 1024, 1024, 16, 16, 128, is_causal=1) == 3            # the sweep's rows: 0.5 GiB / 1 GiB of dS
+    assert plan(8, 2048, 2048, 16, 16, 128, is_causal=1) == 3
+    assert plan(8, 2048, 2048, 32, 32, 128, is_causal=1) == 0             # 2 GiB: over the bound
+    assert plan(32, 512, 512, 16, 16, 128, is_causal=1) == 0              # measured behind at S = 512 ...
+    assert plan(4, 4096, 4096, 32, 32, 128, is_causal=1) == 0             # ... a tie from S = 4096 (config 3 stays on the scratch-free pair)
+    assert plan(16, 1024, 1024, 16, 16, 128) == 0                         # ... behind without a mask
+    assert plan(16, 1024, 1024, 32, 32, 64, is_causal=1) == 0             # ... and at head dim 64
+    assert plan(16, 1024, 1024, 16, 16, 128, is_causal=1, window_left=256) == 0
+    assert plan(16, 1024, 1024, 16, 16, 128, is_causal=1, softcap=30.0) == 0
+    assert plan(16, 1024, 2048, 16, 16, 128, is_causal=1) == 0            # sq != sk: not measured
+    a = _bwd_params(16, 1024, 1024, 16, 16, 128, is_causal=1)
+    assert lib.fa_bwd_workspace_bytes(C.byref(a)) >= 16 * 16 * 32 * 32 * 2048   # the binders size the workspace from this
+    for knob, val in (("FA_BWD_MODE", "-1"), ("FA_BWD_MODE", "1"), ("FA_BWD_DQ_NW", "4"), ("FA_BWD_DKDV", "8"), ("FA_STRICT", "1")):
+        monkeypatch.setenv(knob, val); lib.fa_knobs_reload()
+        try:
+            assert plan(16, 1024, 1024, 16, 16, 128, is_causal=1) == 0, (knob, val)
+        finally:
+            monkeypatch.delenv(knob); lib.fa_knobs_reload()
+
+
+def test_chunked_five_contraction_plan(lib, monkeypatch):
+    """FA_BWD_MODE=5 (fa_api.cpp bwd_c5_plan): chunks of whole XCD rounds under FA_BWD_C5_CAP_MB, two slots; rows of a slot packed in 64-key pairs
+    (csrc/fa_device.h ds_row_start): a head's sub-tile count must equal the sum over its 32-row blocks of the pairs each can see."""
+    monkeypatch.setenv("FA_BWD_MODE", "5"); lib.fa_knobs_reload()
+    try:
+        def pairs_seen(Sq, Sk, wr):   # brute force: per 32-row block, the 64-key pairs up to the last visible key sub-tile
+            np64, tot = (Sk + 63) // 64, 0
+            for i in range((Sq + 31) // 32):
+                last32 = (Sk + 31) // 32 - 1 if wr < 0 else min((Sk + 31) // 32 - 1 + 10 ** 9, (32 * i + 31 + (Sk - Sq) + wr) // 32)
+                tot += min(np64, last32 // 2 + 1)
+            return 2 * tot
+        for (B, Sq, Sk, H, Hk, D, causal, wr) in ((4, 4096, 4096, 32, 32, 128, 1, -1), (2, 1000, 1024, 32, 8, 64, 1, -1), (1, 300, 333, 2, 2, 128, 0, -1), (1, 640, 900, 2, 2, 128, 0, 100),
+                                                  (3, 1536, 1536, 8, 8, 128, 1, -1), (1, 256, 256, 1, 1, 64, 0, -1), (1, 777, 1000, 3, 1, 128, 0, 37)):
+            p = _plan(lib, _bwd_params(B, Sq, Sk, H, Hk, D, is_causal=causal, window_right=wr))
+            assert p[0] == 5, p
+            assert p[3] == pairs_seen(Sq, Sk, 0 if causal else wr), (B, Sq, Sk, causal, wr, p)
+            assert p[4] == (Sk + 63) // 64
+            rounds = (B * Hk + 7) // 8
+            assert p[1] * p[2] >= rounds and (p[1] - 1) * p[2] < rounds                     # the chunks cover the rounds, none is empty
+            slot = 8 * p[2] * (H // Hk) * p[3] * 2048
+            assert 2 * slot <= 1024 << 20 and p[7] == (((slot + 255) & ~255) >> 20)            # within the default bound
+            a = _bwd_params(B, Sq, Sk, H, Hk, D, is_causal=causal, window_right=wr)
+            assert lib.fa_bwd_workspace_bytes(C.byref(a)) == 2 * ((slot + 255) & ~255)
+        p = _plan(lib, _bwd_params(4, 4096, 4096, 32, 32, 128, is_causal=1))
+        assert p[1] >= 4                                                                      # config 3: 2.1 GB of (causal) dS through a 1 GiB workspace
+        # what it does not cover asks for nothing and keeps the pair
+        for kw in (dict(window_left=100), dict(softcap=30.0), dict(p_dropout=0.1), dict(alibi_slopes=1)):
+            assert _plan(lib, _bwd_params(4, 4096, 4096, 32, 32, 128, **kw))[0] == 0
+        assert _plan(lib, _bwd_params(4, 4096, 1024, 32, 32, 128, is_causal=1))[0] == 0       # sk < sq
+        assert _plan(lib, _bwd_params(1, 32768, 32768, 8, 1, 128))[0] == 0                    # one round of units (8 x 8 heads x 2 GiB) does not fit a slot
+        monkeypatch.setenv("FA_BWD_C5_CAP_MB", "128"); lib.fa_knobs_reload()   # (a round of this shape: 8 units x 4 heads x 1.1 MB of packed rows = 36 MB)
+        assert _plan(lib, _bwd_params(2, 1024, 1024, 32, 8, 128, is_causal=1))[1] >= 2
+    finally:
+        monkeypatch.delenv("FA_BWD_MODE", raising=False); monkeypatch.delenv("FA_BWD_C5_CAP_MB", raising=False); lib.fa_knobs_reload()

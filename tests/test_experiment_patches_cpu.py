@@ -1,5 +1,5 @@
-"""The timing-ablation switches, the dS-spill experiment and the feature pricing live OUTSIDE the product sources, as patches under experiments/ (applied to copies
-by tools/ablate_*.sh, experiments/build_experiments.py, tools/price_w64.sh).  A patch that no longer applies would silently take the measurement recipes of
+"""The timing-ablation switches and the feature pricing live OUTSIDE the product sources, as patches under experiments/ (applied to copies
+by tools/ablate_*.sh, tools/ab_c5_build.sh, tools/price_w64.sh).  A patch that no longer applies would silently take the measurement recipes of
 profiles/ away: every one of them must apply to the tree as it stands -- and the product kernel files must carry none of the switches themselves."""
 import glob
 import os
@@ -9,7 +9,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATCHES = sorted(glob.glob(os.path.join(ROOT, "experiments", "ablations", "*.patch"))) + [os.path.join(ROOT, "experiments", n) for n in ("ds_spill.patch", "fa_fwd_w64_price.patch")]
+PATCHES = sorted(glob.glob(os.path.join(ROOT, "experiments", "ablations", "*.patch"))) + [os.path.join(ROOT, "experiments", "fa_fwd_w64_price.patch")]
 
 
 @pytest.mark.parametrize("patch", PATCHES, ids=lambda p: os.path.relpath(p, ROOT))

@@ -2,7 +2,7 @@
 # file + experiments/ablations/<file>.patch) to gpurun_abl/src/ and compiles variants of that copy with -D flags; the tree itself is not touched.
 PKG=flash-attention_amd
 HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I $PKG/csrc -I include"
-ALL_OBJS="fa_fwd_bf16.o fa_fwd_f16.o fa_fwd_il.o fa_fwd_w64_bf16.o fa_fwd_w64_f16.o fa_bwd_dkdv.o fa_bwd_dq.o fa_bwd_fused.o fa_bwd_w64.o fa_bwd_dkdv_w64.o fa_api.o"
+ALL_OBJS="fa_fwd_bf16.o fa_fwd_f16.o fa_fwd_il.o fa_fwd_w64_bf16.o fa_fwd_w64_f16.o fa_bwd_dkdv.o fa_bwd_dq.o fa_bwd_fused.o fa_bwd_w64.o fa_bwd_dkdv_w64.o fa_bwd_c5.o fa_api.o"
 
 # abl_source fa_bwd_w64.hip -> gpurun_abl/src/fa_bwd_w64.hip (prints the path)
 abl_source() {

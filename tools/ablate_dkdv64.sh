@@ -9,7 +9,7 @@ if [ "$1" != "run" ]; then
   SRC=$(abl_source fa_bwd_dkdv_w64.hip)
   for v in $VARIANTS; do
     name=${v%%:*}; flags=$(echo "${v#*:}" | tr ',' ' ')
-    ( $HIPCC -fno-slp-vectorize $flags -c $SRC -o gpurun_abl/dk64_$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Spill|ScratchSize" | sort | uniq -c | sed "s/^/$name: /" ;
+    ( $HIPCC -fno-slp-vectorize -DFA_DKDV64_PART=1 $flags -c $SRC -o gpurun_abl/dk64_$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Spill|ScratchSize" | sort | uniq -c | sed "s/^/$name: /" ;
       abl_link gpurun_abl/libfa_dk64_$name.so fa_bwd_dkdv_w64.o gpurun_abl/dk64_$name.o && rm gpurun_abl/dk64_$name.o ) &
   done
   wait

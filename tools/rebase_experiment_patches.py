@@ -1,4 +1,4 @@
-"""After a product kernel file changed: carry the experiment patches (experiments/ablations/*.patch, experiments/ds_spill.patch, experiments/fa_fwd_w64_price.patch)
+"""After a product kernel file changed: carry the experiment patches (experiments/ablations/*.patch, experiments/fa_fwd_w64_price.patch)
 over to the new text.  For every file a patch touches: old product text = `git show REV:file` (REV defaults to HEAD), old patched text = that + the patch as committed
 at REV, new patched text = a three-way merge (git merge-file) of the working-tree file with the two, new patch = diff(working tree, new patched).  Conflicts are left
 in /tmp/rebase_patches/<file>.merged for a hand merge (the script says which); tests/test_experiment_patches_cpu.py checks the result applies.
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REV = sys.argv[1] if len(sys.argv) > 1 else "HEAD"
 TMP = "/tmp/rebase_patches"
 PATCHES = sorted(os.path.join("experiments", "ablations", f) for f in os.listdir(os.path.join(ROOT, "experiments", "ablations")) if f.endswith(".patch")) + \
-    ["experiments/ds_spill.patch", "experiments/fa_fwd_w64_price.patch"]
+    ["experiments/fa_fwd_w64_price.patch"]
 
 
 def git_show(path):

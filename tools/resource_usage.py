@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "flash-attention_amd", "csrc")
 UNITS = [("fa_fwd.hip", ["-DFA_FWD_PART=1"]), ("fa_fwd.hip", ["-DFA_FWD_PART=2"]), ("fa_fwd_il.hip", []), ("fa_fwd_w64.hip", ["-fno-slp-vectorize", "-DFA_W64_PART=1"]),
          ("fa_fwd_w64.hip", ["-fno-slp-vectorize", "-DFA_W64_PART=2"]), ("fa_bwd.hip", ["-DFA_BWD_PART=1"]), ("fa_bwd.hip", ["-DFA_BWD_PART=2"]), ("fa_bwd.hip", ["-DFA_BWD_PART=3"]),
-         ("fa_bwd_w64.hip", ["-fno-slp-vectorize"])]
+         ("fa_bwd_w64.hip", ["-fno-slp-vectorize"]), ("fa_bwd_dkdv_w64.hip", ["-fno-slp-vectorize", "-DFA_DKDV64_PART=1"]), ("fa_bwd_dkdv_w64.hip", ["-fno-slp-vectorize", "-DFA_DKDV64_PART=2"])]
 def unit(u):
     src, extra = u
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "--offload-device-only", "-Rpass-analysis=kernel-resource-usage"] + extra + \
