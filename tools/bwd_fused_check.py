@@ -8,7 +8,9 @@ import torch
 from flash_attn_amd import backend as be
 
 def run(mode, q, k, v, do, causal, wl=-1, wr=-1):
-    os.environ["FA_BWD_MODE"] = str(mode); os.environ["FA_BWD_FUSE_DELTA"] = "0"; be.reload_knobs()   # (softmax_d from the pre-pass in both: bitwise dK / dV)
+    # (softmax_d from the pre-pass in both, the eight-wave dK/dV kernel in both: bitwise dK / dV.  Mode 0 = the recomputing pair: round 6's table would send some of
+    # these shapes to the fused launch by itself, so the reference run pins -1)
+    os.environ["FA_BWD_MODE"] = str(-1 if mode == 0 else mode); os.environ["FA_BWD_FUSE_DELTA"] = "0"; os.environ["FA_BWD_DKDV"] = "8"; be.reload_knobs()
     D = q.shape[-1]
     out, lse, _, _ = be.fwd(q, k, v, None, None, 0.0, D ** -0.5, causal, wl, wr, 0.0, False, None)
     dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
@@ -69,7 +71,7 @@ def timings():
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         line = f"bwd B{B} S{S} H{H} D{D} c{int(causal)}:"
         for mode in (0, 3, 0, 3):
-            os.environ["FA_BWD_MODE"] = str(mode); os.environ.pop("FA_BWD_FUSE_DELTA", None); be.reload_knobs()
+            os.environ["FA_BWD_MODE"] = str(-1 if mode == 0 else mode); os.environ.pop("FA_BWD_FUSE_DELTA", None); os.environ.pop("FA_BWD_DKDV", None); be.reload_knobs()
             ms = t_ms(lambda: be.bwd(do, q, k, v, out, lse, dq, dk, dv, None, 0.0, D ** -0.5, causal, -1, -1, 0.0, False, None, None))
             fl = 10 * B * H * S * S * D / (2 if causal else 1)
             line += f"  [mode {mode}] {ms:.3f} ms {fl / ms / 1e9:.0f} TF (spill {be.last_schedule()['bwd_spill']})"
