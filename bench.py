@@ -187,8 +187,9 @@ def write_extras(obj):
 
 
 def fused_bwd_rows(be, dev, sync):
-    """Extra key `bwd_fused`: the opt-in fused 5-contraction backward (FA_BWD_MODE=3, fa_bwd.hip fa_bwd_fused_kernel; profiles/r04_bwd_fused.txt) next
-    to the default backward, timed alternately in this process: the headline shape and two shorter causal rows of the sweep.  Never fatal: a failure is
+    """Extra key `bwd_fused`: the 5-contraction backwards (the fused launch FA_BWD_MODE=3, fa_bwd.hip fa_bwd_fused_kernel, profiles/r04_bwd_fused.txt; the chunked
+    one FA_BWD_MODE=5, profiles/r06_bwd_c5.txt) next to the recomputing pair and to what the dispatch picks, timed alternately in this process: the headline shape
+    and two shorter causal rows of the sweep.  Never fatal: a failure is
     reported in the key; the knob is restored whatever happens."""
     rows = []
     try:
@@ -202,16 +203,20 @@ def fused_bwd_rows(be, dev, sync):
             h = lambda: be.bwd(g, q, k, v, o, l, dq, dk, dv, None, 0.0, sc, causal, -1, -1, 0.0, False, None, None)
             fl = 2.5 * fwd_flops(B, H, S, D, causal)
             row = {"batch": B, "heads": H, "seqlen": S, "head_dim": D, "causal": causal}
-            for mode, key in (("0", "default"), ("3", "fused"), ("0", "default_again"), ("3", "fused_again")):
+            # (round 6: "pair" = the recomputing 7-contraction pair pinned with FA_BWD_MODE=-1, "fused" = FA_BWD_MODE=3, "chunked5" = the chunked 5-contraction
+            # backward FA_BWD_MODE=5 within its default 1 GiB of workspace, "default" = what the dispatch table of fa_api.cpp picks by itself)
+            for mode, key in (("-1", "pair"), ("3", "fused"), ("5", "chunked5"), ("0", "default"), ("-1", "pair_again"), ("3", "fused_again")):
                 os.environ["FA_BWD_MODE"] = mode
                 be.reload_knobs()
                 _, mb = time_kernel(h, 8, 2, sync)
                 row[key + "_bwd_tflops"] = round(fl / mb / 1e9, 1)
                 if mode == "3":
                     row["fused_launched"] = be.last_schedule().get("bwd_spill") == 3
+                if mode in ("0", "5"):
+                    row[key + "_handoff"] = be.last_schedule().get("bwd_spill")   # 0 = recomputing pair, 3 = fused launch, 5 = chunked launches
             row["workspace_gb"] = round(B * H * (S // 32) ** 2 * 2048 / 2 ** 30, 2)
             rows.append(row)
-        return {"rows": rows, "note": "FA_BWD_MODE=3 is opt-in: O(S^2) dS workspace"}
+        return {"rows": rows, "note": "default = the table of fa_api.cpp bwd_fused_by_table: the fused launch at head dim 128 under a causal mask from 1k to 2k rows within 1 GiB, else the pair"}
     except Exception as e:  # noqa: BLE001
         return {"rows": rows, "error": repr(e)[:300]}
     finally:
