@@ -487,14 +487,19 @@ void bwd_list_entries(const FaBwdParams* a, int64_t& q_entries, int64_t& k_entri
 // superseded by FA_BWD_MODE=5 below: the same idea on the 64-per-wave kernels with a bounded workspace; git history keeps the old experiment.)
 // Fused backward (FA_BWD_MODE=3, fa_bwd.hip fa_bwd_fused_kernel): bytes of the dS workspace (256-B aligned) when the call qualifies, else 0; the sync
 // area (fa_kernel_params.h FZ_*) sits behind it.  Same conditions as launch_bwd_fused.
-// Round 6: it is the DEFAULT (FA_BWD_MODE=0) where it was measured ahead of the recomputing pair and its workspace stays within 1 GiB: head dim 128 under a causal
-// mask from 1k to 2k rows (+6 % at S = 1024, +9 % at S = 2048 on the sweep's shapes, profiles/r06_bwd_c5.txt: there the recomputing dQ pass runs the 32-rows-per-wave
-// kernel); it loses at S = 512, without a mask, at head dim 64, and ties from S = 4096.  FA_BWD_MODE=3 forces it wherever it applies (cap FA_BWD_DS_CAP_MB), -1 / 1 never.
+// Round 6: it is the DEFAULT (FA_BWD_MODE=0) where it was measured ahead of the recomputing pair and its workspace stays within 1 GiB (profiles/r06_bwd_c5.txt (5), timed
+// WITHOUT the status read -- a stream sync per call, which the default path does not do and which cost the launch 9 % at S = 1024): head dim 128, Sq = Sk, at least
+// 32 (batch, kv head) units, under a causal mask from 512 to 2048 rows (+8 % / +18 % / +15 % at S = 512 / 1024 / 2048; there the recomputing dQ pass runs the
+// 32-rows-per-wave kernel) and without a mask from 512 to 1024 rows (+1.5 % / +5.6 %).  It ties at causal S = 4096 (and would need > 1 GiB there), loses at S = 8192
+// (-8 %), without a mask from S = 2048 (-6 ... -10 %), at head dim 64 without a mask (-20 %; causal +3 % / -1 %: left to the pair) and on small grids (16 units: -3 %).
+// FA_BWD_MODE=3 forces it wherever it applies (cap FA_BWD_DS_CAP_MB), -1 / 1 never.
 bool bwd_fused_by_table(const FaBwdParams* a) {
   int causal = a->is_causal, wl = a->window_left, wr = a->window_right;
   normalize_window(a->seqlen_q, a->seqlen_k, false, causal, wl, wr);
-  return a->d == 128 && wl < 0 && wr == 0 && a->seqlen_q == a->seqlen_k && a->seqlen_q >= 1024 && a->seqlen_q <= 2048 && fa::knobs().bwd_dq_nw == 0 && fa::knobs().bwd_dkdv == 0 &&
-         !fa::knobs().dkdv_prescale && !fa::knobs().strict;
+  if (a->d != 128 || wl >= 0 || a->seqlen_q != a->seqlen_k || (long)a->b * a->h_k < 32) return false;
+  if (fa::knobs().bwd_dq_nw != 0 || fa::knobs().bwd_dkdv != 0 || fa::knobs().dkdv_prescale || fa::knobs().strict) return false;
+  const int s = a->seqlen_q;
+  return (wr == 0 && s >= 512 && s <= 2048) || (wr < 0 && s >= 512 && s <= 1024);
 }
 int64_t bwd_fused_ds_bytes(const FaBwdParams* a) {
   const int mode = fa::knobs().bwd_mode;
@@ -800,7 +805,7 @@ int fa_bwd_fused_status(const FaBwdParams* params, void* stream) {
   // Reading the flag synchronises the stream.  Where the fused backward is the DEFAULT (round 6: the table of bwd_fused_by_table) the binders' call returns at once --
   // a host sync per backward is not acceptable there, and the flag guards a wait that cannot time out while the launch's workgroups run (the publisher a consumer
   // polls for is between two of its own instructions); FA_BWD_MODE=3 (the opt-in form) and FA_BWD_FUSED_CHECK=1 read it.
-  if (fa::knobs().bwd_mode != 3 && !fa::knobs().bwd_fused_check) return FA_OK;
+  if (fa::knobs().bwd_fused_check < 0 || (fa::knobs().bwd_mode != 3 && !fa::knobs().bwd_fused_check)) return FA_OK;   // (-1: never, also for FA_BWD_MODE=3 -- timing the launch without the sync)
   const int64_t fz = bwd_fused_ds_bytes(params);
   if (fz <= 0 || params->workspace_bytes < fz + bwd_fused_sync_bytes(params)) return FA_OK;   // the call did not (could not) take the fused path
   int32_t flag = 0;

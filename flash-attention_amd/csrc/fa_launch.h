@@ -24,7 +24,7 @@ struct Knobs {
   int bwd_c5_cap_mb;   // FA_BWD_C5_CAP_MB: workspace bound of the 5-contraction backward, both slots together (default 1024)
   int fz_line;         // FA_FZ_LINE: fused backward, int32 words between two arrival counters of the sync area (default 32 = one 128-byte line each)
   int bwd_ds_cap_mb;   // FA_BWD_DS_CAP_MB: largest dS workspace FA_BWD_MODE=3 asks for (default 8192)
-  int bwd_fused_check; // FA_BWD_FUSED_CHECK=1: fa_bwd_fused_status reads the fused launch's error flag (a stream sync) also where the fused backward ran by default
+  int bwd_fused_check; // FA_BWD_FUSED_CHECK=-1: never read the flag, not even for FA_BWD_MODE=3 (A/B timings of the launch itself); =1: fa_bwd_fused_status reads the fused launch's error flag (a stream sync) also where the fused backward ran by default
   int w64_persist;     // FA_W64_PERSIST: 0 = one workgroup per block (no persistent walk) in the 64-rows-per-wave forward
   int pack_gqa;        // FA_PACK_GQA: 0 = never pack the query heads of a KV group into the rows of a block on the KV-cache path (A/B, tests)
   int dkdv_prescale;   // FA_DKDV_PRESCALE=1: the plain dK/dV kernel pre-scales K by softmax_scale*log2e (rounded to the input dtype; ~3 % faster, fa_bwd.hip: PRE);

@@ -63,8 +63,9 @@ def test_default_picks_it_from_2k_query_rows_at_head_dim_128(be):
         k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
         g = run_bwd(be, q, k, v, do, causal)
         assert g[3]["bwd_dkdv_nw"] == want and g[3]["bwd_spill"] == 0, (S, d, g[3])
-    # (round 6: head dim 128 under a causal mask from 1k to 2k rows is the fused launch's by default -- its dK/dV part is the eight-wave kernel's text)
-    q = torch.randn(1, 2048, 2, 128, device="cuda", dtype=torch.bfloat16)
+    # (round 6: head dim 128 under a causal mask from 512 to 2k rows, from 32 (batch, kv head) units on, is the fused launch's by default -- its dK/dV part is the
+    # eight-wave kernel's text)
+    q = torch.randn(16, 2048, 2, 128, device="cuda", dtype=torch.bfloat16)
     k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
     assert run_bwd(be, q, k, v, do, True)[3]["bwd_spill"] == 3
     q = torch.randn(1, 4096, 2, 128, device="cuda", dtype=torch.bfloat16)

@@ -102,11 +102,13 @@ def test_dq_w64_default_dispatch_and_fallbacks(be, knobs):
     torch.manual_seed(1)
     q = torch.randn(1, 2048, 2, 128, device="cuda", dtype=torch.bfloat16)
     k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
-    knobs.set("FA_BWD_MODE", -1)   # (the recomputing pair's own dispatch: round 6 gives plain causal attention at 1k - 2k rows to the fused launch by default)
+    knobs.set("FA_BWD_MODE", -1)   # (the recomputing pair's own dispatch: round 6 gives plain causal attention at 512 - 2k rows to the fused launch by default, from 32 units on)
     assert run_bwd(be, q, k, v, do, True)[3]["bwd_dq_nw"] == 64
     assert run_bwd(be, q[:, :1024], k[:, :1024], v[:, :1024], do[:, :1024], True)[3]["bwd_dq_nw"] == 4
     knobs.unset("FA_BWD_MODE")
-    assert run_bwd(be, q, k, v, do, True)[3]["bwd_spill"] == 3 and run_bwd(be, q, k, v, do, False)[3]["bwd_dq_nw"] == 64
+    assert run_bwd(be, q, k, v, do, True)[3]["bwd_spill"] == 0 and run_bwd(be, q, k, v, do, False)[3]["bwd_dq_nw"] == 64   # (two units: the pair)
+    q16 = torch.randn(16, 2048, 2, 128, device="cuda", dtype=torch.bfloat16)
+    assert run_bwd(be, q16, torch.randn_like(q16), torch.randn_like(q16), torch.randn_like(q16), True)[3]["bwd_spill"] == 3
     assert run_bwd(be, q, k, v, do, True, p_drop=0.1)[3]["bwd_dq_nw"] == 64
     assert run_bwd(be, q, k, v, do, True, softcap=20.0)[3]["bwd_dq_nw"] == 64
     assert run_bwd(be, q, k, v, do, True, p_drop=0.1, softcap=20.0)[3]["bwd_dq_nw"] == 4

@@ -191,8 +191,9 @@ def _plan(lib, a):
 
 
 def test_backward_plan_table(lib, monkeypatch):
-    """Round 6 (fa_api.cpp bwd_fused_by_table): the fused 5-contraction launch is the default at head dim 128 under a causal mask from 1k to 2k rows while its dS
-    workspace fits 1 GiB -- where it was measured ahead -- and nowhere else; knobs that pin a kernel of the recomputing pair keep the pair."""
+    """Round 6 (fa_api.cpp bwd_fused_by_table): the fused 5-contraction launch is the default at head dim 128 with Sq = Sk and at least 32 (batch, kv head) units, under a
+    causal mask from 512 to 2048 rows and without a mask from 512 to 1024 rows, while its dS workspace fits 1 GiB -- where it was measured ahead -- and nowhere
+    else; knobs that pin a kernel of the recomputing pair keep the pair."""
     for v in ("FA_BWD_MODE", "FA_BWD_DQ_NW", "FA_BWD_DKDV", "FA_STRICT"):
         monkeypatch.delenv(v, raising=False)
     lib.fa_knobs_reload()
@@ -200,9 +201,14 @@ def test_backward_plan_table(lib, monkeypatch):
     assert plan(16, 1024, 1024, 16, 16, 128, is_causal=1) == 3            # the sweep's rows: 0.5 GiB / 1 GiB of dS
     assert plan(8, 2048, 2048, 16, 16, 128, is_causal=1) == 3
     assert plan(8, 2048, 2048, 32, 32, 128, is_causal=1) == 0             # 2 GiB: over the bound
-    assert plan(32, 512, 512, 16, 16, 128, is_causal=1) == 0              # measured behind at S = 512 ...
-    assert plan(4, 4096, 4096, 32, 32, 128, is_causal=1) == 0             # ... a tie from S = 4096 (config 3 stays on the scratch-free pair)
-    assert plan(16, 1024, 1024, 16, 16, 128) == 0                         # ... behind without a mask
+    assert plan(32, 512, 512, 16, 16, 128, is_causal=1) == 3              # +8 % at S = 512
+    assert plan(64, 256, 256, 16, 16, 128, is_causal=1) == 0              # a tie at S = 256
+    assert plan(4, 4096, 4096, 32, 32, 128, is_causal=1) == 0             # a tie from S = 4096 (config 3 stays on the scratch-free pair)
+    assert plan(2, 8192, 8192, 16, 16, 128, is_causal=1) == 0
+    assert plan(16, 1024, 1024, 16, 16, 128) == 3                         # without a mask: +5.6 % at S = 1024 ...
+    assert plan(8, 2048, 2048, 16, 16, 128) == 0                          # ... behind from S = 2048
+    assert plan(2, 2048, 2048, 32, 8, 128, is_causal=1) == 0              # 16 (batch, kv head) units: measured behind
+    assert plan(4, 1024, 1024, 32, 8, 128, is_causal=1) == 3              # 32 units, four query heads each: +8 %
     assert plan(16, 1024, 1024, 32, 32, 64, is_causal=1) == 0             # ... and at head dim 64
     assert plan(16, 1024, 1024, 16, 16, 128, is_causal=1, window_left=256) == 0
     assert plan(16, 1024, 1024, 16, 16, 128, is_causal=1, softcap=30.0) == 0

@@ -1,5 +1,5 @@
-"""Random shapes inside the region where round 6's dispatch table gives the backward to the fused launch BY DEFAULT (head dim 128, causal, Sq = Sk in 1024 .. 2048,
-dS workspace <= 1 GiB): the default against the recomputing pair pinned onto the same dK/dV kernel text (dK / dV bitwise, dQ within rounding and within the
+"""Random shapes inside the region where round 6's dispatch table gives the backward to the fused launch BY DEFAULT (head dim 128, Sq = Sk, >= 32 (batch, kv head) units, causal 512 .. 2048 rows or
+no mask 512 .. 1024 rows, dS workspace <= 1 GiB): the default against the recomputing pair pinned onto the same dK/dV kernel text (dK / dV bitwise, dQ within rounding and within the
 reference's rule against fp32), twice (bitwise), through the autograd interface as well.  usage: python tools/bwd_table_stress.py [cases] [seed]"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,13 +8,13 @@ import torch
 from flash_attn_amd import backend as be
 from tests.test_bwd_schedules_gpu import ref_grads
 
-def run(env, q, k, v, do):
+def run(env, q, k, v, do, causal=True):
     for kk in ("FA_BWD_MODE", "FA_BWD_FUSE_DELTA", "FA_BWD_DKDV"): os.environ.pop(kk, None)
     os.environ.update(env); be.reload_knobs()
     D = q.shape[-1]
-    out, lse, _, _ = be.fwd(q, k, v, None, None, 0.0, D ** -0.5, True, -1, -1, 0.0, False, None)
+    out, lse, _, _ = be.fwd(q, k, v, None, None, 0.0, D ** -0.5, causal, -1, -1, 0.0, False, None)
     dq, dk, dv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")), torch.full_like(v, float("nan"))
-    be.bwd(do, q, k, v, out, lse, dq, dk, dv, None, 0.0, D ** -0.5, True, -1, -1, 0.0, False, None, None)
+    be.bwd(do, q, k, v, out, lse, dq, dk, dv, None, 0.0, D ** -0.5, causal, -1, -1, 0.0, False, None, None)
     torch.cuda.synchronize()
     return dq, dk, dv, dict(be.last_schedule())
 
@@ -23,24 +23,25 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 os.environ["FA_DEBUG_POISON_WS"] = "1"
 bad = 0
 for i in range(n):
-    S = rng.choice([1024, 2048, rng.randint(1024, 2048), rng.randint(1024, 2048)])
+    causal = rng.random() < 0.7
+    S = rng.choice([512, 1024, 2048, rng.randint(512, 2048), rng.randint(512, 2048)]) if causal else rng.choice([512, 1024, rng.randint(512, 1024)])
     Hk = rng.choice([1, 2, 3, 4, 8]); g = rng.choice([1, 1, 2, 4]); H = Hk * g
     Bmax = max(1, (1 << 30) // (H * ((S + 31) // 32) ** 2 * 2048))
-    B = rng.randint(1, min(9, Bmax))
+    B = rng.randint(max(1, -(-32 // Hk)), max(-(-32 // Hk), min(40, Bmax)))
     dt = rng.choice([torch.bfloat16, torch.float16])
     torch.manual_seed(i)
     q = torch.randn(B, S, H, 128, device="cuda", dtype=dt); k = torch.randn(B, S, Hk, 128, device="cuda", dtype=dt); v = torch.randn_like(k); do = torch.randn_like(q)
-    d = run({}, q, k, v, do); d2 = run({}, q, k, v, do)
-    p = run({"FA_BWD_MODE": "-1", "FA_BWD_FUSE_DELTA": "0", "FA_BWD_DKDV": "8"}, q, k, v, do)
+    d = run({}, q, k, v, do, causal); d2 = run({}, q, k, v, do, causal)
+    p = run({"FA_BWD_MODE": "-1", "FA_BWD_FUSE_DELTA": "0", "FA_BWD_DKDV": "8"}, q, k, v, do, causal)
     ok = d[3]["bwd_spill"] == 3 and p[3]["bwd_spill"] == 0 and all(torch.equal(a, b) for a, b in zip(d[:3], d2[:3])) and torch.equal(d[1], p[1]) and torch.equal(d[2], p[2])
     ok = ok and all(bool(torch.isfinite(x.float()).all()) for x in d[:3])
     e = ""
     if B * H * S * S <= 2 ** 27:
-        r = ref_grads(q, k, v, do, True, -1, -1); pt = ref_grads(q, k, v, do, True, -1, -1, upcast=False)
+        r = ref_grads(q, k, v, do, causal, -1, -1); pt = ref_grads(q, k, v, do, causal, -1, -1, upcast=False)
         ed, ep, et = (float((x.float() - r[0]).abs().max()) for x in (d[0], p[0], pt[0]))
         ok = ok and ed <= 3 * et + 1e-5 and ed <= 2 * ep + 1e-5
         e = f" dq err default {ed:.2e} pair {ep:.2e} torch-in-dtype {et:.2e}"
     bad += not ok
-    print(f"{'ok ' if ok else 'BAD'} {str(dt)[6:]} B{B} S{S} H{H}/{Hk}: default spill {d[3]['bwd_spill']}{e}", flush=True)
+    print(f"{'ok ' if ok else 'BAD'} {str(dt)[6:]} B{B} S{S} H{H}/{Hk} c{int(causal)}: default spill {d[3]['bwd_spill']}{e}", flush=True)
 print("FAILURES", bad)
 sys.exit(1 if bad else 0)
