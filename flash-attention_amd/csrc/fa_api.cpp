@@ -489,9 +489,10 @@ void bwd_list_entries(const FaBwdParams* a, int64_t& q_entries, int64_t& k_entri
 // area (fa_kernel_params.h FZ_*) sits behind it.  Same conditions as launch_bwd_fused.
 // Round 6: it is the DEFAULT (FA_BWD_MODE=0) where it was measured ahead of the recomputing pair and its workspace stays within 1 GiB (profiles/r06_bwd_c5.txt (5), timed
 // WITHOUT the status read -- a stream sync per call, which the default path does not do and which cost the launch 9 % at S = 1024): head dim 128, Sq = Sk, at least
-// 32 (batch, kv head) units, under a causal mask from 512 to 2048 rows (+8 % / +18 % / +15 % at S = 512 / 1024 / 2048; there the recomputing dQ pass runs the
-// 32-rows-per-wave kernel) and without a mask from 512 to 1024 rows (+1.5 % / +5.6 %).  It ties at causal S = 4096 (and would need > 1 GiB there), loses at S = 8192
-// (-8 %), without a mask from S = 2048 (-6 ... -10 %), at head dim 64 without a mask (-20 %; causal +3 % / -1 %: left to the pair) and on small grids (16 units: -3 %).
+// 32 (batch, kv head) units, under a causal mask from 512 to 4096 rows (+8 % / +18 % / +15 % at S = 512 / 1024 / 2048 on the sweep's shapes, +7 ... +9 % at S = 3072 and
+// +9 ... +13 % at S = 4096 on the grids that fit the 1 GiB -- 32 heads) and without a mask from 512 to 1536 rows (+1.5 % / +5 % / +5.6 % / +3 ... +5 % at 512 / 768 / 1024 / 1536).
+// Where the workspace would exceed 1 GiB it ties or loses anyway (config 3: a tie on 4 GiB; S = 4096 on 64 heads +3 % on 2 GiB; S = 8192 -8 %); without a mask from
+// S = 2048 -6 ... -10 %; head dim 64 without a mask -20 % (causal +3 % / -1 %: left to the pair); small grids (16 units) -3 %.
 // FA_BWD_MODE=3 forces it wherever it applies (cap FA_BWD_DS_CAP_MB), -1 / 1 never.
 bool bwd_fused_by_table(const FaBwdParams* a) {
   int causal = a->is_causal, wl = a->window_left, wr = a->window_right;
@@ -499,7 +500,7 @@ bool bwd_fused_by_table(const FaBwdParams* a) {
   if (a->d != 128 || wl >= 0 || a->seqlen_q != a->seqlen_k || (long)a->b * a->h_k < 32) return false;
   if (fa::knobs().bwd_dq_nw != 0 || fa::knobs().bwd_dkdv != 0 || fa::knobs().dkdv_prescale || fa::knobs().strict) return false;
   const int s = a->seqlen_q;
-  return (wr == 0 && s >= 512 && s <= 2048) || (wr < 0 && s >= 512 && s <= 1024);
+  return (wr == 0 && s >= 512 && s <= 4096) || (wr < 0 && s >= 512 && s <= 1536);
 }
 int64_t bwd_fused_ds_bytes(const FaBwdParams* a) {
   const int mode = fa::knobs().bwd_mode;

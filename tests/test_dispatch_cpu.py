@@ -192,7 +192,7 @@ def _plan(lib, a):
 
 def test_backward_plan_table(lib, monkeypatch):
     """Round 6 (fa_api.cpp bwd_fused_by_table): the fused 5-contraction launch is the default at head dim 128 with Sq = Sk and at least 32 (batch, kv head) units, under a
-    causal mask from 512 to 2048 rows and without a mask from 512 to 1024 rows, while its dS workspace fits 1 GiB -- where it was measured ahead -- and nowhere
+    causal mask from 512 to 4096 rows and without a mask from 512 to 1536 rows, while its dS workspace fits 1 GiB -- where it was measured ahead -- and nowhere
     else; knobs that pin a kernel of the recomputing pair keep the pair."""
     for v in ("FA_BWD_MODE", "FA_BWD_DQ_NW", "FA_BWD_DKDV", "FA_STRICT"):
         monkeypatch.delenv(v, raising=False)
@@ -203,7 +203,10 @@ def test_backward_plan_table(lib, monkeypatch):
     assert plan(8, 2048, 2048, 32, 32, 128, is_causal=1) == 0             # 2 GiB: over the bound
     assert plan(32, 512, 512, 16, 16, 128, is_causal=1) == 3              # +8 % at S = 512
     assert plan(64, 256, 256, 16, 16, 128, is_causal=1) == 0              # a tie at S = 256
-    assert plan(4, 4096, 4096, 32, 32, 128, is_causal=1) == 0             # a tie from S = 4096 (config 3 stays on the scratch-free pair)
+    assert plan(4, 4096, 4096, 32, 32, 128, is_causal=1) == 0             # config 3: 4 GiB of dS -- over the bound (and a tie): the scratch-free pair
+    assert plan(1, 4096, 4096, 32, 32, 128, is_causal=1) == 3             # the same rows on 32 heads fit: +9 ... +13 %
+    assert plan(1, 3072, 3072, 32, 32, 128, is_causal=1) == 3 and plan(2, 3072, 3072, 32, 32, 128, is_causal=1) == 0   # (1.2 GiB: over the bound)
+    assert plan(4, 1536, 1536, 32, 32, 128) == 3                          # without a mask up to 1536 rows
     assert plan(2, 8192, 8192, 16, 16, 128, is_causal=1) == 0
     assert plan(16, 1024, 1024, 16, 16, 128) == 3                         # without a mask: +5.6 % at S = 1024 ...
     assert plan(8, 2048, 2048, 16, 16, 128) == 0                          # ... behind from S = 2048

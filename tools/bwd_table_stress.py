@@ -24,9 +24,11 @@ os.environ["FA_DEBUG_POISON_WS"] = "1"
 bad = 0
 for i in range(n):
     causal = rng.random() < 0.7
-    S = rng.choice([512, 1024, 2048, rng.randint(512, 2048), rng.randint(512, 2048)]) if causal else rng.choice([512, 1024, rng.randint(512, 1024)])
+    S = rng.choice([512, 1024, 2048, 4096, rng.randint(512, 4096), rng.randint(512, 2048)]) if causal else rng.choice([512, 1024, 1536, rng.randint(512, 1536)])
     Hk = rng.choice([1, 2, 3, 4, 8]); g = rng.choice([1, 1, 2, 4]); H = Hk * g
     Bmax = max(1, (1 << 30) // (H * ((S + 31) // 32) ** 2 * 2048))
+    if -(-32 // Hk) > Bmax:   # (32 units of this shape do not fit 1 GiB: outside the table's region -- draw again)
+        S = rng.choice([512, 1024]); Bmax = max(1, (1 << 30) // (H * ((S + 31) // 32) ** 2 * 2048))
     B = rng.randint(max(1, -(-32 // Hk)), max(-(-32 // Hk), min(40, Bmax)))
     dt = rng.choice([torch.bfloat16, torch.float16])
     torch.manual_seed(i)
