@@ -502,12 +502,25 @@ bool bwd_fused_by_table(const FaBwdParams* a) {
   const int s = a->seqlen_q;
   return (wr == 0 && s >= 512 && s <= 4096) || (wr < 0 && s >= 512 && s <= 1536);
 }
+struct FusedPack { int np64, c1, jb, head_tiles; };
+FusedPack fused_pack(int sq, int sk, int wr) {   // the row packing of the dS workspace (as C5Plan's)
+  FusedPack f;
+  f.np64 = (sk + 63) / 64;
+  f.c1 = wr >= 0 ? (int)std::min<int64_t>(2 * f.np64, ((int64_t)31 + (sk - sq) + wr) / 32 + 2) : 2 * f.np64;
+  f.jb = std::max(0, 2 * f.np64 - f.c1);
+  f.head_tiles = fa::ds_row_start((sq + 31) / 32, f.c1, f.jb, f.np64);
+  return f;
+}
 int64_t bwd_fused_ds_bytes(const FaBwdParams* a) {
   const int mode = fa::knobs().bwd_mode;
   if ((mode != 3 && mode != 0) || a->cu_seqlens_q || a->cu_seqlens_k || a->seqused_q || a->seqused_k || (a->d != 128 && a->d != 64)) return 0;
   if (a->seqlen_q <= 0 || a->seqlen_k < a->seqlen_q || a->window_left >= 0 || a->softcap > 0.f || a->alibi_slopes || a->p_dropout > 0.f) return 0;
   if (mode == 0 && !bwd_fused_by_table(a)) return 0;
-  const int64_t bytes = (int64_t)a->b * a->h * ((a->seqlen_q + 31) / 32) * ((a->seqlen_k + 31) / 32) * 2048;
+  // (round 6: packed rows, fa_device.h ds_row_start -- a causal mask stores its triangle: half of B*H*Sq*Sk*2 bytes)
+  int causal = a->is_causal, wl = a->window_left, wr = a->window_right;
+  normalize_window(a->seqlen_q, a->seqlen_k, false, causal, wl, wr);
+  const FusedPack fp = fused_pack(a->seqlen_q, a->seqlen_k, wr);
+  const int64_t bytes = (int64_t)a->b * a->h * fp.head_tiles * 2048;
   const int64_t cap = mode == 0 ? ((int64_t)1 << 30) : ((int64_t)fa::knobs().bwd_ds_cap_mb << 20);
   return bytes > cap ? 0 : ((bytes + 255) & ~(int64_t)255);
 }
@@ -599,6 +612,7 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
     k.ds_ws = a->workspace;
     k.ds_nq32 = (a->seqlen_q + 31) / 32;
     k.ds_nk32 = (a->seqlen_k + 31) / 32;
+    { const FusedPack fp = fused_pack(a->seqlen_q, a->seqlen_k, k.wr); k.ds_np64 = fp.np64; k.ds_c1 = fp.c1; k.ds_jb = fp.jb; k.ds_head_tiles = fp.head_tiles; }
     k.nmb = (a->seqlen_q + 255) / 256;
     k.fuse_sync = (int32_t*)((char*)a->workspace + fz);
     k.fuse_items = a->b * a->h * k.nmb;

@@ -477,11 +477,17 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dsfrag[0][j] = (E)0.f; dsfrag[1][j] = (E)0.f; }
       }
-      E* dst = (E*)p.ds_ws + (((((int64_t)b * p.h + item_head(it)) * p.ds_nq32 + (q0 >> 5)) * p.ds_nk32 + (wk0 >> 5)) << 10) + ds_slot(ki, hi) * 8;
+      // (round 6: rows packed as in the chunked path -- fa_device.h ds_row_start: under a causal mask row block i holds only the key pairs it can see, half the workspace)
+      E* dst = (E*)p.ds_ws + ((((int64_t)b * p.h + item_head(it)) * p.ds_head_tiles + ds_row_start(q0 >> 5, p.ds_c1, p.ds_jb, p.ds_np64) + (wk0 >> 5)) << 10) + ds_slot(ki, hi) * 8;
+      // (every wave of the workgroup computes this query sub-block as soon as ONE of the block's 256 keys is visible to it: a wave whose own 32 keys lie behind the
+      // packed row's last pair holds zeros nobody reads -- and no slot: it must not store, the next row starts there)
+      const bool in_row = (wk0 >> 5) < 2 * min(((q0 >> 5) + p.ds_c1) >> 1, p.ds_np64);
       if constexpr (FUSED) {   // read by another workgroup of the SAME launch: written through (sc1), see fa_bwd_fused_kernel
-        st_global_16B_sc1(dst, __builtin_bit_cast(u32x4, dsfrag[0]));
-        st_global_16B_sc1(dst + 512, __builtin_bit_cast(u32x4, dsfrag[1]));
-      } else {
+        if (in_row) {
+          st_global_16B_sc1(dst, __builtin_bit_cast(u32x4, dsfrag[0]));
+          st_global_16B_sc1(dst + 512, __builtin_bit_cast(u32x4, dsfrag[1]));
+        }
+      } else if (in_row) {
         *(u32x4*)dst = __builtin_bit_cast(u32x4, dsfrag[0]);
         *(u32x4*)(dst + 512) = __builtin_bit_cast(u32x4, dsfrag[1]);
       }
@@ -648,7 +654,9 @@ static __device__ __forceinline__ void fa_bwd_dq_from_ds(const BwdK& p, char FA_
   const int n_max = (kmax >= kmin) ? (kmax / BN + 1) : n_min;
   const int w_row0 = m0 + wave * 32;
   const bool wave_valid = w_row0 < sq;
-  const E* __restrict__ ds_row = (const E*)p.ds_ws + (((((int64_t)b * p.h + h) * p.ds_nq32) + (w_row0 >> 5)) * p.ds_nk32 << 10) + lane * 8;
+  const int w_q32 = min(w_row0 >> 5, p.ds_nq32 - 1);
+  const E* __restrict__ ds_row = (const E*)p.ds_ws + ((((int64_t)b * p.h + h) * p.ds_head_tiles + ds_row_start(w_q32, p.ds_c1, p.ds_jb, p.ds_np64)) << 10) + lane * 8;
+  const int row_cnt = 2 * min((w_q32 + p.ds_c1) >> 1, p.ds_np64);   // sub-tiles this packed row holds: nothing is fetched from behind it
 
   constexpr int RPD = 1024 / ROW_BYTES, NDMA = TILE_BYTES / 1024, DPW = NDMA / NW;
   static_assert(NDMA % NW == 0 && DPW >= 1, "tile does not divide over the waves");
@@ -666,7 +674,7 @@ static __device__ __forceinline__ void fa_bwd_dq_from_ds(const BwdK& p, char FA_
     if (wave_valid) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int k32 = min(2 * n + (j >> 1), p.ds_nk32 - 1);
+        const int k32 = min(2 * n + (j >> 1), row_cnt - 1);
         lds_dma_16B(ds_row + ((int64_t)k32 << 10) + (j & 1) * 512, lds + OFF_DS + st * DS_BUF + wave * DS_WAVE + j * 1024);
       }
     }

@@ -128,6 +128,7 @@ struct BwdK {
   int32_t c5_np, c5_nc;      // dK/dV items and dQ items of this launch
   int32_t c5_pbid0;          // number of the launch's first dK/dV item in the whole dK/dV grid
   int32_t c5_pj0, c5_cj0;    // first round of the dK/dV items' chunk / of the dQ items' chunk
+  int32_t ds_np64;           // fused backward (round 6): 64-key pairs per packed row of the dS workspace (ds_nk32 stays the number of 32-key sub-tiles of a sequence)
   int32_t ds_c1, ds_jb, ds_head_tiles;   // row packing of the workspace (fa_device.h ds_row_start(i, ds_c1, ds_jb, ds_nk32): on this path ds_nk32 counts 64-key PAIRS of sub-tiles); sub-tiles per head = ds_head_tiles
   int32_t fuse_delta;        // 64-rows-per-wave dQ kernel only: 1 = compute softmax_d = rowsum(dO * O) of its own rows in the prologue (and write it for the
                              // dK/dV kernel, which is then launched BEHIND the dQ kernel); 0 = read it (fa_bwd_delta_kernel ran first)

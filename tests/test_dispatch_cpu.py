@@ -153,13 +153,19 @@ def test_fused_backward_workspace_and_conditions(lib, monkeypatch):
     assert ws(bp(4, 4096, 4096, 32, 32, 128)) == 0                        # default: the scratch-free 7-contraction pair
     monkeypatch.setenv("FA_BWD_MODE", "3"); lib.fa_knobs_reload()
     try:
-        def expect(B, Sq, Sk, H):
-            ds = (B * H * ((Sq + 31) // 32) * ((Sk + 31) // 32) * 2048 + 255) & ~255
+        def expect(B, Sq, Sk, H, causal=False):
+            # rows packed in 64-key pairs (round 6, csrc/fa_device.h ds_row_start): row block i holds the pairs up to its last visible key sub-tile
+            np64, tiles = (Sk + 63) // 64, 0
+            for i in range((Sq + 31) // 32):
+                last32 = (32 * i + 31 + (Sk - Sq)) // 32 if causal else 10 ** 9
+                tiles += 2 * min(np64, last32 // 2 + 1)
+            ds = (B * H * tiles * 2048 + 255) & ~255
             items = B * H * ((Sq + 255) // 256)
             return ds + (1344 + items * 32 + 8 * items) * 4
-        assert ws(bp(4, 4096, 4096, 32, 32, 128)) == expect(4, 4096, 4096, 32)    # config 3: 4.3 GB
+        assert ws(bp(4, 4096, 4096, 32, 32, 128)) == expect(4, 4096, 4096, 32)    # config 3 without a mask: 4.3 GB
+        assert ws(bp(4, 4096, 4096, 32, 32, 128, is_causal=1)) == expect(4, 4096, 4096, 32, True) < 0.52 * expect(4, 4096, 4096, 32)   # the causal triangle: half
         assert ws(bp(1, 256, 256, 2, 2, 128)) == expect(1, 256, 256, 2)
-        assert ws(bp(2, 1000, 1024, 32, 8, 64, is_causal=1)) == expect(2, 1000, 1024, 32)
+        assert ws(bp(2, 1000, 1024, 32, 8, 64, is_causal=1)) == expect(2, 1000, 1024, 32, True)
         assert ws(bp(1, 16384, 16384, 32, 32, 128)) == 0                    # 17 GB > FA_BWD_DS_CAP_MB (8192)
         assert ws(bp(4, 4096, 4096, 32, 32, 256)) == 0                      # head dim
         assert ws(bp(4, 4096, 4096, 32, 32, 128, window_left=1000)) == 0    # left window
@@ -200,12 +206,12 @@ def test_backward_plan_table(lib, monkeypatch):
     plan = lambda *a, **kw: _plan(lib, _bwd_params(*a, **kw))[0]
     assert plan(16, 1024, 1024, 16, 16, 128, is_causal=1) == 3            # the sweep's rows: 0.5 GiB / 1 GiB of dS
     assert plan(8, 2048, 2048, 16, 16, 128, is_causal=1) == 3
-    assert plan(8, 2048, 2048, 32, 32, 128, is_causal=1) == 0             # 2 GiB: over the bound
+    assert plan(8, 2048, 2048, 32, 32, 128, is_causal=1) == 0             # 1.03 GiB of packed rows (2 GiB as a square): just over the bound
     assert plan(32, 512, 512, 16, 16, 128, is_causal=1) == 3              # +8 % at S = 512
     assert plan(64, 256, 256, 16, 16, 128, is_causal=1) == 0              # a tie at S = 256
     assert plan(4, 4096, 4096, 32, 32, 128, is_causal=1) == 0             # config 3: 4 GiB of dS -- over the bound (and a tie): the scratch-free pair
     assert plan(1, 4096, 4096, 32, 32, 128, is_causal=1) == 3             # the same rows on 32 heads fit: +9 ... +13 %
-    assert plan(1, 3072, 3072, 32, 32, 128, is_causal=1) == 3 and plan(2, 3072, 3072, 32, 32, 128, is_causal=1) == 0   # (1.2 GiB: over the bound)
+    assert plan(2, 3072, 3072, 32, 32, 128, is_causal=1) == 3 and plan(4, 3072, 3072, 32, 32, 128, is_causal=1) == 0   # (0.6 GiB of packed rows / 1.2 GiB: over the bound)
     assert plan(4, 1536, 1536, 32, 32, 128) == 3                          # without a mask up to 1536 rows
     assert plan(2, 8192, 8192, 16, 16, 128, is_causal=1) == 0
     assert plan(16, 1024, 1024, 16, 16, 128) == 3                         # without a mask: +5.6 % at S = 1024 ...
@@ -217,7 +223,7 @@ def test_backward_plan_table(lib, monkeypatch):
     assert plan(16, 1024, 1024, 16, 16, 128, is_causal=1, softcap=30.0) == 0
     assert plan(16, 1024, 2048, 16, 16, 128, is_causal=1) == 0            # sq != sk: not measured
     a = _bwd_params(16, 1024, 1024, 16, 16, 128, is_causal=1)
-    assert lib.fa_bwd_workspace_bytes(C.byref(a)) >= 16 * 16 * 32 * 32 * 2048   # the binders size the workspace from this
+    assert 16 * 16 * 32 * 32 * 2048 > lib.fa_bwd_workspace_bytes(C.byref(a)) >= 16 * 16 * (32 * 33 // 2) * 2048   # the binders size the workspace from this: the causal triangle, not the square
     for knob, val in (("FA_BWD_MODE", "-1"), ("FA_BWD_MODE", "1"), ("FA_BWD_DQ_NW", "4"), ("FA_BWD_DKDV", "8"), ("FA_STRICT", "1")):
         monkeypatch.setenv(knob, val); lib.fa_knobs_reload()
         try:

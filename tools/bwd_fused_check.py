@@ -91,7 +91,8 @@ def stats():
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         for _ in range(3): be.bwd(do, q, k, v, out, lse, dq, dk, dv, None, 0.0, D ** -0.5, causal, -1, -1, 0.0, False, None, None)
         torch.cuda.synchronize()
-        fz = (B * H * ((S + 31) // 32) ** 2 * 2048 + 255) & ~255   # the dS workspace; the sync area sits behind it
+        n32, np64 = (S + 31) // 32, (S + 63) // 64   # the dS workspace (rows packed in 64-key pairs: the causal triangle); the sync area sits behind it
+        fz = (B * H * sum(2 * min(np64, ((i if causal else 10 ** 9) // 2) + 1) for i in range(n32)) * 2048 + 255) & ~255
         w = last["ws"][fz + 32 * 4: fz + 32 * 4 + 64].view(torch.int64).tolist()
         print(f"   error flag {int(last['ws'][fz: fz + 4].view(torch.int32)[0])}  workspace {last['ws'].numel() / 2 ** 20:.0f} MiB", flush=True)
         n = max(1, w[6])
