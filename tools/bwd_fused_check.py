@@ -85,7 +85,7 @@ def stats():
         last["ws"] = orig(a, device, varlen); return last["ws"]
     be._run_bwd = keep
     os.environ["FA_BWD_MODE"] = "3"; os.environ.pop("FA_BWD_FUSE_DELTA", None); be.reload_knobs()
-    for (B, S, H, D, causal) in ((4, 4096, 32, 128, True), (4, 4096, 32, 128, False), (8, 2048, 32, 128, True), (16, 1024, 32, 128, True)):
+    for (B, S, H, D, causal) in ((4, 4096, 32, 128, True), (8, 2048, 16, 128, True), (16, 1024, 16, 128, True), (32, 512, 16, 128, True), (16, 1024, 16, 128, False)):
         q = torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16); k = torch.randn_like(q); v = torch.randn_like(q); do = torch.randn_like(q)
         out, lse, _, _ = be.fwd(q, k, v, None, None, 0.0, D ** -0.5, causal, -1, -1, 0.0, False, None)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
