@@ -3,8 +3,9 @@
 # the same bench command under rocprofv3, in-kernel clock stamps of the forward (if gpurun_abl/libfa_abl_2048.so was built here first), SQ counters of the forward and the
 # backward at config 3, and -- when the git-ignored scratch copy _ref_tmp/ travelled along (tools/ref_suite/make_scratch.sh) -- the reference's own suites.
 # Output: gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
+# (the suite runs serially, as the driver runs it: 4.5 min; under `-n 6` the six processes share one GPU and eight host cores and take 11 min)
 TAG=${1:-final}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
-timeout 1800 python -m pytest tests -q -m gpu -n 6 -p no:cacheprovider > $O/pytest_gpu.txt 2>&1
+timeout 1800 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/pytest_gpu.txt 2>&1
 tail -3 $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 ( time python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_err.txt ) 2> $O/bench_time.txt
