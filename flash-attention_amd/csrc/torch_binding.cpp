@@ -307,12 +307,20 @@ void run_bwd(FaBwdParams& a, const Tensor& q, bool varlen) {
   const int64_t ws = fa_bwd_workspace_bytes(&a);
   Tensor wsbuf;
   if (ws > 0) {
-    wsbuf = at::empty({ws}, q.options().dtype(at::kByte));
-    a.workspace = wsbuf.data_ptr();
-    a.workspace_bytes = ws;
+    // A fixed-length call's workspace is the dS area of the 5-contraction launches (up to 1 GiB by default): a speed-up, not a requirement.  When the allocator
+    // cannot supply it the call proceeds without one and the library runs the recomputing pair (fa_api.cpp do_bwd checks workspace_bytes).
+    try {
+      wsbuf = at::empty({ws}, q.options().dtype(at::kByte));
+    } catch (const c10::OutOfMemoryError&) {
+      if (varlen) throw;   // (work lists: a few KB -- if that fails nothing will succeed)
+    }
+    if (wsbuf.defined()) {
+      a.workspace = wsbuf.data_ptr();
+      a.workspace_bytes = ws;
+    }
   }
   fa_check(varlen ? fa_varlen_bwd(&a, cur_stream(q)) : fa_bwd(&a, cur_stream(q)));
-  if (ws > 0 && !varlen) fa_check(fa_bwd_fused_status(&a, cur_stream(q)));   // (FA_OK at once unless the opt-in fused backward ran: fa_gfx950.h)
+  if (wsbuf.defined() && !varlen) fa_check(fa_bwd_fused_status(&a, cur_stream(q)));   // (FA_OK at once unless the opt-in fused backward ran: fa_gfx950.h)
 }
 
 void fill_bwd_ptrs(FaBwdParams& a, const BwdBufs& t, const Tensor& lse, Tensor& delta) {

@@ -319,12 +319,24 @@ def _fill_bwd_common(a, dout, q, k, v, out, lse, dq, dk, dv, delta, alibi, alibi
     a.softmax_scale, a.softcap, a.deterministic = float(softmax_scale), float(softcap), int(bool(deterministic))
 
 
+def _alloc_workspace(nbytes, device):   # (a seam for tests/test_bwd_schedules_gpu.py: the out-of-memory fallback)
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+
+
 def _run_bwd(a, device, varlen):
     lib = _cabi.load()
     ws_bytes = lib.fa_bwd_workspace_bytes(C.byref(a))
     ws = None
     if ws_bytes > 0:
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=device)
+        # A fixed-length call's workspace is the dS area of the 5-contraction launches (up to 1 GiB by default): a speed-up, not a requirement.  When the allocator
+        # cannot supply it the call proceeds without one and the library runs the recomputing pair (fa_api.cpp do_bwd checks workspace_bytes).
+        try:
+            ws = _alloc_workspace(ws_bytes, device)
+        except torch.OutOfMemoryError:
+            if varlen:   # (work lists: a few KB -- if that fails nothing will succeed)
+                raise
+            ws = None
+    if ws is not None:
         if os.environ.get("FA_DEBUG_POISON_WS"):   # tests: every 16-bit word of the workspace a NaN, so that a read of something nobody wrote shows
             ws.fill_(0xFF)
         a.workspace, a.workspace_bytes = _ptr(ws), ws_bytes

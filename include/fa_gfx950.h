@@ -250,7 +250,10 @@ int fa_set_rng_state(uint64_t seed, uint64_t offset, uint64_t* rng_state, void* 
 int64_t fa_fwd_workspace_bytes(const FaFwdParams* params);
 /* Rotary embedding of q / new keys ahead of fa_kvcache_append + fa_fwd_kvcache (y may alias x). */
 int fa_rotary(const FaRotaryParams* params, void* stream);
-/* Bytes of scratch the backward needs for this problem (0 is possible). */
+/* Bytes of scratch the backward can use for this problem (0 is possible).  For fa_bwd (fixed-length batches) the scratch is the dS area of the 5-contraction
+ * launches (up to 1 GiB by default; FA_BWD_MODE / FA_BWD_DS_CAP_MB / FA_BWD_C5_CAP_MB): a speed-up, not a requirement -- called with workspace = NULL or fewer
+ * bytes, fa_bwd runs the recomputing pair, which needs none (both binders do exactly that when their allocator is out of memory).  For fa_varlen_bwd it holds the
+ * work lists of an uneven batch (a few KB). */
 int64_t fa_bwd_workspace_bytes(const FaBwdParams* params);
 /* Backward, fixed-length batch: writes dq, dk, dv (caller-allocated) and softmax_d. */
 int fa_bwd(const FaBwdParams* params, void* stream);

@@ -264,3 +264,25 @@ def test_default_table_region_takes_the_fused_launch(be, knobs, dtype, shape):
         e, e_pair, e_pt = float((x.float() - base).abs().max()), float((y.float() - base).abs().max()), float((lo - base).abs().max())
         assert torch.isfinite(x.float()).all() and e <= 3 * e_pt + 1e-4, (name, e, e_pt)
         assert e <= 1.5 * e_pair + 1e-4, (name, e, e_pair)
+
+
+def test_dS_workspace_out_of_memory_falls_back_to_the_pair(be, knobs, monkeypatch):
+    """The fixed-length workspace is the 5-contraction launches' dS area -- a speed-up.  When the allocator cannot supply it (here: made to refuse) the binder passes
+    none and the library runs the recomputing pair: same gradients as FA_BWD_MODE=-1, bit for bit."""
+    torch.manual_seed(6)
+    q = torch.randn(8, 1024, 4, 128, device="cuda", dtype=torch.bfloat16)
+    k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
+    assert run_bwd(be, q, k, v, do, True)[3]["bwd_spill"] == 3
+    asked = []
+
+    def refuse(nbytes, device):
+        asked.append(nbytes)
+        raise torch.OutOfMemoryError("test: no room for %d bytes" % nbytes)
+
+    monkeypatch.setattr(be, "_alloc_workspace", refuse)
+    f = run_bwd(be, q, k, v, do, True)
+    assert asked and asked[0] > (1 << 20) and f[3]["bwd_spill"] == 0, (asked, f[3])
+    monkeypatch.undo()
+    knobs.set("FA_BWD_MODE", -1)
+    a = run_bwd(be, q, k, v, do, True)
+    assert all(torch.equal(x, y) for x, y in zip(f[:3], a[:3]))
