@@ -19,3 +19,14 @@ def test_slices_beyond_4_gib():
     env = {k: v for k, v in os.environ.items() if not k.startswith("FA_") or k == "FA_GFX950_LIB"}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_offset_probe.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "False" not in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_slice_spanning_more_than_4_gib_falls_back():
+    """tools/big_span_probe.py: rows 2 MB apart -- one (batch, head) slice spans 8.6 GB, past the 64-per-wave kernels' 32-bit offsets: the dispatch falls back
+    (pipelined forward, lock-step backward: a tile's base in 64 bits) and the results equal the same kernels' on contiguous copies bit for bit (~60 GB for seconds)."""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
+        pytest.skip("needs ~60 GB of device memory")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FA_") or k == "FA_GFX950_LIB"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_span_probe.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "False" not in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-2000:])
