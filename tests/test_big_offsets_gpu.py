@@ -30,3 +30,11 @@ def test_slice_spanning_more_than_4_gib_falls_back():
     env = {k: v for k, v in os.environ.items() if not k.startswith("FA_") or k == "FA_GFX950_LIB"}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_span_probe.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "False" not in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_128k_and_256k_token_sequences():
+    """tools/long_seq_probe.py: 2 048 / 4 096 key tiles per query block (causal, windowed, unmasked; GQA) -- the 64-per-wave kernels against the independent
+    pipelined / lock-step kernel family on the same inputs: out <= 2e-2, LSE <= 1e-2, gradients <= 6e-2 apart (bf16, N(0,1) inputs), everything finite."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FA_") or k == "FA_GFX950_LIB"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "long_seq_probe.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK") and "BAD" not in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-2000:])
