@@ -487,7 +487,7 @@ void bwd_list_entries(const FaBwdParams* a, int64_t& q_entries, int64_t& k_entri
 // superseded by FA_BWD_MODE=5 below: the same idea on the 64-per-wave kernels with a bounded workspace; git history keeps the old experiment.)
 // Fused backward (FA_BWD_MODE=3, fa_bwd.hip fa_bwd_fused_kernel): bytes of the dS workspace (256-B aligned) when the call qualifies, else 0; the sync
 // area (fa_kernel_params.h FZ_*) sits behind it.  Same conditions as launch_bwd_fused.
-// Round 6: it is the DEFAULT (FA_BWD_MODE=0) where it was measured ahead of the recomputing pair and its workspace stays within 1 GiB (profiles/r06_bwd_c5.txt (5), timed
+// Round 6: it is the DEFAULT (FA_BWD_MODE=0) where it was measured ahead of the recomputing pair and its workspace stays within bounds (bwd_fused_plan below; profiles/r06_bwd_c5.txt (5), timed
 // WITHOUT the status read -- a stream sync per call, which the default path does not do and which cost the launch 9 % at S = 1024): head dim 128, Sq = Sk, at least
 // 32 (batch, kv head) units, under a causal mask from 512 to 4096 rows (+8 % / +18 % / +15 % at S = 512 / 1024 / 2048 on the sweep's shapes, +7 ... +9 % at S = 3072 and
 // +9 ... +13 % at S = 4096 on the grids that fit the 1 GiB -- 32 heads) and without a mask from 512 to 1536 rows (+1.5 % / +5 % / +5.6 % / +3 ... +5 % at 512 / 768 / 1024 / 1536).
@@ -511,22 +511,37 @@ FusedPack fused_pack(int sq, int sk, int wr) {   // the row packing of the dS wo
   f.head_tiles = fa::ds_row_start((sq + 31) / 32, f.c1, f.jb, f.np64);
   return f;
 }
-int64_t bwd_fused_ds_bytes(const FaBwdParams* a) {
+// The fused launch's plan (round 6, late): the batch is cut into chunks of whole batch entries so that a chunk's packed dS fits the cap, one launch per chunk on the
+// SAME workspace (stream order: launch c + 1 starts when launch c is over).  By the table (mode 0) the cap is 1.25 GiB (the packed triangle of the shapes whose half
+// square is exactly 1 GiB comes to 1.03 - 1.08 GiB: B8 S2048 H32 +15 %, B4 S4096 H16 +3 %, B4 S3072 H32 +7 %), a chunk keeps >= 32 (batch, kv head) units, and only
+// sequences up to 2048 rows are chunked -- there the launch is 12 ... 25 % ahead of the pair at any grid size (B32 S1024 H32: 524 against 418 TFLOP/s, B16 S2048 H32
+// 652 / 583, B64 S512 H32 366 / 313, no mask B32 S1024 H32 698 / 649; profiles/r06_bwd_c5.txt (7)); from 2048 to 4096 rows it is only ahead of the pair ON THE
+// SAME GRID (+3 ... +9 %) and the pair gains more from a larger grid than that, so there the whole batch has to fit.  FA_BWD_MODE=3: cap FA_BWD_DS_CAP_MB, chunked whenever needed.
+struct FusedPlan { int nb, n_chunks; int64_t ds_bytes, sync_bytes; };   // batch entries per chunk, chunks, bytes of a chunk's dS / sync area
+bool bwd_fused_plan(const FaBwdParams* a, FusedPlan& pl) {
+  pl = FusedPlan{0, 0, 0, 0};
   const int mode = fa::knobs().bwd_mode;
-  if ((mode != 3 && mode != 0) || a->cu_seqlens_q || a->cu_seqlens_k || a->seqused_q || a->seqused_k || (a->d != 128 && a->d != 64)) return 0;
-  if (a->seqlen_q <= 0 || a->seqlen_k < a->seqlen_q || a->window_left >= 0 || a->softcap > 0.f || a->alibi_slopes || a->p_dropout > 0.f) return 0;
-  if (mode == 0 && !bwd_fused_by_table(a)) return 0;
-  // (round 6: packed rows, fa_device.h ds_row_start -- a causal mask stores its triangle: half of B*H*Sq*Sk*2 bytes)
+  if ((mode != 3 && mode != 0) || a->cu_seqlens_q || a->cu_seqlens_k || a->seqused_q || a->seqused_k || (a->d != 128 && a->d != 64)) return false;
+  if (a->seqlen_q <= 0 || a->seqlen_k < a->seqlen_q || a->window_left >= 0 || a->softcap > 0.f || a->alibi_slopes || a->p_dropout > 0.f || a->b <= 0) return false;
+  if (mode == 0 && !bwd_fused_by_table(a)) return false;
+  // (packed rows, fa_device.h ds_row_start -- a causal mask stores its triangle: about half of B*H*Sq*Sk*2 bytes)
   int causal = a->is_causal, wl = a->window_left, wr = a->window_right;
   normalize_window(a->seqlen_q, a->seqlen_k, false, causal, wl, wr);
   const FusedPack fp = fused_pack(a->seqlen_q, a->seqlen_k, wr);
-  const int64_t bytes = (int64_t)a->b * a->h * fp.head_tiles * 2048;
-  const int64_t cap = mode == 0 ? ((int64_t)1 << 30) : ((int64_t)fa::knobs().bwd_ds_cap_mb << 20);
-  return bytes > cap ? 0 : ((bytes + 255) & ~(int64_t)255);
+  const int64_t per_batch = (int64_t)a->h * fp.head_tiles * 2048;
+  const int64_t cap = mode == 0 ? ((int64_t)1280 << 20) : ((int64_t)fa::knobs().bwd_ds_cap_mb << 20);
+  int64_t nb = std::min<int64_t>(a->b, cap / per_batch);
+  if (nb < 1) return false;
+  const int n_chunks = (int)((a->b + nb - 1) / nb);
+  nb = (a->b + n_chunks - 1) / n_chunks;   // (even chunks)
+  if (mode == 0 && n_chunks > 1 && (a->seqlen_q > 2048 || (a->b - (n_chunks - 1) * nb) * a->h_k < 32)) return false;   // (the last chunk is the smallest)
+  pl.nb = (int)nb; pl.n_chunks = n_chunks;
+  pl.ds_bytes = (nb * per_batch + 255) & ~(int64_t)255;
+  pl.sync_bytes = fa::fz_sync_words(nb * a->h * ((a->seqlen_q + 255) / 256), fa::knobs().fz_line) * 4;
+  return true;
 }
-int64_t bwd_fused_sync_bytes(const FaBwdParams* a) {
-  return fa::fz_sync_words((int64_t)a->b * a->h * ((a->seqlen_q + 255) / 256), fa::knobs().fz_line) * 4;
-}
+int64_t bwd_fused_ds_bytes(const FaBwdParams* a) { FusedPlan pl; return bwd_fused_plan(a, pl) ? pl.ds_bytes : 0; }
+int64_t bwd_fused_sync_bytes(const FaBwdParams* a) { FusedPlan pl; return bwd_fused_plan(a, pl) ? pl.sync_bytes : 0; }
 
 // ---- 5-contraction backward (round 6; reference: ONE pass forms S, dP and dS and all three gradients follow from it, csrc/flash_attn/src/flash_bwd_kernel.h:457-733) ----
 // The 64-keys-per-wave dK/dV items write dS (input dtype) to a workspace, dQ = dS.K is one contraction instead of the recomputing dQ kernel's three.  The workspace is
@@ -615,11 +630,26 @@ int do_bwd(const FaBwdParams* a, void* stream, bool varlen) {
     { const FusedPack fp = fused_pack(a->seqlen_q, a->seqlen_k, k.wr); k.ds_np64 = fp.np64; k.ds_c1 = fp.c1; k.ds_jb = fp.jb; k.ds_head_tiles = fp.head_tiles; }
     k.nmb = (a->seqlen_q + 255) / 256;
     k.fuse_sync = (int32_t*)((char*)a->workspace + fz);
-    k.fuse_items = a->b * a->h * k.nmb;
     k.fuse_line = fa::knobs().fz_line;
     const int bf = a->dtype == FA_DTYPE_BF16;
-    int rc = fa::launch_bwd_delta(k, bf, a->d, s);
-    if (rc == 0) rc = fa::launch_bwd_fused(k, bf, a->d, s);
+    int rc = fa::launch_bwd_delta(k, bf, a->d, s);   // (the whole batch at once)
+    FusedPlan fpl;
+    bwd_fused_plan(a, fpl);
+    const fa::BwdK whole = k;
+    for (int b0 = 0; rc == 0 && b0 < a->b; b0 += fpl.nb) {   // one launch per chunk of batch entries, all on the same workspace
+      const int nb = std::min(fpl.nb, a->b - b0);
+      auto at = [&](const void* base, int64_t bs) { return (const void*)((const char*)base + (int64_t)b0 * bs * 2); };
+      k = whole;
+      k.b = nb;
+      k.dout = at(whole.dout, whole.do_bs); k.q = at(whole.q, whole.q_bs); k.k = at(whole.k, whole.k_bs); k.v = at(whole.v, whole.v_bs); k.o = at(whole.o, whole.o_bs);
+      k.dq = (void*)at(whole.dq, whole.dq_bs); k.dk = (void*)at(whole.dk, whole.dk_bs); k.dv = (void*)at(whole.dv, whole.dv_bs);
+      k.lse = whole.lse + (int64_t)b0 * a->h * a->seqlen_q; k.delta = whole.delta + (int64_t)b0 * a->h * a->seqlen_q;
+      fa::choose_units(nb, a->h_k, 1, k.nnb, k.k_units, k.k_unit_size, k.k_unit_hpx);
+      k.fuse_items = nb * a->h * k.nmb;
+      k.fuse_keep_err = b0 > 0;   // (the launch's error flag accumulates over the chunks: only the first launch zeroes it)
+      rc = fa::launch_bwd_fused(k, bf, a->d, s);
+    }
+    k = whole;
     if (rc == 0) {
       fa::LastSchedule& ls = fa::last_schedule();
       ls.bwd_dkdv_nw = 8; ls.bwd_dq_nw = 8; ls.bwd_spill = 3; ls.bwd_list = 0;
@@ -733,6 +763,7 @@ int fa_bwd_plan_query(const FaBwdParams* a, int32_t* out, int n) {
     v[0] = 5; v[1] = pl.n_chunks; v[2] = pl.rounds_per_chunk; v[3] = pl.head_tiles; v[4] = pl.np64; v[5] = pl.c1; v[6] = pl.jb; v[7] = (int32_t)(pl.slot_bytes >> 20);
   } else if (!a->cu_seqlens_q && bwd_fused_ds_bytes(a) > 0) {
     v[0] = 3;
+    FusedPlan fpl; bwd_fused_plan(a, fpl); v[1] = fpl.n_chunks; v[2] = fpl.nb; v[7] = (int32_t)((fpl.ds_bytes + fpl.sync_bytes) >> 20);
   }
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   return 8;

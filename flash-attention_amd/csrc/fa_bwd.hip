@@ -837,7 +837,9 @@ static int launch_fused_t(const BwdK& p, hipStream_t stream) {
   auto kern = fa_bwd_fused_kernel<E, D>;
   static std::atomic<unsigned long long> attr_mask{0};
   if (ensure_dyn_lds(attr_mask, (const void*)kern, smem, true) != 0) return -1;
-  if (hipMemsetAsync(p.fuse_sync, 0, (size_t)fz_sync_words(p.fuse_items, p.fuse_line) * 4, stream) != hipSuccess) return -1;
+  static_assert(FZ_ERR == 0, "the error flag is the sync area's first word");
+  const int keep = p.fuse_keep_err ? 1 : 0;   // (a later chunk of the same call: the flag accumulates)
+  if (hipMemsetAsync(p.fuse_sync + keep, 0, (size_t)(fz_sync_words(p.fuse_items, p.fuse_line) - keep) * 4, stream) != hipSuccess) return -1;
   const long long total = units_grid(p.k_units, p.k_unit_size);
   static const int n_cu = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
   BwdK q = p;

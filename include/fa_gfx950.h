@@ -229,7 +229,8 @@ const char* fa_last_kernel_name(void);
 int fa_fwd_schedule_query(const FaFwdParams* params, int varlen);
 int fa_bwd_dq_schedule_query(const FaBwdParams* params);
 /* Which backward a fixed-length call runs and how its workspace is laid out (round 6; host logic only, for tests of the dispatch on a box without a GPU):
- * out[0] = 0 the recomputing pair (7 contractions, no dS workspace), 3 = the fused launch (dK/dV + dQ = dS.K, FA_BWD_MODE=3 or the default table),
+ * out[0] = 0 the recomputing pair (7 contractions, no dS workspace), 3 = the fused launch (dK/dV + dQ = dS.K, FA_BWD_MODE=3 or the default table; out[1] = launches
+ * = chunks of whole batch entries, out[2] = batch entries per chunk, out[7] = MiB of workspace),
  * 5 = the chunked 5-contraction backward (FA_BWD_MODE=5); for 5: out[1] = chunks, out[2] = XCD rounds (8 units) per chunk, out[3] = dS sub-tiles (2 KB) per
  * head with packed rows, out[4] = 64-key pairs per row, out[5] / out[6] = the row packing's a / jb (csrc/fa_device.h ds_row_start), out[7] = MiB per slot.
  * Returns the number of fields (8) or a negative FA_ERR_*. */
@@ -251,7 +252,7 @@ int64_t fa_fwd_workspace_bytes(const FaFwdParams* params);
 /* Rotary embedding of q / new keys ahead of fa_kvcache_append + fa_fwd_kvcache (y may alias x). */
 int fa_rotary(const FaRotaryParams* params, void* stream);
 /* Bytes of scratch the backward can use for this problem (0 is possible).  For fa_bwd (fixed-length batches) the scratch is the dS area of the 5-contraction
- * launches (up to 1 GiB by default; FA_BWD_MODE / FA_BWD_DS_CAP_MB / FA_BWD_C5_CAP_MB): a speed-up, not a requirement -- called with workspace = NULL or fewer
+ * launches (up to 1.25 GiB by default; FA_BWD_MODE / FA_BWD_DS_CAP_MB / FA_BWD_C5_CAP_MB): a speed-up, not a requirement -- called with workspace = NULL or fewer
  * bytes, fa_bwd runs the recomputing pair, which needs none (both binders do exactly that when their allocator is out of memory).  For fa_varlen_bwd it holds the
  * work lists of an uneven batch (a few KB). */
 int64_t fa_bwd_workspace_bytes(const FaBwdParams* params);

@@ -286,3 +286,63 @@ def test_dS_workspace_out_of_memory_falls_back_to_the_pair(be, knobs, monkeypatc
     knobs.set("FA_BWD_MODE", -1)
     a = run_bwd(be, q, k, v, do, True)
     assert all(torch.equal(x, y) for x, y in zip(f[:3], a[:3]))
+
+
+def _plan_of(B, S, H, Hk, D, causal):
+    import ctypes as C
+    from flash_attn_amd import _cabi
+    lib = _cabi.load()
+    a = _cabi.FaBwdParams()
+    a.b, a.h, a.h_k, a.d = B, H, Hk, D
+    a.seqlen_q, a.seqlen_k, a.total_q, a.total_k = S, S, B * S, B * S
+    a.dtype, a.softmax_scale, a.is_causal = 1, D ** -0.5, int(causal)
+    a.window_left = a.window_right = -1
+    out = (C.c_int32 * 8)()
+    assert lib.fa_bwd_plan_query(C.byref(a), out, 8) == 8
+    return list(out)
+
+
+# Round 6 (late): a batch whose dS does not fit the cap is cut into chunks of whole batch entries, one fused launch per chunk on the SAME workspace (stream order).
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape,cap_mb", [((7, 640, 6, 6, True), 6), ((5, 512, 4, 2, False), 5), ((9, 1024, 2, 2, True), 5), ((4, 300, 3, 3, True), 1)],
+                         ids=lambda x: "B%d_S%d_H%d_%d_c%d" % x if isinstance(x, tuple) else "cap%d" % x)
+def test_fused_backward_in_chunks_of_batch_entries(be, knobs, dtype, shape, cap_mb):
+    B, S, H, Hk, causal = shape
+    torch.manual_seed(8)
+    q = torch.randn(B, S, H, 128, device="cuda", dtype=dtype)
+    k = torch.randn(B, S, Hk, 128, device="cuda", dtype=dtype)
+    v, do = torch.randn_like(k), torch.randn_like(q)
+    knobs.set("FA_BWD_FUSE_DELTA", 0); knobs.set("FA_BWD_DKDV", 8)   # (the pair on the fused launch's arithmetic: pre-pass delta, eight-wave dK/dV body)
+    a = run_bwd(be, q, k, v, do, causal)
+    knobs.set("FA_BWD_MODE", 3)
+    whole = run_bwd(be, q, k, v, do, causal)
+    knobs.set("FA_BWD_DS_CAP_MB", cap_mb); knobs.set("FA_DEBUG_POISON_WS", 1); knobs.set("FA_BWD_FUSED_CHECK", 1)
+    plan = _plan_of(B, S, H, Hk, 128, causal)
+    assert plan[0] == 3 and plan[1] >= 2 and plan[1] * plan[2] >= B > (plan[1] - 1) * plan[2], plan   # really chunked, the last chunk not empty
+    f = run_bwd(be, q, k, v, do, causal)
+    f2 = run_bwd(be, q, k, v, do, causal)
+    assert a[3]["bwd_spill"] == 0 and whole[3]["bwd_spill"] == 3 and f[3]["bwd_spill"] == 3
+    assert all(torch.equal(x, y) for x, y in zip(f[:3], whole[:3]))   # chunked == one launch, all three gradients, bit for bit
+    assert all(torch.equal(x, y) for x, y in zip(f[:3], f2[:3]))
+    assert torch.equal(a[1], f[1]) and torch.equal(a[2], f[2])       # dk, dv == the pair's
+
+
+def test_default_table_chunks_a_large_batch(be, knobs):
+    """64 x 1024 x 32 heads under a causal mask: 2.2 GiB of packed dS -> by default two launches of 32 batch entries on a 1.1 GiB workspace (the launch is +25 % on the
+    pair at this size); gradients under the reference's rule and within 1.5x of the pair's error."""
+    B, S, H = 64, 1024, 32
+    plan = _plan_of(B, S, H, H, 128, True)
+    assert plan[:3] == [3, 2, 32] and plan[7] <= 1280, plan
+    torch.manual_seed(9)
+    q = torch.randn(B, S, H, 128, device="cuda", dtype=torch.bfloat16)
+    k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
+    knobs.set("FA_DEBUG_POISON_WS", 1)
+    f = run_bwd(be, q, k, v, do, True)
+    assert f[3]["bwd_spill"] == 3, f[3]
+    knobs.set("FA_BWD_MODE", -1)
+    a = run_bwd(be, q, k, v, do, True)
+    for sl in (slice(0, 2), slice(31, 33), slice(62, 64)):   # (an fp32 reference of the whole batch is 8 GB per matrix: the first, the seam's and the last entries)
+        r = ref_grads(q[sl], k[sl], v[sl], do[sl], True, -1, -1); rl = ref_grads(q[sl], k[sl], v[sl], do[sl], True, -1, -1, upcast=False)
+        for name, x, y, base, lo in zip(("dq", "dk", "dv"), f[:3], a[:3], r, rl):
+            e, e_pair, e_pt = float((x[sl].float() - base).abs().max()), float((y[sl].float() - base).abs().max()), float((lo - base).abs().max())
+            assert e <= 3 * e_pt + 1e-4 and e <= 1.5 * e_pair + 1e-4, (name, sl, e, e_pair, e_pt)

@@ -173,7 +173,10 @@ def test_fused_backward_workspace_and_conditions(lib, monkeypatch):
         assert ws(bp(4, 4096, 4096, 32, 32, 128, p_dropout=0.1)) == 0
         assert ws(bp(4, 4096, 1024, 32, 32, 128, is_causal=1)) == 0          # sk < sq
         monkeypatch.setenv("FA_BWD_DS_CAP_MB", "1024"); lib.fa_knobs_reload()
-        assert ws(bp(4, 4096, 4096, 32, 32, 128)) == 0 and ws(bp(16, 1024, 1024, 32, 32, 128)) == expect(16, 1024, 1024, 32)
+        # (round 6, late: a batch that does not fit the cap is cut into chunks of whole batch entries, one launch each on the same workspace -- here one entry = 1 GiB)
+        assert ws(bp(4, 4096, 4096, 32, 32, 128)) == expect(1, 4096, 4096, 32) and ws(bp(16, 1024, 1024, 32, 32, 128)) == expect(16, 1024, 1024, 32)
+        monkeypatch.setenv("FA_BWD_DS_CAP_MB", "512"); lib.fa_knobs_reload()
+        assert ws(bp(4, 4096, 4096, 32, 32, 128)) == 0                      # not even one batch entry fits
     finally:
         monkeypatch.delenv("FA_BWD_MODE", raising=False); monkeypatch.delenv("FA_BWD_DS_CAP_MB", raising=False); lib.fa_knobs_reload()
 
@@ -198,7 +201,7 @@ def _plan(lib, a):
 
 def test_backward_plan_table(lib, monkeypatch):
     """Round 6 (fa_api.cpp bwd_fused_by_table): the fused 5-contraction launch is the default at head dim 128 with Sq = Sk and at least 32 (batch, kv head) units, under a
-    causal mask from 512 to 4096 rows and without a mask from 512 to 1536 rows, while its dS workspace fits 1 GiB -- where it was measured ahead -- and nowhere
+    causal mask from 512 to 4096 rows and without a mask from 512 to 1536 rows, while its dS workspace fits 1.25 GiB (whole, or up to 2048 rows in chunks of batch entries) -- where it was measured ahead -- and nowhere
     else; knobs that pin a kernel of the recomputing pair keep the pair."""
     for v in ("FA_BWD_MODE", "FA_BWD_DQ_NW", "FA_BWD_DKDV", "FA_STRICT"):
         monkeypatch.delenv(v, raising=False)
@@ -206,12 +209,22 @@ def test_backward_plan_table(lib, monkeypatch):
     plan = lambda *a, **kw: _plan(lib, _bwd_params(*a, **kw))[0]
     assert plan(16, 1024, 1024, 16, 16, 128, is_causal=1) == 3            # the sweep's rows: 0.5 GiB / 1 GiB of dS
     assert plan(8, 2048, 2048, 16, 16, 128, is_causal=1) == 3
-    assert plan(8, 2048, 2048, 32, 32, 128, is_causal=1) == 0             # 1.03 GiB of packed rows (2 GiB as a square): just over the bound
+    assert plan(8, 2048, 2048, 32, 32, 128, is_causal=1) == 3             # 1.03 GiB of packed rows (2 GiB as a square): inside the 1.25 GiB bound, +15 %
     assert plan(32, 512, 512, 16, 16, 128, is_causal=1) == 3              # +8 % at S = 512
     assert plan(64, 256, 256, 16, 16, 128, is_causal=1) == 0              # a tie at S = 256
     assert plan(4, 4096, 4096, 32, 32, 128, is_causal=1) == 0             # config 3: 4 GiB of dS -- over the bound (and a tie): the scratch-free pair
     assert plan(1, 4096, 4096, 32, 32, 128, is_causal=1) == 3             # the same rows on 32 heads fit: +9 ... +13 %
-    assert plan(2, 3072, 3072, 32, 32, 128, is_causal=1) == 3 and plan(4, 3072, 3072, 32, 32, 128, is_causal=1) == 0   # (0.6 GiB of packed rows / 1.2 GiB: over the bound)
+    assert plan(2, 3072, 3072, 32, 32, 128, is_causal=1) == 3 and plan(4, 3072, 3072, 32, 32, 128, is_causal=1) == 3   # (0.6 / 1.2 GiB of packed rows: +9 % / +7 %)
+    assert plan(8, 3072, 3072, 32, 32, 128, is_causal=1) == 0             # 2.4 GiB: above 2048 rows the whole batch has to fit (the pair gains more from the larger grid)
+    # up to 2048 rows a batch over the bound is cut into chunks of whole batch entries (>= 32 units each), one launch per chunk on the same workspace
+    full = lambda *a, **kw: _plan(lib, _bwd_params(*a, **kw))
+    assert full(32, 1024, 1024, 32, 32, 128, is_causal=1)[:3] == [3, 1, 32]   # 1.09 GiB of packed rows: one launch (+25 %)
+    assert full(64, 1024, 1024, 32, 32, 128, is_causal=1)[:3] == [3, 2, 32]   # 2.2 GiB -> two chunks of 32 batch entries
+    assert full(16, 2048, 2048, 32, 32, 128, is_causal=1)[:3] == [3, 2, 8]    # 2.06 GiB (+12 %)
+    assert full(65, 1024, 1024, 32, 32, 128, is_causal=1)[:3] == [3, 2, 33] and full(65, 1024, 1024, 32, 32, 128, is_causal=1)[7] <= 1280
+    assert full(32, 1024, 1024, 32, 32, 128)[:3] == [3, 2, 16]                # no mask: 2 GiB -> two chunks (+7.5 %)
+    assert full(16, 1024, 1024, 16, 16, 128, is_causal=1)[:3] == [3, 1, 16]
+    assert plan(64, 2048, 2048, 32, 1, 128, is_causal=1) == 0              # MQA: nine batch entries fit = nine (batch, kv head) units per chunk: the pair
     assert plan(4, 1536, 1536, 32, 32, 128) == 3                          # without a mask up to 1536 rows
     assert plan(2, 8192, 8192, 16, 16, 128, is_causal=1) == 0
     assert plan(16, 1024, 1024, 16, 16, 128) == 3                         # without a mask: +5.6 % at S = 1024 ...
