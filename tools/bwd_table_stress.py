@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "flash-attention_amd"))
 import torch
 from flash_attn_amd import backend as be
-from tests.test_bwd_schedules_gpu import ref_grads
+from tests.test_bwd_schedules_gpu import ref_grads, _plan_of
 
 def run(env, q, k, v, do, causal=True):
     for kk in ("FA_BWD_MODE", "FA_BWD_FUSE_DELTA", "FA_BWD_DKDV"): os.environ.pop(kk, None)
@@ -30,13 +30,17 @@ for i in range(n):
     if -(-32 // Hk) > Bmax:   # (32 units of this shape do not fit 1 GiB: outside the table's region -- draw again)
         S = rng.choice([512, 1024]); Bmax = max(1, (1 << 30) // (H * ((S + 31) // 32) ** 2 * 2048))
     B = rng.randint(max(1, -(-32 // Hk)), max(-(-32 // Hk), min(40, Bmax)))
+    if S <= 2048 and rng.random() < 0.3:   # (late round 6: a batch over the 1.25 GiB bound -> chunks of whole batch entries, one launch each)
+        B = rng.randint(Bmax + Bmax // 4 + 1, 3 * Bmax)
+    plan = _plan_of(B, S, H, Hk, 128, causal)
     dt = rng.choice([torch.bfloat16, torch.float16])
     torch.manual_seed(i)
     q = torch.randn(B, S, H, 128, device="cuda", dtype=dt); k = torch.randn(B, S, Hk, 128, device="cuda", dtype=dt); v = torch.randn_like(k); do = torch.randn_like(q)
     d = run({}, q, k, v, do, causal); d2 = run({}, q, k, v, do, causal)
     p = run({"FA_BWD_MODE": "-1", "FA_BWD_FUSE_DELTA": "0", "FA_BWD_DKDV": "8"}, q, k, v, do, causal)
-    ok = d[3]["bwd_spill"] == 3 and p[3]["bwd_spill"] == 0 and all(torch.equal(a, b) for a, b in zip(d[:3], d2[:3])) and torch.equal(d[1], p[1]) and torch.equal(d[2], p[2])
+    ok = d[3]["bwd_spill"] == plan[0] and p[3]["bwd_spill"] == 0 and all(torch.equal(a, b) for a, b in zip(d[:3], d2[:3])) and torch.equal(d[1], p[1]) and torch.equal(d[2], p[2])
     ok = ok and all(bool(torch.isfinite(x.float()).all()) for x in d[:3])
+    if plan[0] != 3: ok = d[3]["bwd_spill"] == 0 and all(torch.equal(a, b) for a, b in zip(d[:3], d2[:3]))   # (outside the table after all, e.g. too few units per chunk: the pair, on its own kernels)
     e = ""
     if B * H * S * S <= 2 ** 27:
         r = ref_grads(q, k, v, do, causal, -1, -1); pt = ref_grads(q, k, v, do, causal, -1, -1, upcast=False)
@@ -44,6 +48,6 @@ for i in range(n):
         ok = ok and ed <= 3 * et + 1e-5 and ed <= 2 * ep + 1e-5
         e = f" dq err default {ed:.2e} pair {ep:.2e} torch-in-dtype {et:.2e}"
     bad += not ok
-    print(f"{'ok ' if ok else 'BAD'} {str(dt)[6:]} B{B} S{S} H{H}/{Hk} c{int(causal)}: default spill {d[3]['bwd_spill']}{e}", flush=True)
+    print(f"{'ok ' if ok else 'BAD'} {str(dt)[6:]} B{B} S{S} H{H}/{Hk} c{int(causal)}: default spill {d[3]['bwd_spill']} launches {plan[1]}{e}", flush=True)
 print("FAILURES", bad)
 sys.exit(1 if bad else 0)
