@@ -426,7 +426,12 @@ int bwd_dkdv_schedule(const FaBwdParams* a) {
   // and stay on the eight-wave kernel below 2k rows of it)
   long walk = a->seqlen_q;
   const int wr = a->is_causal ? 0 : a->window_right;
-  if (a->window_left >= 0 && wr >= 0) walk = std::min<long>(walk, (long)a->window_left + wr + 256) * (a->h / a->h_k);   // (the query heads of a group are walked one after the other: config 5, 4 x 1280 rows, measured +1.5 % on this kernel)
+  const int ratio = a->h / a->h_k;
+  if (a->window_left >= 0 && wr >= 0) walk = std::min<long>(walk, (long)a->window_left + wr + 256) * ratio;   // (the query heads of a group are walked one after the other: config 5, 4 x 1280 rows, measured +1.5 % on this kernel)
+  // (round 6, late: ... and so they are without a window -- a key block of a GQA group walks ratio x Sq rows, half of them on average under a right bound.  Measured on the
+  // pair, TFLOP/s eight-wave | this kernel: causal S = 1024 ratio 4 158-172 | 165-182 (+5 %), ratio 8 168-172 | 178-182 (+6 %), S = 768 ratio 4 +2 %, S = 512 ratio 4 / 8 -2 %;
+  // no mask S = 1024 ratio 4 296-306 | 322-332 (+8.5 %), S = 1536 ratio 4 +8 %, S = 640 ratio 8 +10 %: from 2k walked rows on average, not below 640 rows per head)
+  else if (a->window_left < 0 && ratio > 1 && a->seqlen_q >= 640 && !a->cu_seqlens_q) walk = std::max<long>(walk, (long)a->seqlen_q * ratio / (wr >= 0 ? 2 : 1));
   return (a->d == 128 && walk >= 2048) ? 64 : 8;
 }
 

@@ -103,3 +103,20 @@ def test_packed_batch_equals_its_sequences_bit_for_bit(be, knobs, d, causal):
         o1, l1 = out[None, a0:a1].contiguous(), lse[None, :, a0:a1].contiguous()
         g = be.bwd(do[None, a0:a1], q[None, a0:a1], k[None, b0:b1], v[None, b0:b1], o1, l1, None, None, None, None, 0.0, sc, causal, -1, -1, 0.0, False, None, None)
         assert torch.equal(dk[b0:b1], g[1][0]) and torch.equal(dv[b0:b1], g[2][0]), b
+
+
+def test_default_counts_the_query_heads_of_a_gqa_group(be):
+    """fa_api.cpp bwd_dkdv_schedule (round 6, late): a key block of a GQA group walks ratio x Sq query rows -- half of them on average under a right bound -- so this
+    kernel is picked from 2k WALKED rows (not below 640 rows per head); results under the reference's rule against fp32."""
+    for (B, S, H, Hk, causal, want) in ((2, 1024, 32, 8, True, 64), (2, 1024, 16, 2, True, 64), (2, 1024, 8, 4, True, 8), (2, 1024, 32, 8, False, 64), (3, 640, 16, 2, False, 64),
+                                        (3, 512, 32, 8, True, 8), (2, 768, 8, 2, True, 8), (2, 1024, 8, 4, False, 64), (2, 1024, 4, 4, False, 8)):
+        torch.manual_seed(S + H)
+        q = torch.randn(B, S, H, 128, device="cuda", dtype=torch.bfloat16)
+        k = torch.randn(B, S, Hk, 128, device="cuda", dtype=torch.bfloat16)
+        v, do = torch.randn_like(k), torch.randn_like(q)
+        g = run_bwd(be, q, k, v, do, causal)
+        assert g[3]["bwd_dkdv_nw"] == want and g[3]["bwd_spill"] == 0, (B, S, H, Hk, causal, g[3])
+        r, pt = ref_grads(q, k, v, do, causal, -1, -1), ref_grads(q, k, v, do, causal, -1, -1, upcast=False)
+        for i in (0, 1, 2):
+            e, ept = float((g[i].float() - r[i]).abs().max()), float((pt[i] - r[i]).abs().max())
+            assert torch.isfinite(g[i].float()).all() and e <= 3 * ept + 1e-5, (B, S, H, Hk, causal, i, e, ept)
