@@ -505,6 +505,10 @@ bool bwd_fused_by_table(const FaBwdParams* a) {
   if (a->d != 128 || wl >= 0 || a->seqlen_q != a->seqlen_k || (long)a->b * a->h_k < 32) return false;
   if (fa::knobs().bwd_dq_nw != 0 || fa::knobs().bwd_dkdv != 0 || fa::knobs().dkdv_prescale || fa::knobs().strict) return false;
   const int s = a->seqlen_q;
+  // (late round 6, sync-free timings at large batches: from 256 to 511 rows the launch leads once the grid is large -- causal S = 256: 512 units a tie, 1024 +4 %, 1536 +7 %,
+  // 2048 +10 %; S = 320 / 384 on 1024 units +15 % / +13 %, S = 384 / 448 on 512 units +7 % / +9 %, S = 384 on 256 units a tie; S = 128 -5 %; no mask S = 256 / 384 on 2048 units
+  // +3 % / +7 %, S = 384 on 512 units +1 %: profiles/r06_bwd_c5.txt (8))
+  if (s >= 256 && s < 512) { const long us = (long)a->b * a->h_k * s; return wr == 0 ? us >= 196608 : (wr < 0 && us >= 786432); }
   return (wr == 0 && s >= 512 && s <= 4096) || (wr < 0 && s >= 512 && s <= 1536);
 }
 struct FusedPack { int np64, c1, jb, head_tiles; };

@@ -211,7 +211,10 @@ def test_backward_plan_table(lib, monkeypatch):
     assert plan(8, 2048, 2048, 16, 16, 128, is_causal=1) == 3
     assert plan(8, 2048, 2048, 32, 32, 128, is_causal=1) == 3             # 1.03 GiB of packed rows (2 GiB as a square): inside the 1.25 GiB bound, +15 %
     assert plan(32, 512, 512, 16, 16, 128, is_causal=1) == 3              # +8 % at S = 512
-    assert plan(64, 256, 256, 16, 16, 128, is_causal=1) == 0              # a tie at S = 256
+    assert plan(64, 256, 256, 16, 16, 128, is_causal=1) == 3 and plan(32, 256, 256, 16, 16, 128, is_causal=1) == 0   # S = 256: +4 % on 1024 units, a tie on 512 (units x rows >= 196608)
+    assert plan(32, 384, 384, 16, 16, 128, is_causal=1) == 3 and plan(16, 384, 384, 16, 16, 128, is_causal=1) == 0   # S = 384: +7 % on 512 units, a tie on 256
+    assert plan(256, 128, 128, 32, 32, 128, is_causal=1) == 0             # S = 128: -5 %
+    assert plan(64, 384, 384, 32, 32, 128) == 3 and plan(32, 384, 384, 16, 16, 128) == 0   # no mask below 512 rows: from 2048 units at S = 384 (+7 %)
     assert plan(4, 4096, 4096, 32, 32, 128, is_causal=1) == 0             # config 3: 4 GiB of dS -- over the bound (and a tie): the scratch-free pair
     assert plan(1, 4096, 4096, 32, 32, 128, is_causal=1) == 3             # the same rows on 32 heads fit: +9 ... +13 %
     assert plan(2, 3072, 3072, 32, 32, 128, is_causal=1) == 3 and plan(4, 3072, 3072, 32, 32, 128, is_causal=1) == 3   # (0.6 / 1.2 GiB of packed rows: +9 % / +7 %)

@@ -24,12 +24,13 @@ os.environ["FA_DEBUG_POISON_WS"] = "1"
 bad = 0
 for i in range(n):
     causal = rng.random() < 0.7
-    S = rng.choice([512, 1024, 2048, 4096, rng.randint(512, 4096), rng.randint(512, 2048)]) if causal else rng.choice([512, 1024, 1536, rng.randint(512, 1536)])
+    S = rng.choice([512, 1024, 2048, 4096, rng.randint(512, 4096), rng.randint(512, 2048), rng.randint(256, 511)]) if causal else rng.choice([512, 1024, 1536, rng.randint(512, 1536), rng.randint(256, 511)])
     Hk = rng.choice([1, 2, 3, 4, 8]); g = rng.choice([1, 1, 2, 4]); H = Hk * g
     Bmax = max(1, (1 << 30) // (H * ((S + 31) // 32) ** 2 * 2048))
     if -(-32 // Hk) > Bmax:   # (32 units of this shape do not fit 1 GiB: outside the table's region -- draw again)
         S = rng.choice([512, 1024]); Bmax = max(1, (1 << 30) // (H * ((S + 31) // 32) ** 2 * 2048))
     B = rng.randint(max(1, -(-32 // Hk)), max(-(-32 // Hk), min(40, Bmax)))
+    if S < 512: B = max(B, -(-(196608 if causal else 786432) // (S * Hk)))   # (below 512 rows the table asks for a large grid: units x rows)
     if S <= 2048 and rng.random() < 0.3:   # (late round 6: a batch over the 1.25 GiB bound -> chunks of whole batch entries, one launch each)
         B = rng.randint(Bmax + Bmax // 4 + 1, 3 * Bmax)
     dt = rng.choice([torch.bfloat16, torch.float16])
