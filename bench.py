@@ -216,7 +216,7 @@ def fused_bwd_rows(be, dev, sync):
                     row[key + "_handoff"] = be.last_schedule().get("bwd_spill")   # 0 = recomputing pair, 3 = fused launch, 5 = chunked launches
             row["workspace_gb"] = round(B * H * (S // 32) ** 2 * 2048 / 2 ** 30, 2)
             rows.append(row)
-        return {"rows": rows, "note": "default = the table of fa_api.cpp bwd_fused_by_table: the fused launch at head dim 128, Sq = Sk, >= 32 units, causal 512-4096 rows / no mask 512-1536 rows within 1.25 GiB (up to 2048 rows: in chunks of batch entries), else the pair"}
+        return {"rows": rows, "note": "default = the table of fa_api.cpp bwd_fused_by_table: the fused launch at head dim 128, Sq = Sk, >= 32 units, causal 512-4096 rows within 1.25 GiB (up to 2048 rows: in chunks of batch entries), else the pair"}
     except Exception as e:  # noqa: BLE001
         return {"rows": rows, "error": repr(e)[:300]}
     finally:

@@ -409,7 +409,15 @@ int bwd_dq_schedule(const FaBwdParams* a) {
     if (right_bounded) { avg_keys = (long)a->seqlen_k - a->seqlen_q / 2 + wr; if (avg_keys > a->seqlen_k) avg_keys = a->seqlen_k; if (avg_keys < 0) avg_keys = 0; }
     return (plain && a->window_left < 0 && a->seqlen_q >= 512 && avg_keys >= 2048) ? 64 : 4;
   }
-  return (a->d == 128 && plain && a->seqlen_k >= 2048 && a->seqlen_q >= 512) ? 64 : 4;
+  if (a->d != 128 || !plain || a->seqlen_q < 512) return 4;
+  if (a->seqlen_k >= 2048) return 64;
+  // (late round 6: WITHOUT a right bound the 64-rows-per-wave kernel already leads from 768 keys once its 256-row blocks fill the chip -- whole backward, TFLOP/s, 32 rows
+  // per wave | 64: S = 768 569 | 591, S = 1024 631 | 650, S = 1280 667 | 702, S = 1536 677 | 720 (B16 H32: 699 | 751), S = 1600 on 448 blocks 569 | 619, GQA 32/8 S = 1024 on
+  // 256 blocks 328 | 345; S = 512 500 | 485.  Under a causal mask a tie at S = 1600 (516 | 522) and behind on small grids (S = 1536 on 96 blocks 174 | 165): profiles/r06_bwd_c5.txt (9))
+  const bool right_bounded = a->is_causal || a->window_right >= 0;
+  const long blocks256 = a->cu_seqlens_q ? 0 : (long)a->b * a->h * ((a->seqlen_q + 255) / 256);
+  const bool featureless = a->softcap == 0.f && a->p_dropout == 0.f && !a->alibi_slopes;   // (the feature variants were not measured below 2k keys)
+  return (featureless && !right_bounded && a->window_left < 0 && a->seqlen_k >= 768 && blocks256 >= 256) ? 64 : 4;
 }
 
 // dK/dV schedule (fa_launch.h Knobs::bwd_dkdv): 64 = four waves x 64 keys (fa_bwd_dkdv_w64.hip; plain attention or causal ALiBi at head dim 64 / 128, softcap at head dim 128), 8 = eight waves x 32 keys
@@ -495,7 +503,7 @@ void bwd_list_entries(const FaBwdParams* a, int64_t& q_entries, int64_t& k_entri
 // Round 6: it is the DEFAULT (FA_BWD_MODE=0) where it was measured ahead of the recomputing pair and its workspace stays within bounds (bwd_fused_plan below; profiles/r06_bwd_c5.txt (5), timed
 // WITHOUT the status read -- a stream sync per call, which the default path does not do and which cost the launch 9 % at S = 1024): head dim 128, Sq = Sk, at least
 // 32 (batch, kv head) units, under a causal mask from 512 to 4096 rows (+8 % / +18 % / +15 % at S = 512 / 1024 / 2048 on the sweep's shapes, +7 ... +9 % at S = 3072 and
-// +9 ... +13 % at S = 4096 on the grids that fit the 1 GiB -- 32 heads) and without a mask from 512 to 1536 rows (+1.5 % / +5 % / +5.6 % / +3 ... +5 % at 512 / 768 / 1024 / 1536).
+// +9 ... +13 % at S = 4096 on the grids that fit the 1 GiB -- 32 heads) and -- until the pair's dQ half got the 64-rows-per-wave kernel below 2k keys, see the return below -- without a mask from 512 to 1536 rows (+1.5 % / +5 % / +5.6 % / +3 ... +5 % at 512 / 768 / 1024 / 1536).
 // Where the workspace would exceed 1 GiB it ties or loses anyway (config 3: a tie on 4 GiB; S = 4096 on 64 heads +3 % on 2 GiB; S = 8192 -8 %); without a mask from
 // S = 2048 -6 ... -10 %; head dim 64 without a mask -20 % (causal +3 % / -1 %: left to the pair); small grids (16 units) -3 %.
 // FA_BWD_MODE=3 forces it wherever it applies (cap FA_BWD_DS_CAP_MB), -1 / 1 never.
@@ -509,7 +517,9 @@ bool bwd_fused_by_table(const FaBwdParams* a) {
   // 2048 +10 %; S = 320 / 384 on 1024 units +15 % / +13 %, S = 384 / 448 on 512 units +7 % / +9 %, S = 384 on 256 units a tie; S = 128 -5 %; no mask S = 256 / 384 on 2048 units
   // +3 % / +7 %, S = 384 on 512 units +1 %: profiles/r06_bwd_c5.txt (8))
   if (s >= 256 && s < 512) { const long us = (long)a->b * a->h_k * s; return wr == 0 ? us >= 196608 : (wr < 0 && us >= 786432); }
-  return (wr == 0 && s >= 512 && s <= 4096) || (wr < 0 && s >= 512 && s <= 1536);
+  // (without a mask from 512 rows: the pair, whose dQ half takes the 64-rows-per-wave kernel from 768 keys since late round 6 -- bwd_dq_schedule -- and is then level with
+  // this launch or ahead of it at no workspace: S = 768 569 fused | 591 pair, 1024 658 | 650, 1280 696 | 702, 1536 698 | 720, B16 H32 S = 1536 739 | 751; S = 512 a tie on either dQ kernel)
+  return wr == 0 && s >= 512 && s <= 4096;
 }
 struct FusedPack { int np64, c1, jb, head_tiles; };
 FusedPack fused_pack(int sq, int sk, int wr) {   // the row packing of the dS workspace (as C5Plan's)

@@ -235,10 +235,10 @@ def test_fused_backward_declines_what_it_does_not_cover(be, knobs):
 
 
 # Round 6: the table (fa_api.cpp bwd_fused_by_table) hands plain attention at head dim 128 with Sq = Sk, >= 32 (batch, kv head) units and <= 1 GiB of packed dS to the
-# fused launch BY DEFAULT: causal 512 .. 4096 rows, no mask 512 .. 1536 rows.  No knob is set here except the workspace poison: this is the call a user makes.
+# fused launch BY DEFAULT: causal 512 .. 4096 rows (and from 256 rows on large grids, with or without a mask).  No knob is set here except the workspace poison: this is the call a user makes.
 TABLE_SHAPES = [  # B, S, H, Hk, causal
     (16, 512, 2, 2, True), (8, 1024, 4, 4, True), (4, 2048, 8, 8, True), (1, 4096, 32, 32, True), (8, 1024, 16, 4, True), (11, 704, 3, 3, True), (32, 515, 1, 1, True),
-    (16, 512, 2, 2, False), (8, 1024, 8, 4, False), (4, 1536, 8, 8, False), (9, 777, 4, 4, False),
+    (128, 384, 16, 16, False),   # (without a mask only below 512 rows on large grids: units x rows >= 786432; from 512 rows the pair is level or ahead since its dQ half takes the 64-rows-per-wave kernel from 768 keys)
 ]
 
 

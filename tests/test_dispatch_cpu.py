@@ -117,7 +117,10 @@ def test_backward_dq_schedule(lib, monkeypatch):
         return a
     dq = lambda a: lib.fa_bwd_dq_schedule_query(C.byref(a))
     assert dq(bp(4, 4096, 32, 128)) == 64
-    assert dq(bp(4, 1024, 32, 128)) == 4
+    assert dq(bp(4, 1024, 32, 128, is_causal=1)) == 4
+    # (late round 6) without a right bound from 768 keys, once the 256-row blocks fill the chip (>= 256 of them), plain attention only
+    assert dq(bp(4, 1024, 32, 128)) == 64 and dq(bp(8, 768, 16, 128)) == 64 and dq(bp(8, 640, 16, 128)) == 4 and dq(bp(1, 1024, 16, 128)) == 4
+    assert dq(bp(4, 1024, 32, 128, softcap=20.0)) == 4 and dq(bp(4, 1024, 32, 128, window_left=100)) == 4
     assert dq(bp(4, 4096, 32, 64)) == 64                                 # head dim 64 (round 4): from ~2k visible keys per row on average
     assert dq(bp(8, 2048, 16, 64)) == 64                                 # config 2's shape
     assert dq(bp(4, 4096, 32, 64, is_causal=1)) == 64                    # (a tie there)
@@ -201,7 +204,7 @@ def _plan(lib, a):
 
 def test_backward_plan_table(lib, monkeypatch):
     """Round 6 (fa_api.cpp bwd_fused_by_table): the fused 5-contraction launch is the default at head dim 128 with Sq = Sk and at least 32 (batch, kv head) units, under a
-    causal mask from 512 to 4096 rows and without a mask from 512 to 1536 rows, while its dS workspace fits 1.25 GiB (whole, or up to 2048 rows in chunks of batch entries) -- where it was measured ahead -- and nowhere
+    causal mask from 512 to 4096 rows (from 256 rows on large grids, there also without a mask), while its dS workspace fits 1.25 GiB (whole, or up to 2048 rows in chunks of batch entries) -- where it was measured ahead -- and nowhere
     else; knobs that pin a kernel of the recomputing pair keep the pair."""
     for v in ("FA_BWD_MODE", "FA_BWD_DQ_NW", "FA_BWD_DKDV", "FA_STRICT"):
         monkeypatch.delenv(v, raising=False)
@@ -225,13 +228,12 @@ def test_backward_plan_table(lib, monkeypatch):
     assert full(64, 1024, 1024, 32, 32, 128, is_causal=1)[:3] == [3, 2, 32]   # 2.2 GiB -> two chunks of 32 batch entries
     assert full(16, 2048, 2048, 32, 32, 128, is_causal=1)[:3] == [3, 2, 8]    # 2.06 GiB (+12 %)
     assert full(65, 1024, 1024, 32, 32, 128, is_causal=1)[:3] == [3, 2, 33] and full(65, 1024, 1024, 32, 32, 128, is_causal=1)[7] <= 1280
-    assert full(32, 1024, 1024, 32, 32, 128)[:3] == [3, 2, 16]                # no mask: 2 GiB -> two chunks (+7.5 %)
     assert full(16, 1024, 1024, 16, 16, 128, is_causal=1)[:3] == [3, 1, 16]
     assert plan(64, 2048, 2048, 32, 1, 128, is_causal=1) == 0              # MQA: nine batch entries fit = nine (batch, kv head) units per chunk: the pair
-    assert plan(4, 1536, 1536, 32, 32, 128) == 3                          # without a mask up to 1536 rows
+    assert plan(4, 1536, 1536, 32, 32, 128) == 0                          # without a mask from 512 rows: the pair (its dQ half on 64 rows per wave from 768 keys is level or ahead, at no workspace)
     assert plan(2, 8192, 8192, 16, 16, 128, is_causal=1) == 0
-    assert plan(16, 1024, 1024, 16, 16, 128) == 3                         # without a mask: +5.6 % at S = 1024 ...
-    assert plan(8, 2048, 2048, 16, 16, 128) == 0                          # ... behind from S = 2048
+    assert plan(16, 1024, 1024, 16, 16, 128) == 0 and plan(32, 512, 512, 16, 16, 128) == 0
+    assert plan(8, 2048, 2048, 16, 16, 128) == 0
     assert plan(2, 2048, 2048, 32, 8, 128, is_causal=1) == 0              # 16 (batch, kv head) units: measured behind
     assert plan(4, 1024, 1024, 32, 8, 128, is_causal=1) == 3              # 32 units, four query heads each: +8 %
     assert plan(16, 1024, 1024, 32, 32, 64, is_causal=1) == 0             # ... and at head dim 64

@@ -1,5 +1,5 @@
 """Random shapes inside the region where round 6's dispatch table gives the backward to the fused launch BY DEFAULT (head dim 128, Sq = Sk, >= 32 (batch, kv head) units, causal 512 .. 2048 rows or
-no mask 512 .. 1024 rows, dS workspace <= 1.25 GiB, larger batches in chunks): the default against the recomputing pair pinned onto the same dK/dV kernel text (dK / dV bitwise, dQ within rounding and within the
+from 256 rows on large grids with or without a mask, dS workspace <= 1.25 GiB, larger batches in chunks): the default against the recomputing pair pinned onto the same dK/dV kernel text (dK / dV bitwise, dQ within rounding and within the
 reference's rule against fp32), twice (bitwise), through the autograd interface as well.  usage: python tools/bwd_table_stress.py [cases] [seed]"""
 import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
