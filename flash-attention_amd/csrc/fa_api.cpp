@@ -440,7 +440,8 @@ int bwd_dkdv_schedule(const FaBwdParams* a) {
   // pair, TFLOP/s eight-wave | this kernel: causal S = 1024 ratio 4 158-172 | 165-182 (+5 %), ratio 8 168-172 | 178-182 (+6 %), S = 768 ratio 4 +2 %, S = 512 ratio 4 / 8 -2 %;
   // no mask S = 1024 ratio 4 296-306 | 322-332 (+8.5 %), S = 1536 ratio 4 +8 %, S = 640 ratio 8 +10 %: from 2k walked rows on average, not below 640 rows per head)
   else if (a->window_left < 0 && ratio > 1 && a->seqlen_q >= 640 && !a->cu_seqlens_q) walk = std::max<long>(walk, (long)a->seqlen_q * ratio / (wr >= 0 ? 2 : 1));
-  return (a->d == 128 && walk >= 2048) ? 64 : 8;
+  // (late round 6: without any mask from 1536 walked rows -- S = 1536 688 | 720, S = 1792 667 | 695 TFLOP/s on the whole backward, S = 1280 / 1024 +1 ... +2 %; under a causal mask a tie below 2k)
+  return (a->d == 128 && walk >= ((wr < 0 && a->window_left < 0) ? 1536 : 2048)) ? 64 : 8;
 }
 
 int fill_bwd(const FaBwdParams* a, bool varlen, fa::BwdK& k) {

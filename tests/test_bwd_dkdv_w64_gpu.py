@@ -58,7 +58,7 @@ def test_dkdv_w64_against_fp32_and_the_eight_wave_kernel(be, knobs, shape, dtype
 
 
 def test_default_picks_it_from_2k_query_rows_at_head_dim_128(be):
-    for (S, d, causal, want) in ((4096, 128, True, 64), (2048, 128, False, 64), (1024, 128, False, 8), (4096, 64, True, 8)):
+    for (S, d, causal, want) in ((4096, 128, True, 64), (2048, 128, False, 64), (1024, 128, False, 8), (1536, 128, False, 64), (1536, 128, True, 8), (4096, 64, True, 8)):   # (late round 6: without a mask from 1536 rows)
         q = torch.randn(1, S, 2, d, device="cuda", dtype=torch.bfloat16)
         k, v, do = torch.randn_like(q), torch.randn_like(q), torch.randn_like(q)
         g = run_bwd(be, q, k, v, do, causal)
