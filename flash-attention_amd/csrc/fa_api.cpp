@@ -407,7 +407,8 @@ int bwd_dq_schedule(const FaBwdParams* a) {
     const long wr = a->is_causal ? 0 : a->window_right;
     long avg_keys = a->seqlen_k;
     if (right_bounded) { avg_keys = (long)a->seqlen_k - a->seqlen_q / 2 + wr; if (avg_keys > a->seqlen_k) avg_keys = a->seqlen_k; if (avg_keys < 0) avg_keys = 0; }
-    return (plain && a->window_left < 0 && a->seqlen_q >= 512 && avg_keys >= 2048) ? 64 : 4;
+    // (late round 6: without a right bound from 1536 keys -- whole backward S = 1536 567 | 583, S = 1792 578 | 596 TFLOP/s, a tie at S = 1024)
+    return (plain && a->window_left < 0 && a->seqlen_q >= 512 && avg_keys >= (right_bounded ? 2048 : 1536)) ? 64 : 4;
   }
   if (a->d != 128 || !plain || a->seqlen_q < 512) return 4;
   if (a->seqlen_k >= 2048) return 64;

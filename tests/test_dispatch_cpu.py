@@ -126,7 +126,7 @@ def test_backward_dq_schedule(lib, monkeypatch):
     assert dq(bp(4, 4096, 32, 64, is_causal=1)) == 64                    # (a tie there)
     assert dq(bp(8, 2048, 32, 64, is_causal=1)) == 4
     assert dq(bp(2, 8192, 32, 64, is_causal=1)) == 64
-    assert dq(bp(16, 1024, 32, 64)) == 4
+    assert dq(bp(16, 1024, 32, 64)) == 4 and dq(bp(16, 1536, 32, 64)) == 64 and dq(bp(16, 1536, 32, 64, is_causal=1)) == 4   # (late round 6: without a right bound from 1536 keys)
     assert dq(bp(4, 4096, 32, 128, softcap=20.0)) == 64                   # round 5: softcap / dropout variants of the 64-rows-per-wave dQ kernel at head dim 128
     assert dq(bp(4, 4096, 32, 128, p_dropout=0.1)) == 64
     assert dq(bp(4, 4096, 32, 64, softcap=20.0)) == 4                     # ... not at head dim 64 (the 4-wave feature kernel measured ahead), not for products of features
