@@ -55,6 +55,7 @@ const fa::Knobs* read_knobs() {
   k->bwd_fused_check = env_int("FA_BWD_FUSED_CHECK", 0);
   k->bwd_c5_cap_mb = std::max(16, std::min(65536, env_int("FA_BWD_C5_CAP_MB", 1024)));
   k->fz_line = std::max(1, std::min(64, env_int("FA_FZ_LINE", 32)));
+  k->bwd_gsplit = env_int("FA_BWD_GSPLIT", 1);
   k->w64_persist = env_int("FA_W64_PERSIST", 1);
   k->strict = env_int("FA_STRICT", 0);
   k->dkdv_prescale = env_int("FA_DKDV_PRESCALE", 0);
@@ -605,11 +606,48 @@ bool bwd_c5_plan(const FaBwdParams* a, C5Plan& pl) {
 }
 
 // the dK/dV launch of either schedule (-2 from the 64-keys-per-wave launcher = not covered after all: nothing was enqueued)
-int launch_dkdv_any(const FaBwdParams* a, const fa::BwdK& k, int bf, int dk_, hipStream_t s) {
+// GQA group split (late round 6).  The dK/dV kernels own (batch, kv head, key block) items and walk the group's query heads inside: with few kv heads and a small batch
+// the grid does not fill the chip (B2 S1024 H32/2: 16 workgroups on 256 CUs, 55 TFLOP/s).  The group is then split into gs = 2^n virtual kv heads -- consecutive query
+// heads each, BwdK::kv_in_shift tells the kernels which real K / V head to read --, their partial dK / dV go to a workspace [b][sk][h_k * gs][d] in the input dtype and
+// one small kernel sums them (the reference's own form: per-query-head dK / dV summed by at::sum_out, flash_api.cpp:1000-1004).  Fixed-length batches, head dims the
+// kernels hold natively; gs = the smallest power of two (<= 8) that brings the grid to 1024 workgroups, or the whole group.
+struct GsplitPlan { int gs, shift; int64_t bytes; };
+bool bwd_gsplit_plan(const FaBwdParams* a, GsplitPlan& pl) {
+  pl = GsplitPlan{1, 0, 0};
+  if (fa::knobs().bwd_gsplit == 0 || a->cu_seqlens_q || a->cu_seqlens_k || a->seqused_q || a->seqused_k || a->h_k <= 0 || a->h % a->h_k != 0 || a->d % 8 != 0 || !head_dim_native(a->d)) return false;
+  const int ratio = a->h / a->h_k;
+  if (ratio < 2 || a->seqlen_k <= 0 || a->seqlen_q <= 0 || a->b <= 0) return false;
+  const long wgs = (long)a->b * a->h_k * ((a->seqlen_k + fa::bwd_block_n(a->d) - 1) / fa::bwd_block_n(a->d));
+  int gs = 1, shift = 0;
+  if (fa::knobs().bwd_gsplit > 1) { while (gs * 2 <= fa::knobs().bwd_gsplit && ratio % (gs * 2) == 0) { gs *= 2; ++shift; } }   // (forced, for tests)
+  else { while (wgs * gs < 1024 && gs < 8 && ratio % (gs * 2) == 0) { gs *= 2; ++shift; } }   // (measured, profiles/r06_bwd_gsplit.txt: past 8 virtual heads nothing is gained; 512 uneven causal items on 256 CUs still gain 10 % from a split in two)
+  if (gs < 2) return false;
+  pl.gs = gs; pl.shift = shift;
+  pl.bytes = 2 * (((int64_t)a->b * a->seqlen_k * a->h_k * gs * a->d * 2 + 255) & ~(int64_t)255);
+  return true;
+}
+
+int launch_dkdv_any(const FaBwdParams* a, const fa::BwdK& k_in, int bf, int dk_, hipStream_t s) {
+  fa::BwdK k = k_in;
+  FaBwdParams a2 = *a;
+  GsplitPlan gp;
+  const bool split = !k.ds_ws && !k.k_list && bwd_gsplit_plan(a, gp) && a->workspace && a->workspace_bytes >= gp.bytes;
+  if (split) {
+    const int hk2 = a->h_k * gp.gs;
+    a2.h_k = hk2;
+    k.h_k = hk2; k.hk_ratio = a->h / hk2; k.kv_in_shift = gp.shift;
+    k.dk = a->workspace; k.dv = (char*)a->workspace + gp.bytes / 2;
+    k.dk_bs = k.dv_bs = (int64_t)a->seqlen_k * hk2 * a->d; k.dk_rs = k.dv_rs = (int64_t)hk2 * a->d; k.dk_hs = k.dv_hs = a->d;
+    fa::choose_units(a->b, hk2, 1, k.nnb, k.k_units, k.k_unit_size, k.k_unit_hpx);
+  }
   int rc = -2, nw = 64;
-  if (!k.ds_ws && bwd_dkdv_schedule(a) == 64) rc = fa::launch_bwd_dkdv_w64(k, bf, a->d, s);
+  if (!k.ds_ws && bwd_dkdv_schedule(&a2) == 64) rc = fa::launch_bwd_dkdv_w64(k, bf, a->d, s);
   if (rc == -2) { nw = a->d > 128 ? 4 : 8; rc = fa::launch_bwd_dkdv(k, bf, dk_, s); }
   fa::last_schedule().bwd_dkdv_nw = nw;
+  if (rc == 0 && split) {
+    rc = fa::launch_bwd_gsum(k.dk, k_in.dk, bf, a->b, a->seqlen_k, a->h_k, gp.gs, a->d, k_in.dk_bs, k_in.dk_rs, k_in.dk_hs, s);
+    if (rc == 0) rc = fa::launch_bwd_gsum(k.dv, k_in.dv, bf, a->b, a->seqlen_k, a->h_k, gp.gs, a->d, k_in.dv_bs, k_in.dv_rs, k_in.dv_hs, s);
+  }
   return rc;
 }
 
@@ -786,6 +824,7 @@ int fa_bwd_plan_query(const FaBwdParams* a, int32_t* out, int n) {
     v[0] = 3;
     FusedPlan fpl; bwd_fused_plan(a, fpl); v[1] = fpl.n_chunks; v[2] = fpl.nb; v[7] = (int32_t)((fpl.ds_bytes + fpl.sync_bytes) >> 20);
   }
+  if (v[0] == 0) { GsplitPlan gp; if (bwd_gsplit_plan(a, gp)) { v[3] = gp.gs; v[7] = (int32_t)(gp.bytes >> 20); } }   // (the pair: its dK/dV half on a split GQA group)
   for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   return 8;
 }
@@ -864,6 +903,7 @@ int64_t fa_bwd_workspace_bytes(const FaBwdParams* params) {
   bwd_list_entries(params, qe, ke);
   if (const int64_t fz = bwd_fused_ds_bytes(params); fz > 0) return fz + bwd_fused_sync_bytes(params);
   if (C5Plan pl; bwd_c5_plan(params, pl)) return 2 * pl.slot_bytes;
+  if (GsplitPlan gp; bwd_gsplit_plan(params, gp)) return gp.bytes;   // (a split GQA group's partial dK / dV; optional like the dS area: without it the unsplit kernels run)
   return (qe ? (qe + 1) * 8 : 0) + (ke ? (ke + 1) * 8 : 0);   // (work lists: varlen only)
 }
 int fa_bwd(const FaBwdParams* params, void* stream) { return do_bwd(params, stream, false); }

@@ -95,6 +95,35 @@ __global__ void __launch_bounds__(256) fa_bwd_delta_kernel(const BwdK p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// GQA group split (fa_api.cpp bwd_gsplit_plan): dst[b, row, g, :] = sum over s < gs of src[b, row, g * gs + s, :]  (fp32 sum of partials in the input dtype -- the
+// reference's own form: per-query-head dK / dV in the input dtype summed by at::sum_out, flash_api.cpp:1000-1004).  src is contiguous [b][sk][h_k * gs][d].
+// ------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void __launch_bounds__(256) fa_bwd_gsum_kernel(const E* __restrict__ src, E* __restrict__ dst, long long total, int sk, int h_k, int gs, int d8,
+                                                         int64_t dst_bs, int64_t dst_rs, int64_t dst_hs) {
+  using V8 = typename ElemTraits<E>::v8;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // (b, row, g, 16-byte chunk)
+  if (i >= total) return;
+  const int c = (int)(i % d8);
+  const long long t = i / d8;
+  const int g = (int)(t % h_k);
+  const long long br = t / h_k;
+  const int row = (int)(br % sk);
+  const int b = (int)(br / sk);
+  const E* sp = src + ((br * h_k + g) * gs) * (int64_t)(d8 * 8) + c * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s_ = 0; s_ < gs; ++s_) {
+    const V8 x = bitcast_u32x4<V8>(*reinterpret_cast<const u32x4*>(sp + (int64_t)s_ * d8 * 8));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += (float)x[j];
+  }
+  V8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (E)acc[j];
+  *reinterpret_cast<u32x4*>(dst + (int64_t)b * dst_bs + (int64_t)row * dst_rs + (int64_t)g * dst_hs + c * 8) = __builtin_bit_cast(u32x4, o);
+}
+
+// ------------------------------------------------------------------------------------------------
 // dK / dV
 // ------------------------------------------------------------------------------------------------
 // The kernel's text is a device function so that the fused backward (fa_bwd_fused_kernel below, FUSED = true) can run the dQ contractions of finished
@@ -171,8 +200,8 @@ static __device__ __forceinline__ void fa_bwd_dkdv_body(const BwdK& p, const int
   const int n1 = min(n0 + BNK, sk);
   const int shift = sk - sq;
 
-  const E* __restrict__ kp = (const E*)p.k + k_boff + k_row0 * p.k_rs + (int64_t)hk * p.k_hs;
-  const E* __restrict__ vp = (const E*)p.v + v_boff + k_row0 * p.v_rs + (int64_t)hk * p.v_hs;
+  const E* __restrict__ kp = (const E*)p.k + k_boff + k_row0 * p.k_rs + (int64_t)(hk >> p.kv_in_shift) * p.k_hs;   // (kv_in_shift: a GQA group split into virtual kv heads, fa_kernel_params.h)
+  const E* __restrict__ vp = (const E*)p.v + v_boff + k_row0 * p.v_rs + (int64_t)(hk >> p.kv_in_shift) * p.v_hs;
 
   // ---- query range that can see this key block -------------------------------------------------
   int q_lo = 0, q_hi = sq - 1;
@@ -1260,6 +1289,14 @@ static int launch_dq_t(const BwdK& p, hipStream_t stream) {
 
 #if FA_BWD_PART == 0 || FA_BWD_PART == 1
 int launch_bwd_delta(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_delta_t) }
+int launch_bwd_gsum(const void* src, void* dst, int dtype_bf16, int b, int sk, int h_k, int gs, int d, int64_t dst_bs, int64_t dst_rs, int64_t dst_hs, hipStream_t stream) {
+  const long long total = (long long)b * sk * h_k * (d / 8);
+  if (total <= 0) return 0;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype_bf16) hipLaunchKernelGGL(fa_bwd_gsum_kernel<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)src, (__bf16*)dst, total, sk, h_k, gs, d / 8, dst_bs, dst_rs, dst_hs);
+  else hipLaunchKernelGGL(fa_bwd_gsum_kernel<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)src, (_Float16*)dst, total, sk, h_k, gs, d / 8, dst_bs, dst_rs, dst_hs);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream) { FA_BWD_DISPATCH(launch_dkdv_t) }
 #endif
 #if FA_BWD_PART == 0 || FA_BWD_PART == 2

@@ -137,8 +137,8 @@ static __device__ __forceinline__ void dkdv_w64_body(const BwdK p, const int bid
   const int n1 = min(n0 + BNK, sk);
   const int shift = sk - sq;
 
-  const E* __restrict__ kp = (const E*)p.k + k_boff + k_row0 * p.k_rs + (int64_t)hk * p.k_hs;
-  const E* __restrict__ vp = (const E*)p.v + v_boff + k_row0 * p.v_rs + (int64_t)hk * p.v_hs;
+  const E* __restrict__ kp = (const E*)p.k + k_boff + k_row0 * p.k_rs + (int64_t)(hk >> p.kv_in_shift) * p.k_hs;   // (kv_in_shift: a GQA group split into virtual kv heads, fa_kernel_params.h)
+  const E* __restrict__ vp = (const E*)p.v + v_boff + k_row0 * p.v_rs + (int64_t)(hk >> p.kv_in_shift) * p.v_hs;
 
   // query range that can see this key block, in tiles of 32
   int q_lo = 0, q_hi = sq - 1;

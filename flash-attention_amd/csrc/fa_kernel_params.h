@@ -120,6 +120,8 @@ struct BwdK {
   int32_t fuse_items;        // dQ items of the fused backward = b * h * nmb (256-row blocks)
   int32_t fuse_line;         // words between two arrival counters of the sync area
   int32_t fuse_total;        // key-block items of the fused backward (= the dK/dV kernel's grid)
+  int32_t kv_in_shift;       // dK/dV kernels: K / V are read from kv head (hk >> kv_in_shift) while dK / dV, the head walk and everything else use hk -- a GQA group split into
+                             // 2^kv_in_shift virtual kv heads whose partial dK / dV the host sums afterwards (fa_api.cpp bwd_gsplit_plan; 0 = off)
   int32_t fuse_keep_err;     // host side: this launch is not the call's first chunk -- its memset leaves the error flag (word FZ_ERR = 0) alone
   // 5-contraction backward (round 6, fa_bwd_dkdv_w64.hip fa_bwd_c5_kernel): one launch = the dK/dV items of one chunk of (batch, kv head) units, which write dS to the
   // slot ds_ws, followed by the dQ = dS.K items of the chunk BEFORE it, which read the slot ds_rd the previous launch filled (stream order is the hand-off).  Units are

@@ -22,6 +22,7 @@ struct Knobs {
                        // 5 = the 5-contraction backward in chunked mixed launches (fa_bwd_dkdv_w64.hip fa_bwd_c5_kernel; workspace bounded by FA_BWD_C5_CAP_MB);
                        // -1 = never (the recomputing pair everywhere); 0 = the measured table (fa_api.cpp bwd_c5_plan)
   int bwd_c5_cap_mb;   // FA_BWD_C5_CAP_MB: workspace bound of the 5-contraction backward, both slots together (default 1024)
+  int bwd_gsplit;      // FA_BWD_GSPLIT: GQA group split of the dK/dV kernels (fa_api.cpp bwd_gsplit_plan): 1 (default) = when the grid does not fill the chip, 0 = never, n > 1 = always, up to n virtual heads per group (tests)
   int fz_line;         // FA_FZ_LINE: fused backward, int32 words between two arrival counters of the sync area (default 32 = one 128-byte line each)
   int bwd_ds_cap_mb;   // FA_BWD_DS_CAP_MB: largest dS workspace FA_BWD_MODE=3 asks for (default 8192)
   int bwd_fused_check; // FA_BWD_FUSED_CHECK=-1: never read the flag, not even for FA_BWD_MODE=3 (A/B timings of the launch itself); =1: fa_bwd_fused_status reads the fused launch's error flag (a stream sync) also where the fused backward ran by default
@@ -132,6 +133,7 @@ int launch_fwd_w64(const FwdK& p, int dtype_bf16, int d, hipStream_t stream);
 // Backward: delta = rowsum(dO*O) pre-pass, dK/dV kernel (loops over query blocks),
 // dQ kernel (loops over key blocks).  Same return convention.
 int launch_bwd_delta(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
+int launch_bwd_gsum(const void* src, void* dst, int dtype_bf16, int b, int sk, int h_k, int gs, int d, int64_t dst_bs, int64_t dst_rs, int64_t dst_hs, hipStream_t stream);   // fa_bwd.hip: sums a split GQA group's partial dK / dV
 int launch_bwd_dkdv(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);
 int launch_bwd_fused(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);   // fa_bwd.hip (FA_BWD_PART=3): dK/dV + dQ = dS.K in one launch; -2 = does not apply
 int launch_bwd_dq(const BwdK& p, int dtype_bf16, int d, hipStream_t stream);

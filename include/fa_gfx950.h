@@ -233,6 +233,7 @@ int fa_bwd_dq_schedule_query(const FaBwdParams* params);
  * = chunks of whole batch entries, out[2] = batch entries per chunk, out[7] = MiB of workspace),
  * 5 = the chunked 5-contraction backward (FA_BWD_MODE=5); for 5: out[1] = chunks, out[2] = XCD rounds (8 units) per chunk, out[3] = dS sub-tiles (2 KB) per
  * head with packed rows, out[4] = 64-key pairs per row, out[5] / out[6] = the row packing's a / jb (csrc/fa_device.h ds_row_start), out[7] = MiB per slot.
+ * For 0 (the pair): out[3] = virtual kv heads per GQA group when the dK/dV kernels split the groups to fill the chip (0 = unsplit), out[7] = MiB of workspace for the partials.
  * Returns the number of fields (8) or a negative FA_ERR_*. */
 int fa_bwd_plan_query(const FaBwdParams* params, int32_t* out, int n);
 

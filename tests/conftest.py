@@ -59,3 +59,23 @@ def dropout_cases():
         B, Sq, Sk, H = [int(x) for x in c["meta"][:4]]
         c["keep"] = np.unpackbits(c["keep"])[: B * H * Sq * Sk].reshape(B, H, Sq, Sk).astype(bool)
     return cases
+
+
+# Modules whose tests compare two PATHS bit for bit (varlen against per-sequence calls, the fused / chunked launches against the pair, one dK/dV kernel against the other):
+# those equalities are statements about kernel texts and hold between UNSPLIT GQA groups -- the group split of the dK/dV kernels (fa_api.cpp bwd_gsplit_plan, late round 6)
+# rounds its partial dK / dV to the input dtype before summing them and is chosen per call from the grid's size, so a one-sequence call may split where the packed batch
+# does not.  They run with FA_BWD_GSPLIT=0; tests/test_bwd_gsplit_gpu.py covers the split (forced, automatic, off), every other module runs with the default.
+_UNSPLIT_MODULES = {"test_bwd_gpu", "test_bwd_schedules_gpu", "test_bwd_c5_gpu", "test_bwd_dkdv_w64_gpu", "test_bwd_alibi_w64_gpu", "test_headdim_trimmed_gpu"}
+
+
+@pytest.fixture(autouse=True)
+def _pin_group_split(request, monkeypatch):
+    if request.module.__name__.split(".")[-1] in _UNSPLIT_MODULES:
+        from flash_attn_amd import backend
+        monkeypatch.setenv("FA_BWD_GSPLIT", "0")
+        backend.reload_knobs()
+        yield
+        monkeypatch.undo()
+        backend.reload_knobs()
+    else:
+        yield

@@ -3,6 +3,7 @@ tail) against the recomputing pair: dK / dV must be bitwise equal (same kernel t
 contraction order and against an fp32 PyTorch backward, everything bitwise reproducible, with the workspace poisoned (every word a NaN) and the chunk size forced
 small (FA_BWD_C5_CAP_MB) so that several launches alternate the slots; then timings.  Usage: python tools/bwd_c5_check.py [--time-only | --check-only | --short]"""
 import os, sys, statistics
+os.environ["FA_BWD_GSPLIT"] = "0"   # (cross-path bitwise comparisons hold between UNSPLIT GQA groups: tests/conftest.py _UNSPLIT_MODULES)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "flash-attention_amd"))
 import torch

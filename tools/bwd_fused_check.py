@@ -2,6 +2,7 @@
 dK / dV must be bitwise equal (same dK/dV arithmetic), dQ within the rounding of the other contraction order, every result bitwise reproducible and correct
 again when the same workspace is reused with other inputs; then timings.  Usage: python tools/bwd_fused_check.py [--time-only | --check-only]"""
 import os, sys, statistics
+os.environ["FA_BWD_GSPLIT"] = "0"   # (cross-path bitwise comparisons hold between UNSPLIT GQA groups: tests/conftest.py _UNSPLIT_MODULES)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "flash-attention_amd"))
 import torch

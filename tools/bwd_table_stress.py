@@ -2,6 +2,7 @@
 from 256 rows on large grids with or without a mask, dS workspace <= 1.25 GiB, larger batches in chunks): the default against the recomputing pair pinned onto the same dK/dV kernel text (dK / dV bitwise, dQ within rounding and within the
 reference's rule against fp32), twice (bitwise), through the autograd interface as well.  usage: python tools/bwd_table_stress.py [cases] [seed]"""
 import os, sys, random
+os.environ["FA_BWD_GSPLIT"] = "0"   # (cross-path bitwise comparisons hold between UNSPLIT GQA groups: tests/conftest.py _UNSPLIT_MODULES)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "flash-attention_amd"))
 import torch

@@ -2,6 +2,7 @@
 reference: fixed-length and packed batches, causal / windows / GQA / ragged lengths, bf16 and fp16, head dims 128 and 64.  Prints one line per case and
 a final verdict; exit code 1 on a mismatch.  (Different accumulation orders: the two kernels agree to rounding, not bit for bit.)"""
 import os, sys, itertools
+os.environ["FA_BWD_GSPLIT"] = "0"   # (cross-path bitwise comparisons hold between UNSPLIT GQA groups: tests/conftest.py _UNSPLIT_MODULES)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flash-attention_amd"))
 import torch
