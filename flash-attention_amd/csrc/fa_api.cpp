@@ -619,8 +619,11 @@ bool bwd_gsplit_plan(const FaBwdParams* a, GsplitPlan& pl) {
   if (ratio < 2 || a->seqlen_k <= 0 || a->seqlen_q <= 0 || a->b <= 0) return false;
   const long wgs = (long)a->b * a->h_k * ((a->seqlen_k + fa::bwd_block_n(a->d) - 1) / fa::bwd_block_n(a->d));
   int gs = 1, shift = 0;
+  // (under a right bound alone the items are uneven -- 1024 of them; with a left window or no mask they are uniform and short walks pay for the split's extra K / V loads
+  // and partials: config 5, 512 items, 0.994 -> 1.055 ms with a split in two; B1 S8192 H32/8 window 1024 0.502 -> 0.578 -- so there only a grid under 256 items is split)
+  const long target = ((a->is_causal || a->window_right >= 0) && a->window_left < 0) ? 1024 : 256;
   if (fa::knobs().bwd_gsplit > 1) { while (gs * 2 <= fa::knobs().bwd_gsplit && ratio % (gs * 2) == 0) { gs *= 2; ++shift; } }   // (forced, for tests)
-  else { while (wgs * gs < 1024 && gs < 8 && ratio % (gs * 2) == 0) { gs *= 2; ++shift; } }   // (measured, profiles/r06_bwd_gsplit.txt: past 8 virtual heads nothing is gained; 512 uneven causal items on 256 CUs still gain 10 % from a split in two)
+  else { while (wgs * gs < target && gs < 8 && ratio % (gs * 2) == 0) { gs *= 2; ++shift; } }   // (measured, profiles/r06_bwd_gsplit.txt: past 8 virtual heads nothing is gained; 512 uneven causal items on 256 CUs still gain 10 % from a split in two)
   if (gs < 2) return false;
   pl.gs = gs; pl.shift = shift;
   pl.bytes = 2 * (((int64_t)a->b * a->seqlen_k * a->h_k * gs * a->d * 2 + 255) & ~(int64_t)255);
