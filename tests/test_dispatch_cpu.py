@@ -284,3 +284,29 @@ def test_chunked_five_contraction_plan(lib, monkeypatch):
         assert _plan(lib, _bwd_params(2, 1024, 1024, 32, 8, 128, is_causal=1))[1] >= 2
     finally:
         monkeypatch.delenv("FA_BWD_MODE", raising=False); monkeypatch.delenv("FA_BWD_C5_CAP_MB", raising=False); lib.fa_knobs_reload()
+
+
+def test_gqa_group_split_plan(lib, monkeypatch):
+    """fa_api.cpp bwd_gsplit_plan (late round 6): the dK/dV kernels split a GQA group into 2 / 4 / 8 virtual kv heads while their (batch, kv head, key block) grid has
+    fewer than 1024 items under a right bound alone, fewer than 256 with a left window or no mask; the workspace holds the partial dK and dV in the input dtype."""
+    for v in ("FA_BWD_MODE", "FA_BWD_GSPLIT"):
+        monkeypatch.delenv(v, raising=False)
+    lib.fa_knobs_reload()
+    full = lambda *a, **kw: _plan(lib, _bwd_params(*a, **kw))
+    ws = lambda *a, **kw: lib.fa_bwd_workspace_bytes(C.byref(_bwd_params(*a, **kw)))
+    assert full(2, 1024, 1024, 32, 2, 128, is_causal=1)[:4] == [0, 0, 0, 8]      # 16 items: eight virtual heads per group of 16
+    assert ws(2, 1024, 1024, 32, 2, 128, is_causal=1) == 2 * 2 * 1024 * 2 * 8 * 128 * 2
+    assert full(4, 4096, 4096, 32, 8, 128, is_causal=1)[3] == 2                    # 512 uneven items: two
+    assert full(8, 4096, 4096, 32, 8, 128, is_causal=1)[3] == 0 and ws(8, 4096, 4096, 32, 8, 128, is_causal=1) == 0
+    assert full(2, 8192, 8192, 32, 8, 128, is_causal=1, window_left=1024)[3] == 0   # config 5: 512 uniform items (a split in two costs 6 %)
+    assert full(1, 2048, 2048, 32, 2, 128, is_causal=1, window_left=512)[3] == 8    # 16 items: split, window or not
+    assert full(2, 4096, 4096, 32, 8, 128)[3] == 0 and full(4, 2048, 2048, 32, 4, 128)[3] == 2   # no mask: 256 items unsplit, 128 split in two
+    assert full(2, 1024, 1024, 6, 2, 128, is_causal=1)[3] == 0                     # a group of three: no power of two divides it
+    assert full(2, 1024, 1024, 8, 8, 128, is_causal=1)[3] == 0                     # no group
+    a = _bwd_params(2, 1024, 1024, 32, 2, 128, is_causal=1); a.cu_seqlens_q = a.cu_seqlens_k = 1
+    assert _plan(lib, a)[3] == 0                                                   # packed batches: not split
+    monkeypatch.setenv("FA_BWD_GSPLIT", "0"); lib.fa_knobs_reload()
+    assert full(2, 1024, 1024, 32, 2, 128, is_causal=1)[3] == 0 and ws(2, 1024, 1024, 32, 2, 128, is_causal=1) == 0
+    monkeypatch.setenv("FA_BWD_GSPLIT", "4"); lib.fa_knobs_reload()
+    assert full(8, 4096, 4096, 32, 8, 128, is_causal=1)[3] == 4                    # forced (tests): up to the knob, never past the group
+    monkeypatch.delenv("FA_BWD_GSPLIT"); lib.fa_knobs_reload()
